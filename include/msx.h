@@ -1,0 +1,143 @@
+/* msx.h -- C ABI of the MI355X (gfx950) implementation of mcmc_spec's per-walker log-likelihood path.
+ *
+ * The reference (kendallsullivan/mcmc_spec, mft6.py) is pure Python and exposes no FFI of its own
+ * (SURVEY.md §8b); this header is therefore the boundary a maintainer would bind with ctypes (the
+ * stub is shown in INTEGRATION.md).  Each entry point names the reference code it stands in for.
+ *
+ * Conventions
+ *   - every call returns MSX_OK (0) or a negative MSX_ERR_* code; nothing throws across the ABI;
+ *     msx_last_error(ctx) returns a human-readable message for the last failing call on that ctx.
+ *   - the caller owns every host buffer; they are consumed before the call returns.
+ *   - the ctx owns every device buffer.  One ctx per device; calls on one ctx must be serialised by
+ *     the caller, different ctxs may be driven concurrently from different host threads.
+ *   - all floating point data are IEEE float64, arrays are C-contiguous.
+ *   - "*_dev" entry points take DEVICE pointers and a hipStream_t (as void*) and do not synchronise.
+ */
+#ifndef MSX_H
+#define MSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSX_OK 0
+#define MSX_ERR_INVALID (-1) /* bad argument / inconsistent sizes                          */
+#define MSX_ERR_HIP (-2)     /* a HIP runtime call failed (message has the hipError string) */
+#define MSX_ERR_STATE (-3)   /* call order: grid or problem not staged yet                  */
+#define MSX_ERR_RANGE (-4)   /* a value is outside the staged tables (Python: ValueError)   */
+
+/* per-walker status written next to each log-probability (reference error conventions) */
+#define MSX_W_OK 0
+#define MSX_W_REJECT 1     /* prior box / non-finite -> log-prob = -inf        (mft6.py:1228,1230) */
+#define MSX_W_KEYERROR 2   /* a needed grid node is not staged                 (mft6.py:489-500)   */
+#define MSX_W_INDEXERROR 3 /* logg/Teff bracket runs past the last node        (mft6.py:453,477)   */
+#define MSX_W_VALUEERROR 4 /* Teff outside the isochrone table                 (mft6.py:95)        */
+
+/* evaluation modes for msx_logprob_batch* */
+#define MSX_MODE_LOGLIKE 0      /* loglikelihood   (mft6.py:1139-1205)                              */
+#define MSX_MODE_LOGPOST 1      /* logposterior = logprior gate + loglikelihood (mft6.py:1459-1470) */
+#define MSX_MODE_CHISQ 2        /* loglikelihood(optimize=True): returns total chi^2 (mft6.py:1198) */
+
+#define MSX_MAX_SPEC 3
+#define MSX_MAX_BANDS 8
+#define MSX_MAX_DIM 8
+
+typedef struct msx_ctx msx_ctx;
+
+/* Everything that is static per dataset.  Built on the host by mcmc_spec_amd/staging.py from the
+ * reference's own arguments (data, err, fr, ctm, ptm, matrix, prior ...); copied at stage time. */
+typedef struct msx_problem {
+    int32_t struct_size; /* sizeof(msx_problem), ABI check */
+    int32_t nspec;       /* 2 (binary, ndim 6) or 3 (triple, ndim 8)          mft6.py:1145,1153 */
+    int64_t npix;        /* data pixels                                                          */
+    /* A8 resample tables: for pixel p the model samples wl[lo], wl[lo+1] bracket the pixel and
+     * t = (x - x_lo)/(x_hi - x_lo)                                              mft6.py:1169-1170 */
+    const int64_t *pix_lo;
+    const double *pix_t;
+    const double *pix_u;    /* wavelength mapped to [-1,1] for the quadratic fit   mft6.py:195     */
+    const double *pix_flux; /* data (already median-normalised by the caller)      mft6.py:3507    */
+    const double *pix_err;  /* sigma per pixel                                     mft6.py:120     */
+    double median_flux;     /* np.median(data)                                     mft6.py:1173    */
+    double fit_minv[9];     /* inverse Gram matrix of [1,u,u^2] (row major)        mft6.py:195     */
+    /* A5/A6 band integrals are linear in the node spectrum: out = sum_i w[i]*flux[node][i0+i]    */
+    int32_t n_contrast;     /* contrast filters (first in the band list)           mft6.py:717     */
+    int32_t n_phot;         /* photometric bands                                   mft6.py:771     */
+    const int64_t *band_i0; /* [n_contrast+n_phot] first grid index of each band                   */
+    const int64_t *band_len;
+    const double *band_w;   /* concatenated weights                                                */
+    const double *cmag, *cerr;       /* [n_contrast] observed contrasts            mft6.py:1182    */
+    const double *pmag, *perr;       /* [n_phot] observed magnitudes               mft6.py:1188    */
+    const double *phot_zero;         /* [n_phot] zero-point flux per band          mft6.py:780-782 */
+    const double *phot_k;            /* [n_phot] CCM89 a+b/Rv at phot_cwl          mft6.py:1163    */
+    int64_t win_j0, win_n;  /* make_composite's window into the grid wavelength    mft6.py:687,542 */
+    /* A1 isochrone, sorted by Teff (stable)                                        mft6.py:87-98   */
+    int32_t niso;
+    const double *iso_teff, *iso_logg, *iso_lum;
+    /* prior                                                         mft6.py:1207-1272 */
+    int32_t nav;            /* A_V(distance) table bins; 0 = no A_V prior term                     */
+    const double *av_edges_pc; /* [nav+1] */
+    const double *av_mu, *av_sig; /* [nav] */
+    double tmin, tmax;      /* Teff box                                             mft6.py:1227    */
+    double prior_mean[MSX_MAX_DIM]; /* Gaussian priors; mean == 0 -> unused         mft6.py:1257-1260 */
+    double prior_sig[MSX_MAX_DIM];
+    int32_t use_av;         /* `a` / `av` flag                                      mft6.py:1161,1229 */
+    int32_t dist_fit;       /* only dist_fit = 1 is implemented                     mft6.py:1212    */
+    int32_t rad_prior;      /*                                                      mft6.py:1262    */
+    int32_t has_prior_list; /* `prior != 0`                                         mft6.py:1241    */
+} msx_problem;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int msx_create(int device, msx_ctx **out);
+void msx_destroy(msx_ctx *ctx);
+const char *msx_last_error(msx_ctx *ctx);
+/* device facts for reports: out[0]=CUs, out[1]=total global memory bytes, out[2]=clock kHz */
+int msx_device_info(msx_ctx *ctx, int64_t *out3, char *name, int name_len);
+
+/* ---- A0: the staged grid (replaces the `specs` dict, mft6.py:342-383 / consumed :481-500) ----- */
+/* flux is [nt][ng][nwl]; present is [nt][ng] (0 = node absent -> KeyError when touched) or NULL.  */
+int msx_stage_grid(msx_ctx *ctx, const double *wl, int64_t nwl, const double *teff_nodes, int32_t nt,
+                   const double *logg_nodes, int32_t ng, const double *flux, const uint8_t *present);
+
+/* ---- A7: CCM89 k(lambda) = a(x) + b(x)/R_V at arbitrary wavelengths [A] (extinction.ccm89 with
+ * a_v = 1, mft6.py:62); the per-grid-sample table is built inside msx_stage_grid with R_V = 3.1.  */
+int msx_ccm89_k(msx_ctx *ctx, const double *wl, int64_t n, double rv, double *out);
+
+/* ---- A3: instrumental broadening (pyasl.instrBroadGaussFast + edge patches, mft6.py:124-152) -- */
+/* one spectrum, host buffers; used by the drop-in `broaden()`                                     */
+int msx_broaden(msx_ctx *ctx, const double *wl, const double *flux, int64_t n, double resolution,
+                double maxsig, double *out);
+/* every staged node, in place, over grid samples [i0, i0+n): the staging step mft6.py:366-378     */
+int msx_broaden_grid(msx_ctx *ctx, int64_t i0, int64_t n, double resolution, double maxsig);
+/* copy one staged node back to the host (tests / the drop-in `specs` view)                        */
+int msx_read_node(msx_ctx *ctx, int32_t it, int32_t ig, double *out_nwl);
+
+/* ---- problem staging -------------------------------------------------------------------------- */
+int msx_stage_problem(msx_ctx *ctx, const msx_problem *p);
+
+/* ---- the hot path: log-probability of a whole ensemble in one launch -------------------------- */
+/* theta is [n][ndim] row-major (ndim = 2*nspec+2); logp_out [n]; status_out [n] (MSX_W_*).        */
+int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n, int32_t ndim,
+                      double *logp_out, int32_t *status_out);
+/* same with device pointers on a caller stream; does not synchronise.  block_threads = 0 -> auto  */
+int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
+                          double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
+
+/* ---- A4-A6: make_composite (mft6.py:651-831, plot=False) -------------------------------------- */
+/* teff/logg/rad are [nspec]; use_distance = 0 mirrors `distance=False` (mft6.py:701-703).         */
+/* spec_out [win_n], contrast_out [n_contrast], phot_out [n_phot] (unreddened magnitudes).         */
+int msx_make_composite(msx_ctx *ctx, const double *teff, const double *logg, const double *rad,
+                       int32_t use_distance, double plx, double *spec_out, double *contrast_out,
+                       double *phot_out, int32_t *status_out);
+
+/* ---- measurement helpers ----------------------------------------------------------------------- */
+/* float4 device-to-device copy of `bytes` bytes, `iters` times; returns GB/s (read+write counted)  */
+int msx_stream_copy_gbps(msx_ctx *ctx, int64_t bytes, int32_t iters, double *gbps_out);
+/* bytes the hot kernel requests from memory per walker for the staged problem (pair table form)   */
+int msx_bytes_per_eval(msx_ctx *ctx, int64_t *requested_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSX_H */

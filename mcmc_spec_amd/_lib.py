@@ -1,0 +1,223 @@
+"""ctypes binding of ``libmsx.so`` (the C ABI declared in ``include/msx.h``).
+
+There is no CPU fallback: if the HIP library has not been built the import of any compute entry
+point fails loudly with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmsx.so')
+
+MSX_OK = 0
+MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
+W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR = 0, 1, 2, 3, 4
+MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ = 0, 1, 2
+MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+
+class MsxProblem(C.Structure):
+    """Mirror of ``struct msx_problem`` (include/msx.h) -- keep the field order identical."""
+    _fields_ = [
+        ('struct_size', C.c_int32), ('nspec', C.c_int32), ('npix', C.c_int64),
+        ('pix_lo', _ip), ('pix_t', _dp), ('pix_u', _dp), ('pix_flux', _dp), ('pix_err', _dp),
+        ('median_flux', C.c_double), ('fit_minv', C.c_double * 9),
+        ('n_contrast', C.c_int32), ('n_phot', C.c_int32),
+        ('band_i0', _ip), ('band_len', _ip), ('band_w', _dp),
+        ('cmag', _dp), ('cerr', _dp), ('pmag', _dp), ('perr', _dp), ('phot_zero', _dp), ('phot_k', _dp),
+        ('win_j0', C.c_int64), ('win_n', C.c_int64),
+        ('niso', C.c_int32), ('iso_teff', _dp), ('iso_logg', _dp), ('iso_lum', _dp),
+        ('nav', C.c_int32), ('av_edges_pc', _dp), ('av_mu', _dp), ('av_sig', _dp),
+        ('tmin', C.c_double), ('tmax', C.c_double),
+        ('prior_mean', C.c_double * MAX_DIM), ('prior_sig', C.c_double * MAX_DIM),
+        ('use_av', C.c_int32), ('dist_fit', C.c_int32), ('rad_prior', C.c_int32), ('has_prior_list', C.c_int32),
+    ]
+
+
+class MsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('msx error {}: {}'.format(code, msg))
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def load():
+    """Load ``libmsx.so`` once.  Raises ImportError with the build recipe if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'mcmc_spec_amd: the HIP library {} is missing. Build it with\n'
+            '  python -c "import __graft_entry__ as g; g.build()"   (or: make -C mcmc_spec_amd/csrc)\n'
+            'There is no CPU fallback for the log-likelihood path.'.format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        'msx_create': (C.c_int, [C.c_int, C.POINTER(vp)]),
+        'msx_destroy': (None, [vp]),
+        'msx_last_error': (C.c_char_p, [vp]),
+        'msx_device_info': (C.c_int, [vp, _ip, C.c_char_p, C.c_int]),
+        'msx_stage_grid': (C.c_int, [vp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.POINTER(C.c_uint8)]),
+        'msx_ccm89_k': (C.c_int, [vp, _dp, C.c_int64, C.c_double, _dp]),
+        'msx_broaden': (C.c_int, [vp, _dp, _dp, C.c_int64, C.c_double, C.c_double, _dp]),
+        'msx_broaden_grid': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_double, C.c_double]),
+        'msx_read_node': (C.c_int, [vp, C.c_int32, C.c_int32, _dp]),
+        'msx_stage_problem': (C.c_int, [vp, C.POINTER(MsxProblem)]),
+        'msx_logprob_batch': (C.c_int, [vp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
+        'msx_logprob_batch_dev': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32]),
+        'msx_make_composite': (C.c_int, [vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp,
+                                         C.POINTER(C.c_int32)]),
+        'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
+        'msx_bytes_per_eval': (C.c_int, [vp, _ip]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library skew, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
+            'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
+            'msx_logprob_batch_dev', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Context:
+    """One ``msx_ctx`` (one device).  Thin, typed wrapper; all numerics happen in the library."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.msx_create(int(device), C.byref(h))
+        self.h = h
+        if rc != MSX_OK:
+            msg = self.lib.msx_last_error(h).decode() if h else 'allocation failed'
+            if h:
+                self.lib.msx_destroy(h)
+                self.h = None
+            raise MsxError(rc, msg)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.msx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != MSX_OK:
+            msg = self.lib.msx_last_error(self.h).decode()
+            if rc == MSX_ERR_RANGE:
+                raise ValueError(msg)
+            raise MsxError(rc, msg)
+
+    # ---- device ---------------------------------------------------------------------------------
+    def device_info(self):
+        out = np.zeros(3, dtype=np.int64)
+        name = C.create_string_buffer(256)
+        self.check(self.lib.msx_device_info(self.h, iptr(out), name, 256))
+        return {'name': name.value.decode(), 'cus': int(out[0]), 'mem_bytes': int(out[1]), 'clock_khz': int(out[2])}
+
+    def stream_copy_gbps(self, nbytes=1 << 30, iters=10):
+        out = C.c_double()
+        self.check(self.lib.msx_stream_copy_gbps(self.h, int(nbytes), int(iters), C.byref(out)))
+        return out.value
+
+    # ---- grid -----------------------------------------------------------------------------------
+    def stage_grid(self, wl, teff_nodes, logg_nodes, flux, present=None):
+        wl, teff_nodes, logg_nodes = as_f64(wl), as_f64(teff_nodes), as_f64(logg_nodes)
+        flux = as_f64(flux)
+        nt, ng, nwl = len(teff_nodes), len(logg_nodes), len(wl)
+        if flux.shape != (nt, ng, nwl):
+            raise ValueError('flux must be [nt][ng][nwl]')
+        pp = None
+        if present is not None:
+            present = np.ascontiguousarray(present, dtype=np.uint8)
+            pp = present.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.check(self.lib.msx_stage_grid(self.h, dptr(wl), nwl, dptr(teff_nodes), nt, dptr(logg_nodes), ng,
+                                           dptr(flux), pp))
+        self.nwl = nwl
+
+    def ccm89_k(self, wl, rv=3.1):
+        wl = as_f64(np.atleast_1d(wl))
+        out = np.empty_like(wl)
+        self.check(self.lib.msx_ccm89_k(self.h, dptr(wl), len(wl), float(rv), dptr(out)))
+        return out
+
+    def broaden(self, wl, flux, resolution, maxsig=5.0):
+        wl, flux = as_f64(wl), as_f64(flux)
+        out = np.empty_like(flux)
+        self.check(self.lib.msx_broaden(self.h, dptr(wl), dptr(flux), len(wl), float(resolution), float(maxsig),
+                                        dptr(out)))
+        return out
+
+    def broaden_grid(self, i0, n, resolution, maxsig=5.0):
+        self.check(self.lib.msx_broaden_grid(self.h, int(i0), int(n), float(resolution), float(maxsig)))
+
+    def read_node(self, it, ig):
+        out = np.empty(self.nwl)
+        self.check(self.lib.msx_read_node(self.h, int(it), int(ig), dptr(out)))
+        return out
+
+    # ---- problem + hot path -----------------------------------------------------------------------
+    def stage_problem(self, prob: MsxProblem):
+        self.check(self.lib.msx_stage_problem(self.h, C.byref(prob)))
+
+    def logprob_batch(self, theta, mode=MODE_LOGPOST):
+        theta = as_f64(theta)
+        n, ndim = theta.shape
+        logp = np.empty(n)
+        status = np.empty(n, dtype=np.int32)
+        self.check(self.lib.msx_logprob_batch(self.h, int(mode), dptr(theta), n, ndim, dptr(logp),
+                                              status.ctypes.data_as(C.POINTER(C.c_int32))))
+        return logp, status
+
+    def logprob_batch_dev(self, d_theta_ptr, n, ndim, d_logp_ptr, d_status_ptr, stream_ptr, mode=MODE_LOGPOST,
+                          block_threads=0):
+        self.check(self.lib.msx_logprob_batch_dev(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim),
+                                                  C.c_void_p(d_logp_ptr), C.c_void_p(d_status_ptr),
+                                                  C.c_void_p(stream_ptr), int(block_threads)))
+
+    def make_composite(self, teff, logg, rad, use_distance, plx, win_n, nc, nph):
+        teff, logg, rad = as_f64(teff), as_f64(logg), as_f64(rad)
+        spec = np.empty(win_n)
+        con = np.empty(max(nc, 1))
+        ph = np.empty(max(nph, 1))
+        st = C.c_int32()
+        self.check(self.lib.msx_make_composite(self.h, dptr(teff), dptr(logg), dptr(rad), int(bool(use_distance)),
+                                               float(plx), dptr(spec), dptr(con), dptr(ph), C.byref(st)))
+        return spec, con[:nc], ph[:nph], st.value
+
+    def bytes_per_eval(self):
+        out = C.c_int64()
+        self.check(self.lib.msx_bytes_per_eval(self.h, C.byref(out)))
+        return out.value

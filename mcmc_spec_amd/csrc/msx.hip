@@ -1,0 +1,1237 @@
+// msx.hip -- gfx950 (CDNA4) kernels + C ABI for mcmc_spec's per-walker log-likelihood path.
+//
+// What is in here (rows of SURVEY.md §8a; reference = /root/reference/mft6.py):
+//   A0  staged grid [nt][ng][nwl] in HBM                      (specs dict, :342-383)
+//   A1  isochrone Teff -> logg / luminosity lookup            (get_logg :87-98, get_radius :66-85)
+//   A2  nearest-node bracket + bilinear blend                 (get_spec :387-563)
+//   A3  Gaussian instrumental broadening, LDS-tiled FIR       (broaden :124-152 -> instrBroadGaussFast)
+//   A4  flux scaling + component sum                          (make_composite :687-707,:740-751)
+//   A5  contrast magnitudes via per-node band integrals       (:713-741)
+//   A6  unresolved photometry via per-node band integrals     (:755-783)
+//   A7  CCM89 reddening                                       (extinct :46-64)
+//   A8  resample to data pixels, median scale, quadratic fit  (:1169-1174, norm_spec :193-196)
+//   A9  chi^2 + combine                                       (chisq :115-122, :1178-1205)
+//   f1  prior box + Gaussian terms                            (logprior :1207-1272, logposterior :1459-1470)
+//
+// Design notes (details in DESIGN.md):
+//   * one workgroup per walker; the walker's Npix-long model vector lives in LDS for the exact
+//     median (radix select), the 3-term fit and the chi^2 pass; all sums are float64 with a fixed
+//     reduction order (wave shuffles, then LDS across waves) -> bit-reproducible run to run.
+//   * the resample (A8) only ever touches the two model samples bracketing each data pixel, and
+//     those indices are static per dataset, so staging gathers them once into a pixel-major
+//     "pair table" pairs[node][pix] = {flux[lo], flux[lo+1]}: every hot-loop load is a 16-byte
+//     per-lane, fully coalesced read (1 KiB per wave instruction).
+//   * wave = 64 lanes everywhere; no MFMA (nothing here is a GEMM); no CUDA-compat shims.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/msx.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxWaves = 16;            // 1024 threads
+constexpr int kMaxCorners = MSX_MAX_SPEC * 4;
+constexpr int kMaxBandsTotal = 2 * MSX_MAX_BANDS;
+constexpr int kSelectFinish = 256;       // radix select switches to all-pairs ranking at this many candidates
+constexpr double kRsunCm = 6.957e10;     // mft6.py:691
+constexpr double kPcCm = 3.086e18;       // mft6.py:691
+constexpr double kLog2Of10 = 3.321928094887362347870319429489390175864831393024580612054;
+
+// ------------------------------------------------------------------------------------------------
+// Device-side view of everything staged.  Passed to kernels by value (well under the 4 KiB limit).
+// ------------------------------------------------------------------------------------------------
+struct DevProblem {
+    // grid (A0)
+    const double *grid;   // [nt*ng][nwl]
+    const double *kgrid;  // [nwl]  CCM89 a + b/3.1 per grid sample (A7)
+    int64_t nwl;
+    int32_t nt, ng;
+    const double *teff_nodes;
+    const double *logg_nodes;
+    const uint8_t *present;
+    // pixel tables (A8)
+    const double2 *pairs;  // [nt*ng][npix] {flux[lo], flux[lo+1]}
+    const double2 *pix_k;  // [npix] {k[lo], k[lo+1]}
+    const double *pix_t, *pix_u, *pix_flux, *pix_err;
+    int64_t npix;
+    double median_flux;
+    double minv[9];
+    // bands (A5/A6)
+    int32_t nc, np;
+    const double *band_tab;  // [nt*ng][nc+np]
+    double cmag[MSX_MAX_BANDS], cerr[MSX_MAX_BANDS];
+    double pmag[MSX_MAX_BANDS], perr[MSX_MAX_BANDS], pzero[MSX_MAX_BANDS], pk[MSX_MAX_BANDS];
+    int64_t win_j0, win_n;
+    // isochrone (A1)
+    int32_t niso;
+    const double *iso_t, *iso_g, *iso_l;
+    // prior (f1)
+    int32_t nav;
+    const double *av_edges, *av_mu, *av_sig;
+    double tmin, tmax;
+    double pmean[MSX_MAX_DIM], psig[MSX_MAX_DIM];
+    int32_t use_av, dist_fit, rad_prior, has_prior;
+    int32_t nspec;
+};
+
+// Per-walker recipe computed once by one lane and broadcast through LDS.
+struct WalkerDesc {
+    int32_t node[kMaxCorners];   // flat node index it*ng+ig of each corner
+    double w[kMaxCorners];       // bilinear weight * (R/d)^2 scale
+    double redc;                 // exp2 coefficient -0.4*log2(10)*A_V; 0 -> no reddening (A_V <= 0)
+    double lp;                   // log prior (0 in LOGLIKE mode)
+    double chi_extra;            // icontrast + iphot                        mft6.py:1183,1189
+    double contrast[MSX_MAX_BANDS];
+    double phot[MSX_MAX_BANDS];
+    int32_t status;
+    int32_t ncorner;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_down(v, o, kWave);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_down(v, o, kWave);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// order-preserving map double -> uint64 (NaN with sign bit clear sorts above +inf, like np.sort)
+__device__ __forceinline__ unsigned long long key_of(double x) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double val_of(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// np.interp semantics on a table sorted in x (what scipy's interp1d(kind='linear') evaluates for
+// 1-D float64 input); returns false when x is outside [x0, xn-1] (interp1d raises ValueError).
+__device__ bool table_interp(const double *xs, const double *ys, int n, double x, double *out) {
+    if (!(x >= xs[0]) || !(x <= xs[n - 1])) return false;
+    int lo = 0, hi = n;  // upper_bound: first index with xs[i] > x
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    int j = lo - 1;
+    if (j >= n - 1) { *out = ys[n - 1]; return true; }
+    if (xs[j] == x) { *out = ys[j]; return true; }
+    double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
+    *out = slope * (x - xs[j]) + ys[j];
+    return true;
+}
+
+// mft6.py:439-453 / :467-477.  Nearest node first (first index on ties), then its neighbour on the
+// other side; Python index semantics: -1 wraps to the last node, == n is an IndexError.
+__device__ int bracket_nodes(const double *nodes, int n, double v, int *i1, int *i2) {
+    int best = 0;
+    double bd = fabs(nodes[0] - v);
+    for (int i = 1; i < n; ++i) {
+        double d = fabs(nodes[i] - v);
+        if (d < bd) { bd = d; best = i; }
+    }
+    int other;
+    if (nodes[best] == v) other = best;
+    else if (nodes[best] > v) other = best - 1;
+    else other = best + 1;
+    if (other == -1) other = n - 1;
+    if (other >= n) return MSX_W_INDEXERROR;
+    *i1 = best;
+    *i2 = other;
+    return MSX_W_OK;
+}
+
+// Build the corner list + weights for every star (A2 + A4) and the band terms (A5/A6).
+// Executed by ONE lane.  rad[] is the reference's rad_guess = [R1, R2/R1, (R3/R1)].
+__device__ void build_desc(const DevProblem &P, const double *teff, const double *logg, const double *rad,
+                           bool use_distance, double plx, double a_v, WalkerDesc *D) {
+    const int ns = P.nspec;
+    D->status = MSX_W_OK;
+    D->ncorner = ns * 4;
+    double starscale[MSX_MAX_SPEC];
+    for (int s = 0; s < ns; ++s) {
+        int t1, t2, g1, g2;
+        int st = bracket_nodes(P.teff_nodes, P.nt, teff[s], &t1, &t2);
+        if (st == MSX_W_OK) st = bracket_nodes(P.logg_nodes, P.ng, logg[s], &g1, &g2);
+        if (st != MSX_W_OK) { D->status = st; return; }
+        // the reference looks up all four keys unless both axes are on-node (mft6.py:488-500)
+        int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+        if (!P.present[n11] || !P.present[n12] || !P.present[n21] || !P.present[n22]) {
+            D->status = MSX_W_KEYERROR;
+            return;
+        }
+        double a = (g1 == g2) ? 0.0 : (logg[s] - P.logg_nodes[g1]) / (P.logg_nodes[g2] - P.logg_nodes[g1]);
+        double b = (t1 == t2) ? 0.0 : (teff[s] - P.teff_nodes[t1]) / (P.teff_nodes[t2] - P.teff_nodes[t1]);
+        double sc;
+        if (use_distance) {
+            double di = 1.0 / plx;  // mft6.py:690
+            double r = (s == 0) ? rad[0] : rad[0] * rad[s];
+            double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+            sc = q * q;
+        } else {
+            sc = (s == 0) ? 1.0 : rad[s - 1] * rad[s - 1];  // mft6.py:703
+        }
+        starscale[s] = sc;
+        D->node[4 * s + 0] = n11; D->w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
+        D->node[4 * s + 1] = n12; D->w[4 * s + 1] = (1.0 - b) * a * sc;
+        D->node[4 * s + 2] = n21; D->w[4 * s + 2] = b * (1.0 - a) * sc;
+        D->node[4 * s + 3] = n22; D->w[4 * s + 3] = b * a * sc;
+    }
+    (void)starscale;
+    const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
+    D->redc = redden ? -0.4 * kLog2Of10 * a_v : 0.0;
+    const int nb = P.nc + P.np;
+    double chi = 0.0;
+    // contrasts: instrumental magnitude of each star through each filter (A5)
+    for (int f = 0; f < P.nc; ++f) {
+        double mag[MSX_MAX_SPEC];
+        for (int s = 0; s < ns; ++s) {
+            double m = 0.0;
+            for (int c = 0; c < 4; ++c) m += D->w[4 * s + c] * P.band_tab[(int64_t)D->node[4 * s + c] * nb + f];
+            mag[s] = -2.5 * log10(m);  // mft6.py:733
+        }
+        int sec = 1;
+        if (ns == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+        double con = mag[sec] - mag[0];
+        D->contrast[f] = con;
+        double z = (con - P.cmag[f]);
+        chi += (z * z) / (P.cerr[f] * P.cerr[f]);  // mft6.py:120,1182
+    }
+    // unresolved photometry of the composite (A6) + reddening of the magnitudes (mft6.py:1163)
+    for (int f = 0; f < P.np; ++f) {
+        double flux = 0.0;
+        for (int c = 0; c < ns * 4; ++c) flux += D->w[c] * P.band_tab[(int64_t)D->node[c] * nb + P.nc + f];
+        double mag = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+        D->phot[f] = mag;
+        double mred = redden ? mag + a_v * P.pk[f] : mag;
+        double z = mred - P.pmag[f];
+        chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
+    }
+    D->chi_extra = chi;
+}
+
+// logprior for one walker (mft6.py:1207-1272 ndim 6; :1329-1393 ndim 8).  Returns false -> -inf.
+__device__ bool log_prior(const DevProblem &P, const double *th, int ndim, double *lp_out, int *status) {
+    const int ns = P.nspec;
+    const double *T = th;
+    const double a_v = th[ns];
+    const double *rad = th + ns + 1;
+    const double plx = th[2 * ns + 1];
+    for (int s = 0; s < ns; ++s)
+        if (T[s] > P.tmax || T[s] < P.tmin) return false;
+    for (int s = 0; s < ns; ++s)
+        if (rad[s] < 0.05) return false;
+    if (ns == 2) {
+        if (rad[0] > 1.5 || plx < 1.0 / 3000 || plx > 1.0 / 4) return false;  // mft6.py:1227
+    } else {
+        if (plx < 1.0 / 1000 || plx > 1.0 / 4) return false;  // mft6.py:1347
+    }
+    double lp = 0.0;
+    if (P.use_av) {
+        if (a_v < 0.0) return false;  // mft6.py:1229
+        if (P.nav > 0) {
+            double d = 1.0 / plx;  // pc, mft6.py:1233
+            int lo = 0, hi = P.nav + 1;  // searchsorted(edges, d, 'right') - 1, clipped
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (P.av_edges[mid] <= d) lo = mid + 1; else hi = mid;
+            }
+            int b = lo - 1;
+            b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
+            double sig = P.av_sig[b];
+            if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
+            double z = (a_v - P.av_mu[b]) / sig;
+            lp += -0.5 * (z * z);
+        }
+    }
+    if (P.has_prior) {
+        for (int k = 0; k < ndim; ++k) {
+            if (P.pmean[k] != 0.0) {  // mft6.py:1258
+                double z = (th[k] - P.pmean[k]) / P.psig[k];
+                lp += -0.5 * (z * z);
+            }
+        }
+    }
+    if (P.rad_prior) {  // mft6.py:1262-1269
+        double mr[MSX_MAX_SPEC];
+        for (int s = 0; s < ns; ++s) {
+            double lum;
+            if (!table_interp(P.iso_t, P.iso_l, P.niso, T[s], &lum)) { *status = MSX_W_VALUEERROR; return false; }
+            const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
+            double t2 = T[s] * T[s];
+            mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+        }
+        for (int s = 0; s < ns; ++s) {
+            double target = (s == 0) ? mr[0] : mr[s] / mr[0];
+            double z = (rad[s] - target) / (0.02 * target);
+            lp += -0.5 * (z * z);
+        }
+    }
+    *lp_out = lp;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-level reductions (fixed order: lanes via shuffles, then waves 0..nw-1 serially)
+// ------------------------------------------------------------------------------------------------
+struct BlockScratch {
+    double d[4][kMaxWaves];
+    unsigned long long u[2][kMaxWaves];
+    unsigned int hist[256];
+    unsigned long long cand[kSelectFinish];
+    unsigned long long sel_prefix;
+    unsigned long long sel_result[2];
+    unsigned int sel_bin, sel_k, sel_cnt, cand_n;
+    unsigned int cnt_le;
+};
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], BlockScratch &S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double r = wave_sum(v[i]);
+        if (lane == 0) S.d[i][wave] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double r = 0.0;
+        for (int w = 0; w < nw; ++w) r += S.d[i][w];
+        v[i] = r;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE HOT KERNEL: one workgroup per walker.
+// ------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+
+template <int NS>
+__global__ void __launch_bounds__(1024)
+logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t n, int ndim,
+               double *__restrict__ logp, int32_t *__restrict__ status) {
+    __shared__ WalkerDesc D;
+    __shared__ BlockScratch S;
+    double *model = reinterpret_cast<double *>(dyn_lds);  // [npix]
+
+    const int64_t wk = blockIdx.x;
+    if (wk >= n) return;
+    const int tid = threadIdx.x, B = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    const int npix = (int)P.npix;
+
+    // ---- phase 0: one lane builds the walker's recipe (prior gate, A1, A2, A4, A5, A6) ----------
+    if (tid == 0) {
+        const double *th = theta + wk * ndim;
+        D.status = MSX_W_OK;
+        D.lp = 0.0;
+        bool alive = true;
+        for (int k = 0; k < ndim; ++k)
+            if (!isfinite(th[k])) alive = false;  // emcee refuses non-finite coordinates anyway
+        int st = MSX_W_OK;
+        if (alive && mode == MSX_MODE_LOGPOST) {
+            double lp = 0.0;
+            alive = log_prior(P, th, ndim, &lp, &st);
+            D.lp = lp;
+        }
+        if (st != MSX_W_OK) {
+            D.status = st;
+        } else if (!alive) {
+            D.status = MSX_W_REJECT;
+        } else {
+            double lg[MSX_MAX_SPEC];
+            bool ok = true;
+            for (int s = 0; s < NS; ++s) ok = ok && table_interp(P.iso_t, P.iso_g, P.niso, th[s], &lg[s]);  // A1
+            if (!ok) {
+                D.status = MSX_W_VALUEERROR;
+            } else {
+                build_desc(P, th, lg, th + NS + 1, true, th[2 * NS + 1], th[NS], &D);
+            }
+        }
+    }
+    __syncthreads();
+    if (D.status != MSX_W_OK) {
+        if (tid == 0) {
+            logp[wk] = (D.status == MSX_W_REJECT) ? -INFINITY : NAN;
+            status[wk] = D.status;
+        }
+        return;
+    }
+
+    // ---- phase A: blend 4 corners x NS stars at the two bracketing samples of each pixel, redden,
+    //      resample (A2+A4+A7+A8.1); accumulate the fit sums of data/model and the key range --------
+    const double2 *rows[NS * 4];
+    double w[NS * 4];
+#pragma unroll
+    for (int c = 0; c < NS * 4; ++c) {
+        rows[c] = P.pairs + (int64_t)D.node[c] * npix;
+        w[c] = D.w[c];
+    }
+    const double redc = D.redc;
+    const bool redden = redc != 0.0;
+    double q[3] = {0.0, 0.0, 0.0};
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (int p = tid; p < npix; p += B) {
+        double ylo = 0.0, yhi = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS * 4; ++c) {
+            const double2 v = rows[c][p];
+            ylo = fma(w[c], v.x, ylo);
+            yhi = fma(w[c], v.y, yhi);
+        }
+        if (redden) {
+            const double2 k = P.pix_k[p];
+            ylo *= exp2(redc * k.x);  // 10^(-0.4 A_V k)                mft6.py:62-63
+            yhi *= exp2(redc * k.y);
+        }
+        const double m = fma(yhi - ylo, P.pix_t[p], ylo);  // mft6.py:1169-1170
+        model[p] = m;
+        const double f = P.pix_flux[p] / m;  // frac before the median scale, mft6.py:194
+        const double u = P.pix_u[p];
+        q[0] += f;
+        q[1] += f * u;
+        q[2] += f * (u * u);
+        const unsigned long long key = key_of(m);
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+    }
+    block_sum<3>(q, S);
+    {
+        unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
+        if (lane == 0) { S.u[0][wave] = a; S.u[1][wave] = b; }
+        __syncthreads();
+        kmin = S.u[0][0]; kmax = S.u[1][0];
+        for (int i = 1; i < nw; ++i) {
+            kmin = S.u[0][i] < kmin ? S.u[0][i] : kmin;
+            kmax = S.u[1][i] > kmax ? S.u[1][i] : kmax;
+        }
+        __syncthreads();
+    }
+
+    // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
+    if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
+        if (tid == 0) {
+            logp[wk] = (mode == MSX_MODE_CHISQ) ? NAN : -INFINITY;
+            status[wk] = MSX_W_OK;
+        }
+        return;
+    }
+
+    // ---- phase B: exact median of model[0..npix) (np.median, mft6.py:1173) by radix select --------
+    // k1 = lower middle (0-based); for even npix the median is the mean of ranks k1 and k1+1.
+    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
+    const bool need_two = (npix & 1) == 0;
+    unsigned long long v1 = kmin;
+    if (kmin != kmax) {
+        int hb = 63 - __clzll((long long)(kmin ^ kmax));  // highest differing bit
+        int shift = hb + 1;
+        unsigned long long pmask = (shift >= 64) ? 0ull : ~((1ull << shift) - 1ull);
+        unsigned long long pval = kmin & pmask;
+        unsigned int k = k1;
+        bool done = false;
+        while (shift > 0 && !done) {
+            const int bits = shift < 8 ? shift : 8;
+            shift -= bits;
+            const unsigned int dmask = (1u << bits) - 1u;
+            if (tid < 256) S.hist[tid] = 0;
+            __syncthreads();
+            for (int p = tid; p < npix; p += B) {
+                const unsigned long long key = key_of(model[p]);
+                if ((key & pmask) == pval) atomicAdd(&S.hist[(unsigned int)(key >> shift) & dmask], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {  // locate the bin holding rank k: 4 bins per lane + wave inclusive scan
+                unsigned int c0 = S.hist[4 * lane], c1 = S.hist[4 * lane + 1], c2 = S.hist[4 * lane + 2],
+                             c3 = S.hist[4 * lane + 3];
+                unsigned int tot = c0 + c1 + c2 + c3, inc = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    unsigned int t = __shfl_up(inc, o, kWave);
+                    if (lane >= o) inc += t;
+                }
+                const unsigned long long ball = __ballot(inc > k);
+                const int L = __ffsll((long long)ball) - 1;
+                if (lane == L) {
+                    unsigned int kk = k - (inc - tot);
+                    unsigned int bin, cnt;
+                    if (kk < c0) { bin = 0; cnt = c0; }
+                    else if ((kk -= c0) < c1) { bin = 1; cnt = c1; }
+                    else if ((kk -= c1) < c2) { bin = 2; cnt = c2; }
+                    else { kk -= c2; bin = 3; cnt = c3; }
+                    S.sel_bin = 4 * L + bin;
+                    S.sel_k = kk;
+                    S.sel_cnt = cnt;
+                    S.cand_n = 0;
+                }
+            }
+            __syncthreads();
+            k = S.sel_k;
+            const unsigned int cnt = S.sel_cnt;
+            pval |= ((unsigned long long)S.sel_bin) << shift;
+            pmask |= ((unsigned long long)dmask) << shift;
+            if (shift == 0) {
+                v1 = pval;  // every remaining candidate equals the prefix
+                done = true;
+            } else if (cnt <= (unsigned int)kSelectFinish) {
+                // finish: gather the candidates and rank them all-pairs (ties broken by slot)
+                for (int p = tid; p < npix; p += B) {
+                    const unsigned long long key = key_of(model[p]);
+                    if ((key & pmask) == pval) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+                }
+                __syncthreads();
+                if (tid < (int)cnt) {
+                    const unsigned long long mine = S.cand[tid];
+                    unsigned int r = 0;
+                    for (unsigned int j = 0; j < cnt; ++j) {
+                        const unsigned long long o = S.cand[j];
+                        r += (o < mine) || (o == mine && j < (unsigned int)tid);
+                    }
+                    if (r == k) S.sel_result[0] = mine;
+                }
+                __syncthreads();
+                v1 = S.sel_result[0];
+                done = true;
+            }
+            __syncthreads();
+        }
+    }
+    double med_model = val_of(v1);
+    if (need_two && kmin != kmax) {
+        // rank k1+1: equals v1 when v1 is duplicated past rank k1, else the smallest key above v1
+        unsigned int cle = 0;
+        unsigned long long nxt = ~0ull;
+        for (int p = tid; p < npix; p += B) {
+            const unsigned long long key = key_of(model[p]);
+            cle += key <= v1;
+            if (key > v1 && key < nxt) nxt = key;
+        }
+        if (tid == 0) S.cnt_le = 0;
+        __syncthreads();
+        unsigned int wc = cle;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wc += __shfl_down(wc, o, kWave);
+        nxt = wave_min_u64(nxt);
+        if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.u[0][wave] = nxt; }
+        __syncthreads();
+        unsigned long long v2 = S.u[0][0];
+        for (int i = 1; i < nw; ++i) v2 = S.u[0][i] < v2 ? S.u[0][i] : v2;
+        if (S.cnt_le >= k1 + 2) v2 = v1;
+        med_model = (val_of(v1) + val_of(v2)) / 2.0;  // np.median: mean of the two middle values
+        __syncthreads();
+    }
+
+    // ---- phase C: median scale, quadratic continuum fit, chi^2 (A8.2, A8.3, A9) ------------------
+    const double scale = P.median_flux / med_model;  // mft6.py:1173
+    double coef[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
+    double chi[1] = {0.0};
+    for (int p = tid; p < npix; p += B) {
+        const double ms = model[p] * scale;
+        const double u = P.pix_u[p];
+        const double poly = fma(fma(coef[2], u, coef[1]), u, coef[0]);
+        const double dn = P.pix_flux[p] / poly;  // mft6.py:196
+        const double r = ms - dn;
+        const double e = P.pix_err[p];
+        chi[0] += (r * r) / (e * e);  // mft6.py:120
+    }
+    block_sum<1>(chi, S);
+    if (tid == 0) {
+        const double iic = chi[0] / (double)npix;  // mft6.py:1179
+        const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191
+        double out;
+        if (mode == MSX_MODE_CHISQ) out = total;  // mft6.py:1198-1199
+        else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
+        logp[wk] = out;
+        status[wk] = MSX_W_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// staging kernels
+// ------------------------------------------------------------------------------------------------
+// CCM89 k(lambda) = a(x) + b(x)/R_V, x = 1e4/lambda[A] (A7; coefficients of Cardelli+ 1989)
+__global__ void ccm89_kernel(const double *__restrict__ wl, int64_t n, double rv, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = 1e4 / wl[i];
+    double a, b;
+    if (x < 1.1) {
+        const double y = pow(x, 1.61);
+        a = 0.574 * y;
+        b = -0.527 * y;
+    } else if (x < 3.3) {
+        const double y = x - 1.82;
+        a = ((((((0.329990 * y - 0.77530) * y + 0.01979) * y + 0.72085) * y - 0.02427) * y - 0.50447) * y + 0.17699) * y + 1.0;
+        b = ((((((-2.09002 * y + 5.30260) * y - 0.62251) * y - 5.38434) * y + 1.07233) * y + 2.28305) * y + 1.41338) * y;
+    } else if (x < 8.0) {
+        a = 1.752 - 0.316 * x - 0.104 / ((x - 4.67) * (x - 4.67) + 0.341);
+        b = -3.090 + 1.825 * x + 1.206 / ((x - 4.62) * (x - 4.62) + 0.263);
+        if (x >= 5.9) {
+            const double y = x - 5.9;
+            a += -0.04473 * (y * y) - 0.009779 * (y * y * y);
+            b += 0.2130 * (y * y) + 0.1207 * (y * y * y);
+        }
+    } else {
+        const double y = x - 8.0;
+        a = -0.070 * (y * y * y) + 0.137 * (y * y) - 0.628 * y - 1.073;
+        b = 0.374 * (y * y * y) - 0.420 * (y * y) + 4.257 * y + 13.670;
+    }
+    out[i] = a + b / rv;
+}
+
+// pairs[node][p] = {grid[node][lo_p], grid[node][lo_p+1]};  node = blockIdx.y
+__global__ void gather_pairs_kernel(const double *__restrict__ grid, int64_t nwl, const int64_t *__restrict__ lo,
+                                    int64_t npix, double2 *__restrict__ pairs) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const double *row = grid + (int64_t)blockIdx.y * nwl;
+    const int64_t j = lo[p];
+    pairs[(int64_t)blockIdx.y * npix + p] = make_double2(row[j], row[j + 1]);
+}
+
+// band_tab[node][b] = sum_i w_b[i] * grid[node][i0_b + i];  grid.x = band, grid.y = node
+__global__ void band_integral_kernel(const double *__restrict__ grid, int64_t nwl, const double *__restrict__ w,
+                                     const int64_t *__restrict__ woff, const int64_t *__restrict__ i0,
+                                     const int64_t *__restrict__ len, int nb, double *__restrict__ tab) {
+    __shared__ double part[kMaxWaves];
+    const int b = blockIdx.x, node = blockIdx.y;
+    const double *row = grid + (int64_t)node * nwl + i0[b];
+    const double *wb = w + woff[b];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < len[b]; i += blockDim.x) acc = fma(wb[i], row[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += part[i];
+        tab[(int64_t)node * nb + b] = r;
+    }
+}
+
+// A3: out[n] = sum_k e[k] * y[n + c - k], zero outside [0, N)  (np.convolve(y, e, 'same'), c=(lx-1)/2)
+// e = normalised Gaussian taps built in LDS by every block; tile of y staged through LDS.
+constexpr int kConvTile = 1024;
+__global__ void __launch_bounds__(256)
+broaden_conv_kernel(const double *__restrict__ in, int64_t in_stride, double *__restrict__ out, int64_t out_stride,
+                    int64_t n, int lx, double dx, double sigma) {
+    double *taps = reinterpret_cast<double *>(dyn_lds);  // [lx]
+    double *tile = taps + lx;                             // [kConvTile + lx - 1]
+    __shared__ double part[4];
+    const int tid = threadIdx.x;
+    const int c = (lx - 1) / 2;
+    const int off0 = lx / 2 + lx % 2 - 1;  // nx[k] = (k - off0) * dx   (PyAstronomy broadGaussFast)
+    double acc = 0.0;
+    for (int k = tid; k < lx; k += 256) {
+        const double x = (double)(k - off0) * dx;
+        const double e = exp(-(x * x) / (2.0 * (sigma * sigma)));
+        taps[k] = e;
+        acc += e;
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    const double norm = (part[0] + part[1]) + (part[2] + part[3]);
+    const double *row = in + (int64_t)blockIdx.y * in_stride;
+    const int64_t t0 = (int64_t)blockIdx.x * kConvTile;
+    const int64_t g0 = t0 + c - (lx - 1);  // global index of tile[0]
+    for (int j = tid; j < kConvTile + lx - 1; j += 256) {
+        const int64_t g = g0 + j;
+        tile[j] = (g >= 0 && g < n) ? row[g] : 0.0;
+    }
+    for (int k = tid; k < lx; k += 256) taps[k] = taps[k] / norm;
+    __syncthreads();
+    double *orow = out + (int64_t)blockIdx.y * out_stride;
+#pragma unroll
+    for (int r = 0; r < kConvTile / 256; ++r) {
+        const int nl = tid + r * 256;
+        if (t0 + nl >= n) break;
+        double s = 0.0;
+        const double *tp = tile + nl + (lx - 1);
+        for (int k = 0; k < lx; ++k) s = fma(taps[k], tp[-k], s);
+        orow[t0 + nl] = s;
+    }
+}
+
+// edge patches broad[0:5] = broad[5]; broad[n-10:n] = broad[n-11] (mft6.py:129-130) while copying
+__global__ void broaden_patch_kernel(const double *__restrict__ tmp, int64_t tmp_stride, double *__restrict__ dst,
+                                     int64_t dst_stride, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t src = i;
+    if (i < 5) src = 5;
+    if (i >= n - 10) src = n - 11;
+    dst[(int64_t)blockIdx.y * dst_stride + i] = tmp[(int64_t)blockIdx.y * tmp_stride + src];
+}
+
+// make_composite (A4-A6): one lane builds the recipe, then an elementwise blend over the window
+__global__ void composite_setup_kernel(DevProblem P, const double *__restrict__ args, int use_distance,
+                                       WalkerDesc *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // args = teff[ns], logg[ns], rad[ns], plx
+    const int ns = P.nspec;
+    WalkerDesc D;
+    build_desc(P, args, args + ns, args + 2 * ns, use_distance != 0, args[3 * ns], 0.0, &D);
+    *out = D;
+}
+
+__global__ void composite_kernel(DevProblem P, const WalkerDesc *__restrict__ Dp, double *__restrict__ spec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.win_n || Dp->status != MSX_W_OK) return;
+    const int nc = Dp->ncorner;
+    // the reference sums star by star: spec1 = pri + sec (+ ter)     mft6.py:744,751
+    double total = 0.0;
+    for (int s = 0; s < nc / 4; ++s) {
+        double acc = 0.0;
+        for (int c = 0; c < 4; ++c)
+            acc = fma(Dp->w[4 * s + c], P.grid[(int64_t)Dp->node[4 * s + c] * P.nwl + P.win_j0 + i], acc);
+        total += acc;
+    }
+    spec[i] = total;
+}
+
+__global__ void copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side: context + C ABI
+// ================================================================================================
+struct msx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    // grid
+    int64_t nwl = 0;
+    int nt = 0, ng = 0;
+    std::vector<double> h_wl;
+    double *d_grid = nullptr, *d_wl = nullptr, *d_kgrid = nullptr, *d_teff = nullptr, *d_logg = nullptr;
+    uint8_t *d_present = nullptr;
+    bool grid_staged = false;
+    // problem
+    bool problem_staged = false;
+    DevProblem P;
+    std::vector<void *> prob_allocs;
+    // scratch for host-pointer entry points
+    double *d_theta = nullptr, *d_logp = nullptr;
+    int32_t *d_status = nullptr;
+    int64_t cap_walkers = 0;
+    double *d_misc = nullptr;  // composite args / desc / small outputs
+    double *d_spec = nullptr;
+    int64_t cap_spec = 0;
+    int max_dyn_lds = 0;
+};
+
+namespace {
+
+int fail(msx_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(ctx, MSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+template <typename T>
+int dev_alloc_copy(msx_ctx *c, std::vector<void *> *track, const T *host, int64_t count, T **out) {
+    *out = nullptr;
+    if (count <= 0) {
+        // keep kernels simple: always a valid pointer
+        HIP_TRY(c, hipMalloc((void **)out, 16));
+        if (track) track->push_back(*out);
+        return MSX_OK;
+    }
+    HIP_TRY(c, hipMalloc((void **)out, sizeof(T) * count));
+    if (track) track->push_back(*out);
+    HIP_TRY(c, hipMemcpy(*out, host, sizeof(T) * count, hipMemcpyHostToDevice));
+    return MSX_OK;
+}
+
+void free_problem(msx_ctx *c) {
+    for (void *p : c->prob_allocs) (void)hipFree(p);
+    c->prob_allocs.clear();
+    c->problem_staged = false;
+}
+
+void free_grid(msx_ctx *c) {
+    void *ptrs[] = {c->d_grid, c->d_wl, c->d_kgrid, c->d_teff, c->d_logg, c->d_present};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_grid = c->d_wl = c->d_kgrid = c->d_teff = c->d_logg = nullptr;
+    c->d_present = nullptr;
+    c->grid_staged = false;
+}
+
+int conv_taps(double mean_wl, double dx, double resolution, double maxsig, double *sigma_out, int *lx_out) {
+    // pyasl.instrBroadGaussFast: fwhm = mean(wl)/R; sigma = fwhm/(2 sqrt(2 ln 2)); broadGaussFast:
+    // lx = int(((sigma*maxsig)/dx)*2.0) + 1
+    const double fwhm = 1.0 / resolution * mean_wl;
+    const double sigma = fwhm / (2.0 * sqrt(2.0 * log(2.0)));
+    const int lx = (int)(((sigma * maxsig) / dx) * 2.0) + 1;
+    *sigma_out = sigma;
+    *lx_out = lx;
+    return lx;
+}
+
+int check_even_spacing(msx_ctx *c, const double *wl, int64_t n) {
+    // broadGaussFast: abs(max(dxs) - min(dxs)) > mean(dxs)*1e-6 -> error
+    double mx = -INFINITY, mn = INFINITY, sum = 0.0;
+    for (int64_t i = 1; i < n; ++i) {
+        const double d = wl[i] - wl[i - 1];
+        mx = d > mx ? d : mx;
+        mn = d < mn ? d : mn;
+        sum += d;
+    }
+    if (fabs(mx - mn) > (sum / (double)(n - 1)) * 1e-6)
+        return fail(c, MSX_ERR_RANGE, "broaden: the wavelength axis is not equidistant");
+    return MSX_OK;
+}
+
+int launch_conv(msx_ctx *c, const double *d_in, int64_t in_stride, double *d_tmp, int64_t rows, int64_t n, int lx,
+                double dx, double sigma) {
+    const size_t lds = sizeof(double) * ((size_t)lx + kConvTile + lx - 1);
+    if (lds > 150 * 1024) return fail(c, MSX_ERR_RANGE, "broaden: kernel too long for the LDS tile");
+    if ((int)lds > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute((const void *)broaden_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+    dim3 g((unsigned)((n + kConvTile - 1) / kConvTile), (unsigned)rows);
+    hipLaunchKernelGGL(broaden_conv_kernel, g, dim3(256), lds, c->stream, d_in, in_stride, d_tmp, n, n, lx, dx, sigma);
+    HIP_TRY(c, hipGetLastError());
+    return MSX_OK;
+}
+
+int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
+    // few walkers or long spectra: spread one walker over 16 waves; many walkers: 4 waves each so
+    // several workgroups share a CU (LDS permitting).
+    const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    if (npix >= 8192 || n < 2 * cus) return 1024;
+    if (n < 4 * cus) return 512;
+    return 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msx_create(int device, msx_ctx **out) {
+    if (!out) return MSX_ERR_INVALID;
+    *out = nullptr;
+    msx_ctx *c = new msx_ctx();
+    c->device = device;
+    memset(&c->P, 0, sizeof(c->P));
+    *out = c;  // returned even on failure so the caller can read msx_last_error
+    HIP_TRY(c, hipSetDevice(device));
+    HIP_TRY(c, hipGetDeviceProperties(&c->prop, device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipMalloc((void **)&c->d_misc, 4096));
+    return MSX_OK;
+}
+
+void msx_destroy(msx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_problem(c);
+    free_grid(c);
+    void *ptrs[] = {c->d_theta, c->d_logp, c->d_status, c->d_misc, c->d_spec};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *msx_last_error(msx_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+int msx_device_info(msx_ctx *c, int64_t *out3, char *name, int name_len) {
+    if (!c || !out3) return MSX_ERR_INVALID;
+    out3[0] = c->prop.multiProcessorCount;
+    out3[1] = (int64_t)c->prop.totalGlobalMem;
+    out3[2] = c->prop.clockRate;
+    if (name && name_len > 0) {
+        strncpy(name, c->prop.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return MSX_OK;
+}
+
+int msx_stage_grid(msx_ctx *c, const double *wl, int64_t nwl, const double *teff_nodes, int32_t nt,
+                   const double *logg_nodes, int32_t ng, const double *flux, const uint8_t *present) {
+    if (!c || !wl || !teff_nodes || !logg_nodes || !flux || nwl < 2 || nt < 1 || ng < 1)
+        return fail(c, MSX_ERR_INVALID, "msx_stage_grid: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    free_problem(c);
+    free_grid(c);
+    const int64_t nn = (int64_t)nt * ng;
+    c->nwl = nwl; c->nt = nt; c->ng = ng;
+    c->h_wl.assign(wl, wl + nwl);
+    HIP_TRY(c, hipMalloc((void **)&c->d_grid, sizeof(double) * nn * nwl));
+    HIP_TRY(c, hipMemcpy(c->d_grid, flux, sizeof(double) * nn * nwl, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = dev_alloc_copy(c, nullptr, wl, nwl, &c->d_wl))) return rc;
+    if ((rc = dev_alloc_copy(c, nullptr, teff_nodes, (int64_t)nt, &c->d_teff))) return rc;
+    if ((rc = dev_alloc_copy(c, nullptr, logg_nodes, (int64_t)ng, &c->d_logg))) return rc;
+    std::vector<uint8_t> pres(nn, 1);
+    if (present) pres.assign(present, present + nn);
+    if ((rc = dev_alloc_copy(c, nullptr, pres.data(), nn, &c->d_present))) return rc;
+    HIP_TRY(c, hipMalloc((void **)&c->d_kgrid, sizeof(double) * nwl));
+    hipLaunchKernelGGL(ccm89_kernel, dim3((unsigned)((nwl + 255) / 256)), dim3(256), 0, c->stream, c->d_wl, nwl, 3.1,
+                       c->d_kgrid);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->grid_staged = true;
+    return MSX_OK;
+}
+
+int msx_ccm89_k(msx_ctx *c, const double *wl, int64_t n, double rv, double *out) {
+    if (!c || !wl || !out || n < 0) return fail(c, MSX_ERR_INVALID, "msx_ccm89_k: bad arguments");
+    if (n == 0) return MSX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_in, sizeof(double) * n));
+    HIP_TRY(c, hipMalloc((void **)&d_out, sizeof(double) * n));
+    HIP_TRY(c, hipMemcpy(d_in, wl, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ccm89_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, rv, d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return MSX_OK;
+}
+
+int msx_broaden(msx_ctx *c, const double *wl, const double *flux, int64_t n, double resolution, double maxsig,
+                double *out) {
+    if (!c || !wl || !flux || !out || n < 16 || !(resolution > 0) || !(maxsig > 0))
+        return fail(c, MSX_ERR_INVALID, "msx_broaden: bad arguments (need n >= 16)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = check_even_spacing(c, wl, n);
+    if (rc) return rc;
+    double mean = 0.0;
+    for (int64_t i = 0; i < n; ++i) mean += wl[i];
+    mean /= (double)n;
+    double sigma;
+    int lx;
+    conv_taps(mean, wl[1] - wl[0], resolution, maxsig, &sigma, &lx);
+    if (lx < 1) return fail(c, MSX_ERR_RANGE, "msx_broaden: empty kernel");
+    double *d_in = nullptr, *d_tmp = nullptr, *d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_in, sizeof(double) * n));
+    HIP_TRY(c, hipMalloc((void **)&d_tmp, sizeof(double) * n));
+    HIP_TRY(c, hipMalloc((void **)&d_out, sizeof(double) * n));
+    HIP_TRY(c, hipMemcpy(d_in, flux, sizeof(double) * n, hipMemcpyHostToDevice));
+    rc = launch_conv(c, d_in, n, d_tmp, 1, n, lx, wl[1] - wl[0], sigma);
+    if (rc == MSX_OK) {
+        hipLaunchKernelGGL(broaden_patch_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, c->stream, d_tmp, n,
+                           d_out, n, n);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, MSX_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_tmp);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int msx_broaden_grid(msx_ctx *c, int64_t i0, int64_t n, double resolution, double maxsig) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!c->grid_staged) return fail(c, MSX_ERR_STATE, "msx_broaden_grid: no grid staged");
+    if (i0 < 0 || n < 16 || i0 + n > c->nwl || !(resolution > 0) || !(maxsig > 0))
+        return fail(c, MSX_ERR_INVALID, "msx_broaden_grid: bad window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double *wl = c->h_wl.data() + i0;
+    int rc = check_even_spacing(c, wl, n);
+    if (rc) return rc;
+    double mean = 0.0;
+    for (int64_t i = 0; i < n; ++i) mean += wl[i];
+    mean /= (double)n;
+    double sigma;
+    int lx;
+    conv_taps(mean, wl[1] - wl[0], resolution, maxsig, &sigma, &lx);
+    const int64_t rows = (int64_t)c->nt * c->ng;
+    double *d_tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_tmp, sizeof(double) * rows * n));
+    rc = launch_conv(c, c->d_grid + i0, c->nwl, d_tmp, rows, n, lx, wl[1] - wl[0], sigma);
+    if (rc == MSX_OK) {
+        hipLaunchKernelGGL(broaden_patch_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0,
+                           c->stream, d_tmp, n, c->d_grid + i0, c->nwl, n);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, MSX_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_tmp);
+    // any staged problem was derived from the pre-broadening grid
+    free_problem(c);
+    return rc;
+}
+
+int msx_read_node(msx_ctx *c, int32_t it, int32_t ig, double *out) {
+    if (!c || !out) return MSX_ERR_INVALID;
+    if (!c->grid_staged) return fail(c, MSX_ERR_STATE, "msx_read_node: no grid staged");
+    if (it < 0 || it >= c->nt || ig < 0 || ig >= c->ng) return fail(c, MSX_ERR_INVALID, "msx_read_node: bad node");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(out, c->d_grid + ((int64_t)it * c->ng + ig) * c->nwl, sizeof(double) * c->nwl,
+                         hipMemcpyDeviceToHost));
+    return MSX_OK;
+}
+
+int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
+    if (!c || !p) return MSX_ERR_INVALID;
+    if (p->struct_size != (int32_t)sizeof(msx_problem))
+        return fail(c, MSX_ERR_INVALID, "msx_stage_problem: struct_size mismatch (header/library skew)");
+    if (!c->grid_staged) return fail(c, MSX_ERR_STATE, "msx_stage_problem: stage the grid first");
+    if (p->nspec < 2 || p->nspec > MSX_MAX_SPEC) return fail(c, MSX_ERR_INVALID, "nspec must be 2 or 3");
+    if (p->npix < 4) return fail(c, MSX_ERR_INVALID, "npix too small");
+    if (p->n_contrast < 0 || p->n_contrast > MSX_MAX_BANDS || p->n_phot < 0 || p->n_phot > MSX_MAX_BANDS)
+        return fail(c, MSX_ERR_INVALID, "too many bands");
+    if (p->niso < 2) return fail(c, MSX_ERR_INVALID, "isochrone table needs >= 2 rows");
+    if (!p->dist_fit) return fail(c, MSX_ERR_INVALID, "dist_fit=False (mft6.py:1275-1327) is not implemented");
+    if (p->win_j0 < 0 || p->win_n < 1 || p->win_j0 + p->win_n > c->nwl)
+        return fail(c, MSX_ERR_RANGE, "composite window is outside the staged grid");
+    const int64_t need_lds = (int64_t)sizeof(double) * p->npix;
+    if (need_lds > 150 * 1024)
+        return fail(c, MSX_ERR_RANGE, "npix too large for the LDS-resident model vector (max 19200 pixels)");
+    for (int64_t i = 0; i < p->npix; ++i)
+        if (p->pix_lo[i] < 0 || p->pix_lo[i] + 1 >= c->nwl)
+            return fail(c, MSX_ERR_RANGE, "A value in x_new is outside the interpolation range (data pixel vs model grid)");
+    const int nb = p->n_contrast + p->n_phot;
+    for (int b = 0; b < nb; ++b)
+        if (p->band_i0[b] < 0 || p->band_len[b] < 0 || p->band_i0[b] + p->band_len[b] > c->nwl)
+            return fail(c, MSX_ERR_RANGE, "band weights run outside the staged grid");
+    HIP_TRY(c, hipSetDevice(c->device));
+    free_problem(c);
+    std::vector<void *> &tr = c->prob_allocs;
+    DevProblem &P = c->P;
+    memset(&P, 0, sizeof(P));
+    P.grid = c->d_grid; P.kgrid = c->d_kgrid; P.nwl = c->nwl; P.nt = c->nt; P.ng = c->ng;
+    P.teff_nodes = c->d_teff; P.logg_nodes = c->d_logg; P.present = c->d_present;
+    P.npix = p->npix; P.median_flux = p->median_flux; P.nspec = p->nspec;
+    memcpy(P.minv, p->fit_minv, sizeof(P.minv));
+    P.nc = p->n_contrast; P.np = p->n_phot;
+    for (int i = 0; i < P.nc; ++i) { P.cmag[i] = p->cmag[i]; P.cerr[i] = p->cerr[i]; }
+    for (int i = 0; i < P.np; ++i) {
+        P.pmag[i] = p->pmag[i]; P.perr[i] = p->perr[i]; P.pzero[i] = p->phot_zero[i]; P.pk[i] = p->phot_k[i];
+    }
+    P.win_j0 = p->win_j0; P.win_n = p->win_n;
+    P.niso = p->niso; P.nav = p->nav; P.tmin = p->tmin; P.tmax = p->tmax;
+    memcpy(P.pmean, p->prior_mean, sizeof(P.pmean));
+    memcpy(P.psig, p->prior_sig, sizeof(P.psig));
+    P.use_av = p->use_av; P.dist_fit = p->dist_fit; P.rad_prior = p->rad_prior; P.has_prior = p->has_prior_list;
+    int rc;
+    double *d;
+    if ((rc = dev_alloc_copy(c, &tr, p->pix_t, p->npix, &d))) return rc; P.pix_t = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->pix_u, p->npix, &d))) return rc; P.pix_u = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->pix_flux, p->npix, &d))) return rc; P.pix_flux = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->pix_err, p->npix, &d))) return rc; P.pix_err = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->iso_teff, (int64_t)p->niso, &d))) return rc; P.iso_t = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->iso_logg, (int64_t)p->niso, &d))) return rc; P.iso_g = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->iso_lum, (int64_t)p->niso, &d))) return rc; P.iso_l = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->av_edges_pc, (int64_t)(p->nav > 0 ? p->nav + 1 : 0), &d))) return rc; P.av_edges = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->av_mu, (int64_t)p->nav, &d))) return rc; P.av_mu = d;
+    if ((rc = dev_alloc_copy(c, &tr, p->av_sig, (int64_t)p->nav, &d))) return rc; P.av_sig = d;
+
+    const int64_t nn = (int64_t)c->nt * c->ng;
+    // pair table + k pairs
+    int64_t *d_lo = nullptr;
+    if ((rc = dev_alloc_copy(c, &tr, p->pix_lo, p->npix, &d_lo))) return rc;
+    double2 *d_pairs = nullptr, *d_pk = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_pairs, sizeof(double2) * nn * p->npix)); tr.push_back(d_pairs);
+    HIP_TRY(c, hipMalloc((void **)&d_pk, sizeof(double2) * p->npix)); tr.push_back(d_pk);
+    dim3 gg((unsigned)((p->npix + 255) / 256), (unsigned)nn);
+    hipLaunchKernelGGL(gather_pairs_kernel, gg, dim3(256), 0, c->stream, c->d_grid, c->nwl, d_lo, p->npix, d_pairs);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3(gg.x, 1), dim3(256), 0, c->stream, c->d_kgrid, c->nwl, d_lo, p->npix, d_pk);
+    HIP_TRY(c, hipGetLastError());
+    P.pairs = d_pairs; P.pix_k = d_pk;
+    // band integrals
+    double *d_tab = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_tab, sizeof(double) * std::max<int64_t>(1, nn * nb))); tr.push_back(d_tab);
+    if (nb > 0) {
+        std::vector<int64_t> woff(nb);
+        int64_t tot = 0;
+        for (int b = 0; b < nb; ++b) { woff[b] = tot; tot += p->band_len[b]; }
+        double *d_w = nullptr;
+        int64_t *d_woff = nullptr, *d_i0 = nullptr, *d_len = nullptr;
+        if ((rc = dev_alloc_copy(c, &tr, p->band_w, tot, &d_w))) return rc;
+        if ((rc = dev_alloc_copy(c, &tr, woff.data(), (int64_t)nb, &d_woff))) return rc;
+        if ((rc = dev_alloc_copy(c, &tr, p->band_i0, (int64_t)nb, &d_i0))) return rc;
+        if ((rc = dev_alloc_copy(c, &tr, p->band_len, (int64_t)nb, &d_len))) return rc;
+        hipLaunchKernelGGL(band_integral_kernel, dim3((unsigned)nb, (unsigned)nn), dim3(256), 0, c->stream, c->d_grid,
+                           c->nwl, d_w, d_woff, d_i0, d_len, nb, d_tab);
+        HIP_TRY(c, hipGetLastError());
+    }
+    P.band_tab = d_tab;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the hot kernel may need more than the default 64 KiB of dynamic LDS
+    c->max_dyn_lds = (int)need_lds;
+    if (need_lds > 48 * 1024) {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)need_lds));
+        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)need_lds));
+    }
+    c->problem_staged = true;
+    return MSX_OK;
+}
+
+int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
+                          int32_t *d_status, void *hip_stream, int32_t block_threads) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_logprob_batch: no problem staged");
+    if (n < 0 || !d_theta || !d_logp || !d_status) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad arguments");
+    if (ndim != 2 * c->P.nspec + 2)
+        return fail(c, MSX_ERR_INVALID, "P0 doesn't match what I was expecting (ndim must be 2*nspec+2)");
+    if (mode < 0 || mode > 2) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad mode");
+    if (n == 0) return MSX_OK;
+    int B = block_threads > 0 ? block_threads : pick_block(c, n, c->P.npix);
+    if (B % 64 != 0 || B < 64 || B > 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be a multiple of 64 in [64,1024]");
+    // the bin scan of the radix select uses lanes of wave 0 and tid < 256 to clear the histogram
+    if (B < 256) return fail(c, MSX_ERR_INVALID, "block_threads must be >= 256");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t lds = sizeof(double) * (size_t)c->P.npix;
+    if (c->P.nspec == 2)
+        hipLaunchKernelGGL(logprob_kernel<2>, dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+    else
+        hipLaunchKernelGGL(logprob_kernel<3>, dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+    HIP_TRY(c, hipGetLastError());
+    return MSX_OK;
+}
+
+int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, int32_t ndim, double *logp_out,
+                      int32_t *status_out) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!theta || !logp_out || !status_out || n < 0) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad arguments");
+    if (n == 0) return MSX_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > c->cap_walkers) {
+        if (c->d_theta) (void)hipFree(c->d_theta);
+        if (c->d_logp) (void)hipFree(c->d_logp);
+        if (c->d_status) (void)hipFree(c->d_status);
+        c->d_theta = c->d_logp = nullptr; c->d_status = nullptr; c->cap_walkers = 0;
+        const int64_t cap = std::max<int64_t>(n, 1024);
+        HIP_TRY(c, hipMalloc((void **)&c->d_theta, sizeof(double) * cap * MSX_MAX_DIM));
+        HIP_TRY(c, hipMalloc((void **)&c->d_logp, sizeof(double) * cap));
+        HIP_TRY(c, hipMalloc((void **)&c->d_status, sizeof(int32_t) * cap));
+        c->cap_walkers = cap;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * n * ndim, hipMemcpyHostToDevice, c->stream));
+    int rc = msx_logprob_batch_dev(c, mode, c->d_theta, n, ndim, c->d_logp, c->d_status, c->stream, 0);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(logp_out, c->d_logp, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(status_out, c->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MSX_OK;
+}
+
+int msx_make_composite(msx_ctx *c, const double *teff, const double *logg, const double *rad, int32_t use_distance,
+                       double plx, double *spec_out, double *contrast_out, double *phot_out, int32_t *status_out) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_make_composite: no problem staged");
+    if (!teff || !logg || !rad || !spec_out || !status_out) return fail(c, MSX_ERR_INVALID, "msx_make_composite: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int ns = c->P.nspec;
+    double args[3 * MSX_MAX_SPEC + 1];
+    for (int i = 0; i < ns; ++i) { args[i] = teff[i]; args[ns + i] = logg[i]; args[2 * ns + i] = rad[i]; }
+    args[3 * ns] = plx;
+    if (c->P.win_n > c->cap_spec) {
+        if (c->d_spec) (void)hipFree(c->d_spec);
+        c->d_spec = nullptr; c->cap_spec = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_spec, sizeof(double) * c->P.win_n));
+        c->cap_spec = c->P.win_n;
+    }
+    double *d_args = c->d_misc;
+    WalkerDesc *d_desc = reinterpret_cast<WalkerDesc *>(c->d_misc + 64);
+    static_assert(sizeof(WalkerDesc) + 64 * sizeof(double) <= 4096, "misc buffer too small");
+    HIP_TRY(c, hipMemcpyAsync(d_args, args, sizeof(double) * (3 * ns + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(composite_setup_kernel, dim3(1), dim3(64), 0, c->stream, c->P, d_args, (int)use_distance, d_desc);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((c->P.win_n + 255) / 256)), dim3(256), 0, c->stream, c->P, d_desc,
+                       c->d_spec);
+    HIP_TRY(c, hipGetLastError());
+    WalkerDesc h;
+    HIP_TRY(c, hipMemcpyAsync(&h, d_desc, sizeof(WalkerDesc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *status_out = h.status;
+    if (h.status != MSX_W_OK) return MSX_OK;
+    HIP_TRY(c, hipMemcpy(spec_out, c->d_spec, sizeof(double) * c->P.win_n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < c->P.nc && contrast_out; ++i) contrast_out[i] = h.contrast[i];
+    for (int i = 0; i < c->P.np && phot_out; ++i) phot_out[i] = h.phot[i];
+    return MSX_OK;
+}
+
+int msx_stream_copy_gbps(msx_ctx *c, int64_t bytes, int32_t iters, double *gbps_out) {
+    if (!c || !gbps_out || bytes < 4096 || iters < 1) return fail(c, MSX_ERR_INVALID, "msx_stream_copy_gbps: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t n4 = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&a, n4 * 16));
+    HIP_TRY(c, hipMalloc((void **)&b, n4 * 16));
+    HIP_TRY(c, hipMemsetAsync(a, 1, n4 * 16, c->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    const int blocks = c->prop.multiProcessorCount * 8;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copy_float4_kernel, dim3(blocks), dim3(256), 0, c->stream, a, b, n4);
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(copy_float4_kernel, dim3(blocks), dim3(256), 0, c->stream, a, b, n4);
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    *gbps_out = (2.0 * (double)(n4 * 16) * iters) / ((double)ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return MSX_OK;
+}
+
+int msx_bytes_per_eval(msx_ctx *c, int64_t *requested_bytes) {
+    if (!c || !requested_bytes) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_bytes_per_eval: no problem staged");
+    const int64_t npix = c->P.npix;
+    // pair rows (16 B x corners) + per-pixel statics read in phases A and C
+    *requested_bytes = npix * (16 * (int64_t)c->P.nspec * 4 + 16 + 8 * 3 + 8 * 3) + 8 * (2 * c->P.nspec + 2) + 12;
+    return MSX_OK;
+}
+
+}  // extern "C"
