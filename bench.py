@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: walker log-posterior evaluations per second (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one fused launch of the per-walker log-posterior (prior gate + two-component spectrum
+synthesis + reddening + resample + median/continuum normalisation + chi^2 + contrast terms) over
+this rank's walkers, inputs resident in HBM, followed -- when N > 1 -- by one RCCL all-gather of the
+log-probabilities (walkers are independent: shard, no other data-path collective).  Workload at
+N = 1 is BASELINE.json configs[1]: binary, 4096-pixel spectrum, 256 walkers; weak scaling keeps
+256 walkers per GPU (N = 8 is configs[2], 2048 walkers).
+
+Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` and
+`cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NWIN_DOC = 'B_alg = nspec*4*Nwin*8 + ndim*8 + 8 (SURVEY.md §8d)'
+
+
+def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False):
+    """Stage the synthetic 26x4x135,000 grid, broaden the data window on the device (A3), synthesise
+    a data spectrum at theta* with the GPU's own make_composite and stage the problem."""
+    from mcmc_spec_amd import bands, staging, synth
+    wl = np.arange(3000, 30000, 0.2)  # mft6.py:343 with specmin/specmax of param_koi2298.txt:15-16
+    teffs = np.arange(3000, 5600, 100)
+    loggs = np.array([4.0, 4.5, 5.0, 5.5])
+    flux = synth.make_grid(teffs, loggs, wl)
+    eng.stage_grid(wl, teffs, loggs, flux)
+    wl_um = synth.data_wavelengths_um(npix)
+    r = [float(wl_um.min()), float(wl_um.max())]
+    win = [np.floor(r[0] * 1e4), np.ceil(r[1] * 1e4)]  # "spmin/spmax" of the run, Angstrom
+    eng.broaden_grid_window(win, resolution)
+    matrix = synth.make_isochrone_matrix()
+    ctm = synth.synthetic_contrast_filters()
+    if with_phot:
+        ptm = synth.synthetic_phot_filters()
+        pfilt, pmag, perr = ['sdss,r', 'sdss,i', 'sdss,z', 'j', 'h', 'k'], synth.EXAMPLE_PMAG, synth.EXAMPLE_PERR
+    else:
+        ptm, pfilt, pmag, perr = [[], [], [], []], [], [], []
+    fr = [synth.EXAMPLE_CMAG, synth.EXAMPLE_CERR, ['lp600', 'Kp'], pmag, perr, pfilt]
+    tmi = min(min(w) for w in ctm[0] + ptm[0])
+    tma = max(max(w) for w in ctm[0] + ptm[0])
+    tabs, (vw, vf) = synth.synthetic_band_tables(), synth.synthetic_vega()
+    bl = bands.make_bands(tabs, vw, vf)
+    av_table = synth.make_av_table()
+    prior = [*np.zeros(10), 2.0732e-3, 0.0277e-3]  # mft6.py:3689
+    kw = dict(nspec=2, bands=bl, av_table=av_table, tmin=float(teffs[0]), tmax=float(teffs[-1]), prior=prior)
+    # pass 1: placeholder data so that make_composite has its window/tables; pass 2: real data
+    ones = np.ones(npix)
+    eng.stage_problem([wl_um, ones], ones, fr, r, ctm, ptm, tmi, tma, matrix, **kw)
+    p = synth.TRUTH_THETA
+    lg = staging.isochrone_logg(p[:2], matrix)
+    w1, c1, _, _, _ = eng.make_composite(p[:2], lg, p[3:5], p[5])
+    c1 = c1 * 10.0 ** (-0.4 * p[2] * eng.ctx.ccm89_k(w1, 3.1))  # extinct(), mft6.py:62-63
+    f = np.interp(wl_um * 1e4, w1, c1)
+    rng = np.random.default_rng(seed)
+    d = f + rng.normal(0, 0.01 * f)  # mft6.py:3640
+    med = np.median(d)
+    data, err = [wl_um, d / med], 0.01 * f / med  # mft6.py:3506-3507
+    eng.stage_problem(data, err, fr, r, ctm, ptm, tmi, tma, matrix, **kw)
+    nwin = int(np.sum((wl >= win[0] - 1) & (wl <= win[1] + 1)))
+    out = dict(data=data, err=err, fr=fr, r=r, ctm=ctm, ptm=ptm, tmi=tmi, tma=tma, matrix=matrix, tabs=tabs,
+               vega=(vw, vf), prior=prior, tmin=float(teffs[0]), tmax=float(teffs[-1]), nwin=nwin, win=win,
+               resolution=resolution, teffs=teffs, loggs=loggs, wl=wl)
+    if keep_host_grid:
+        out['flux'] = flux
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle driven like emcee drives a pool.  Only this leg of
+# bench.py touches oracle/.
+# ------------------------------------------------------------------------------------------------
+_CPU = {}
+
+
+def _cpu_one(theta):
+    from oracle import mft6_oracle as orc
+    W = _CPU['w']
+    return orc.logposterior(list(theta), W['fr'], 2, W['data'], W['err'], W['r'], _CPU['specs'], W['ctm'], W['ptm'],
+                            W['tmi'], W['tma'], W['tmin'], W['tmax'], W['matrix'], _CPU['av_prior'], prior=W['prior'],
+                            bandlib=_CPU['bandlib'])
+
+
+def cpu_baseline(W, theta, gpu_logp, budget_s=20.0, procs=0):
+    import multiprocessing as mp
+    import warnings
+    from mcmc_spec_amd import synth
+    from oracle import mft6_oracle as orc
+    warnings.filterwarnings('ignore')
+    specs = synth.grid_to_specs(W['teffs'], W['loggs'], W['wl'], W['flux'])
+    specs = orc.broaden_specs_window(specs, W['win'], W['resolution'])  # CPU restatement of the A3 staging
+    edges, mu, sig = synth.make_av_table()
+
+    def av_prior(d):
+        b = int(np.clip(np.searchsorted(edges, d, side='right') - 1, 0, len(mu) - 1))
+        return mu[b], sig[b]
+
+    _CPU.update(procs=procs, w=W, specs=specs, av_prior=av_prior, bandlib=orc.make_band_library(W['tabs'], *W['vega']))
+    t0 = time.time()
+    first = _cpu_one(theta[0])
+    t_one = time.time() - t0
+    # the GPU box gives one GPU's CPU share (16 cores) to this job; never oversubscribe it
+    cores = _CPU.get('procs') or min(len(os.sched_getaffinity(0)), 16)
+    n = int(max(cores, min(len(theta), budget_s * cores / max(t_one, 1e-3))))
+    n = min(n, len(theta))
+    ctx = mp.get_context('fork')  # tables inherited, not pickled per call
+    with ctx.Pool(processes=cores) as pool:
+        pool.map(_cpu_one, theta[:cores])  # warm-up
+        t0 = time.time()
+        res = pool.map(_cpu_one, theta[:n])
+        dt = time.time() - t0
+    res = np.array(res)
+    g = gpu_logp[:n]
+    fin = np.isfinite(res)
+    rel = float(np.max(np.abs(res[fin] - g[fin]) / np.abs(res[fin]))) if fin.any() else 0.0
+    same_inf = bool(np.array_equal(np.isinf(res), np.isinf(g)))
+    return dict(value=n / dt, unit='evals/s', cores=cores, kind='port',
+                sample='{} walkers of the same ensemble, oracle logposterior under multiprocessing.Pool({}) (fork); '
+                       'single eval {:.1f} ms'.format(n, cores, t_one * 1e3),
+                max_rel_err_gpu_vs_oracle=rel, inf_pattern_equal=same_inf)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--walkers', type=int, default=256, help='walkers per GPU per launch (weak scaling)')
+    ap.add_argument('--npix', type=int, default=4096)
+    ap.add_argument('--phot', action='store_true', help='add the 6-band photometry term (config 4)')
+    ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = auto)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--cpu-procs', type=int, default=0, help='CPU baseline pool width (0 = min(affinity, 16))')
+    ap.add_argument('--copy-gib', type=float, default=1.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run'.format(args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    eng = Engine(local)
+    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    W = build_workload(eng, args.npix, args.phot, keep_host_grid=want_cpu)
+    n = args.walkers
+    ndim = 6
+    # distinct coordinates per rank and a few distinct batches so no launch repeats the previous one
+    nbatch = 4
+    thetas = [torch.from_numpy(synth.draw_walkers(n, seed=3 + 1000 * rank + b, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+              for b in range(nbatch)]
+    logp = torch.empty(n, dtype=torch.float64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+
+    def step(i):
+        eng.ctx.logprob_batch_dev(thetas[i % nbatch].data_ptr(), n, ndim, logp.data_ptr(), status.data_ptr(), sptr,
+                                  _lib.MODE_LOGPOST, args.block)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, logp)
+
+    for i in range(args.warmup):
+        step(i)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        eng.ctx.logprob_batch_dev(thetas[i % nbatch].data_ptr(), n, ndim, logp.data_ptr(), status.data_ptr(), sptr,
+                                  _lib.MODE_LOGPOST, args.block)
+        ev[i][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, logp)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    bad = int((status > _lib.W_REJECT).sum().item())
+
+    if rank == 0:
+        nwin = W['nwin']
+        b_alg = 2 * 4 * nwin * 8 + ndim * 8 + 8  # SURVEY.md §8(d), float64 grid
+        peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md); measured stream copy reported beside it
+        achieved = n * b_alg / (kern_ms * 1e-3) / 1e9
+        copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
+        out = {
+            'metric': 'walker log-likelihood evals/sec (whole node)',
+            'value': n * world * args.steps / dt, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'binary (T1=3850/T2=3025) {}-pixel spectrum{}, {} walkers per GPU per launch, '
+                                   'logposterior (prior gate + likelihood){}'.format(
+                                       args.npix, ' + 6-band photometry' if args.phot else ' + 2 contrast terms', n,
+                                       ', RCCL all-gather of log-probs' if world > 1 else ''),
+                       'walkers_total': n * world, 'npix': args.npix, 'nwin': nwin, 'grid': '26x4x135000 f64 synthetic',
+                       'block_threads': args.block or 'auto'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
+                         'traffic': None, 'kernel': 'logprob_kernel<2>', 'kernel_ms': kern_ms,
+                         'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
+                         'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
+                         'note': NWIN_DOC},
+            'walker_error_statuses': bad,
+        }
+        if want_cpu:
+            g, st = eng.ctx.logprob_batch(thetas[0].cpu().numpy(), _lib.MODE_LOGPOST)
+            out['cpu_baseline'] = cpu_baseline(W, thetas[0].cpu().numpy(), g, args.cpu_budget, args.cpu_procs)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

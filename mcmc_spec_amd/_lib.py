@@ -61,6 +61,16 @@ def load():
             'mcmc_spec_amd: the HIP library {} is missing. Build it with\n'
             '  python -c "import __graft_entry__ as g; g.build()"   (or: make -C mcmc_spec_amd/csrc)\n'
             'There is no CPU fallback for the log-likelihood path.'.format(LIB_PATH))
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  If torch were imported *after* this library had bound to /opt/rocm's copy the
+    # process would hold two runtimes and torch's streams / device pointers would be foreign to
+    # ours.  Importing torch first makes the loader resolve our NEEDED entry to the copy torch
+    # already mapped.  (torch is plumbing here: device memory, streams, torch.distributed.)
+    if os.environ.get('MSX_SKIP_TORCH_IMPORT') is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     sig = {

@@ -243,3 +243,11 @@ def build_problem(ctx, grid_wl, data, err, fr, r, ctm, ptm, tmi, tma, matrix, ns
     st.phot_cwl = np.array(phot_cwl)
     st.nc, st.nph = nc, nph
     return st
+
+
+def isochrone_logg(teff, matrix):
+    """Host-side logg(Teff) for building inputs (same table/ordering the device lookup uses)."""
+    x, g, _ = sorted_isochrone(np.asarray(matrix))
+    if np.any(np.asarray(teff) < x[0]) or np.any(np.asarray(teff) > x[-1]):
+        raise ValueError('A value in x_new is outside the interpolation range (isochrone Teff)')
+    return np.interp(teff, x, g)

@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports exactly what include/msx.h declares; the ctypes mirror of
+struct msx_problem has the C layout.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import common  # noqa: F401
+from mcmc_spec_amd import _lib
+
+ROOT = common.ROOT
+HDR = os.path.join(ROOT, 'include', 'msx.h')
+
+
+def declared_functions():
+    txt = open(HDR).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(msx_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTED) == names
+
+
+def test_struct_layout_matches_c():
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "msx.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",' \
+          'sizeof(msx_problem), offsetof(msx_problem, fit_minv), offsetof(msx_problem, win_j0),' \
+          'offsetof(msx_problem, tmin), offsetof(msx_problem, has_prior_list));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(src)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', os.path.join(d, 't'),
+                               os.path.join(d, 't.c')])
+        out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
+    P = _lib.MsxProblem
+    assert [int(x) for x in out] == [ctypes.sizeof(P), P.fit_minv.offset, P.win_j0.offset, P.tmin.offset,
+                                     P.has_prior_list.offset]
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libmsx.so')
+    try:
+        _lib.load()
+    except ImportError as e:
+        assert 'no CPU fallback' in str(e)
+    else:
+        raise AssertionError('load() must raise when the HIP library is missing')

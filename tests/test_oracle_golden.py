@@ -1,0 +1,108 @@
+"""CPU: the oracle (oracle/mft6_oracle.py) against the golden vectors produced by the reference's own
+functions (tests/golden/make_golden.py ran them in the build container).  These pin the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+import common
+from common import golden_case, oracle_loglike, oracle_logpost, rel_err
+from oracle import mft6_oracle as orc
+
+warnings.filterwarnings('ignore')
+
+
+def test_a1_isochrone_lookups_bitwise():
+    c = golden_case('A')
+    g = c.g
+    assert np.array_equal([float(orc.get_logg(t, c.matrix)) for t in g['a1_teff']], g['a1_logg'])
+    assert np.array_equal([float(orc.get_radius(t, c.matrix)) for t in g['a1_teff']], g['a1_radius'])
+    with pytest.raises(ValueError):
+        orc.get_logg(2899.0, c.matrix)
+
+
+def test_a2_get_spec_bitwise_incl_on_node_and_tie_cases():
+    c = golden_case('A')
+    g = c.g
+    for (t, lg), want in zip(g['a2_cases'], g['a2_flux_sub']):
+        w, s = orc.get_spec(float(t), float(lg), [0.55, 0.90], c.specs)
+        assert len(w) == int(g['a2_npts'][0])
+        assert np.array_equal(s[::97], want), (t, lg)
+
+
+@pytest.mark.parametrize('which', ['A', 'B'])
+def test_loglikelihood_bitwise(which):
+    c = golden_case(which)
+    g = c.g
+    idx = list(g[which + '_model_idx'])
+    for i, th in enumerate(c.theta[:12]):
+        parts = {}
+        v = oracle_loglike(c, th, parts)
+        assert v == g[which + '_loglike'][i]
+        assert np.array_equal(parts['contrast'], g[which + '_contrast'][i])
+        assert np.array_equal(parts['phot'], g[which + '_phot'][i])
+        assert parts['iic'] == g[which + '_iic'][i]
+        if i in idx:
+            assert np.array_equal(parts['model'], g[which + '_model'][idx.index(i)])
+
+
+@pytest.mark.parametrize('rad_prior', [False, True])
+def test_logprior_logposterior(rad_prior):
+    c = golden_case('A')
+    tag = 'radprior' if rad_prior else 'noradprior'
+    th = c.g['theta_post']
+    lp = np.array([orc.logprior(list(t), 2, c.tmin, c.tmax, c.matrix, common.av_prior, prior=c.prior,
+                                rad_prior=rad_prior) for t in th])
+    want = c.g['A_logprior_' + tag]
+    assert np.array_equal(np.isinf(lp), np.isinf(want))
+    assert rel_err(lp, want).max() < 1e-13
+    # every rejection case of the box (mft6.py:1227-1230) is in the last 8 rows
+    assert np.all(np.isinf(want[-8:]))
+    sel = [0, 3, len(th) - 1, len(th) - 5]
+    po = np.array([oracle_logpost(c, th[i], rad_prior) for i in sel])
+    assert rel_err(po, c.g['A_logpost_' + tag][sel]).max() < 1e-13
+
+
+def test_chisq_and_norm_spec_bitwise():
+    g = golden_case('A').g
+    m, d, v = g['chisq_in']
+    assert np.array_equal(orc.chisq(m, d, v), g['chisq_out'])
+    assert np.array_equal(orc.norm_spec(np.linspace(0.55, 0.9, 50), m, d), g['norm_spec_out'])
+
+
+def test_make_composite_reference_pieces():
+    c = golden_case('B')
+    p = c.theta[0]
+    lg = [orc.get_logg(t, c.matrix) for t in p[:2]]
+    w, s, con, pcw, ph, _ = orc.make_composite(p[:2], lg, p[3:5], p[5], c.fr[2], c.fr[5], c.r, c.specs, c.ctm, c.ptm,
+                                               c.tmi, c.tma, bandlib=c.bandlib)
+    g = c.g
+    assert [w[0], w[-1], len(w)] == list(g['B_mc_wl_ends'])
+    assert np.array_equal(s[::211], g['B_mc_spec_sub'])
+    assert np.array_equal(con, g['B_mc_contrast'])
+    assert np.array_equal(ph, g['B_mc_phot'])
+
+
+def test_broadening_kernel_properties():
+    """A3 is restated from PyAstronomy's published algorithm (parity unpinned): check the properties
+    the algorithm guarantees -- unit area, symmetry for odd length, flat spectrum preserved inside."""
+    wl = np.arange(6450.0, 8400.0, 0.2)
+    sigma = np.mean(wl) / 1700 / (2 * np.sqrt(2 * np.log(2)))
+    e = orc.broad_gauss_kernel(0.2, sigma, 5)
+    assert len(e) == int(sigma * 5 / 0.2 * 2) + 1 and abs(e.sum() - 1) < 1e-15
+    if len(e) % 2:
+        assert np.allclose(e, e[::-1], rtol=0, atol=1e-18)
+    _, b = orc.broaden(wl, np.ones_like(wl), 1700)
+    assert np.allclose(b[200:-200], 1.0, atol=1e-14)
+    assert np.all(b[:5] == b[5]) and np.all(b[-10:] == b[-11])  # mft6.py:129-130
+    with pytest.raises(ValueError):
+        orc.instr_broad_gauss_fast(wl**1.01, np.ones_like(wl), 1700)
+
+
+def test_ccm89_known_values():
+    """A_V normalisation: a(x)+b(x)/R_V = 1 at x = 1.82 (V band) by construction of CCM89; IR power law."""
+    assert abs(orc.ccm89(np.array([1e4 / 1.82]), 1.0, 3.1)[0] - 1.0) < 1e-12
+    k = orc.ccm89(np.array([20000.0]), 1.0, 3.1)[0]
+    assert abs(k - (0.574 - 0.527 / 3.1) * 0.5**1.61) < 1e-15
+    f = orc.extinct(np.array([5500.0, 8000.0]), np.array([1.0, 1.0]), 0.5)
+    assert np.all(f < 1) and f[0] < f[1]
