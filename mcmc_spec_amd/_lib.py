@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmsx.so')
+# MSX_LIB overrides the library path (diagnostic builds such as -DMSX_STAMPS; never a CPU fallback)
+LIB_PATH = os.environ.get('MSX_LIB') or os.path.join(_HERE, 'libmsx.so')
 
 MSX_OK = 0
 MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4

@@ -81,7 +81,16 @@ struct DevProblem {
     double pmean[MSX_MAX_DIM], psig[MSX_MAX_DIM];
     int32_t use_av, dist_fit, rad_prior, has_prior;
     int32_t nspec;
+#ifdef MSX_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
+#endif
 };
+
+#ifdef MSX_STAMPS
+#define MSX_STAMP(P, wk, i) do { if (threadIdx.x == 0) (P).stamps[(wk) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MSX_STAMP(P, wk, i) do { } while (0)
+#endif
 
 // Per-walker recipe computed once by one lane and broadcast through LDS.
 struct WalkerDesc {
@@ -92,6 +101,7 @@ struct WalkerDesc {
     double chi_extra;            // icontrast + iphot                        mft6.py:1183,1189
     double contrast[MSX_MAX_BANDS];
     double phot[MSX_MAX_BANDS];
+    double mag[MSX_MAX_BANDS * MSX_MAX_SPEC + MSX_MAX_BANDS];  // per-lane magnitudes of the wave recipe
     int32_t status;
     int32_t ncorner;
 };
@@ -299,43 +309,554 @@ __device__ bool log_prior(const DevProblem &P, const double *th, int ndim, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// block-level reductions (fixed order: lanes via shuffles, then waves 0..nw-1 serially)
+// wave-parallel recipe helpers (phase 0 of the hot kernel runs on wave 0, all 64 lanes)
 // ------------------------------------------------------------------------------------------------
+// number of entries of the sorted table xs[0..n) that are <= x (an upper_bound), 64 entries per step
+__device__ __forceinline__ int wave_count_le(const double *__restrict__ xs, int n, double x, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += kWave) {
+        const int i = base + lane;
+        const bool pred = (i < n) && (xs[i] <= x);
+        cnt += __popcll(__ballot(pred));
+    }
+    return cnt;
+}
+
+// np.interp on a sorted table given cnt = #{xs <= x}; caller has checked xs[0] <= x <= xs[n-1]
+__device__ __forceinline__ double interp_from_count(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                    int n, double x, int cnt) {
+    const int j = cnt - 1;
+    if (j >= n - 1) return ys[n - 1];
+    const double x0 = xs[j], y0 = ys[j];
+    if (x0 == x) return y0;
+    const double slope = (ys[j + 1] - y0) / (xs[j + 1] - x0);
+    return slope * (x - x0) + y0;
+}
+
+// mft6.py:439-453 / :467-477 for SORTED, unique node values (staging sorts them; so does the
+// reference, :436,:457-465): the nearest node is one of the two neighbours of v, ties go to the lower
+// index like argmin; then the neighbour on the other side of v.  Python index semantics as in
+// bracket_nodes(): -1 wraps to the last node, == n is an IndexError.
+__device__ __forceinline__ int wave_bracket(const double *__restrict__ nodes, int n, double v, int lane, int *i1,
+                                            int *i2, double *e1, double *e2) {
+    const int j = wave_count_le(nodes, n, v, lane) - 1;  // nodes[j] <= v < nodes[j+1]
+    int best;
+    if (j < 0) best = 0;
+    else if (j >= n - 1) best = n - 1;
+    else best = (fabs(nodes[j + 1] - v) < fabs(nodes[j] - v)) ? j + 1 : j;
+    const double nb = nodes[best];
+    int other;
+    if (nb == v) other = best;
+    else if (nb > v) other = best - 1;
+    else other = best + 1;
+    if (other == -1) other = n - 1;
+    if (other >= n) return MSX_W_INDEXERROR;
+    *i1 = best;
+    *i2 = other;
+    *e1 = nb;
+    *e2 = nodes[other];
+    return MSX_W_OK;
+}
+
+// The small lookup tables of phase 0.  The hot kernel copies them into LDS (into the region that later
+// holds the model vector) with all threads at once, so the recipe's dependent lookups cost an LDS
+// round trip (~100 cycles) instead of an L2/MALL one (~500+); pointers are generic on purpose.
+struct RecipeTabs {
+    const double *iso_t, *iso_g, *iso_l, *av_edges, *av_mu, *av_sig, *teff_nodes, *logg_nodes;
+};
+
+// Phase 0 on wave 0: prior gate (f1), A1, A2, A4 weights, A5/A6 band terms.  Writes D (LDS).
+template <int NS>
+__device__ void build_recipe_wave(const DevProblem &P, const RecipeTabs &T, int mode, const double *__restrict__ th,
+                                  int ndim, WalkerDesc &D, int lane, int64_t wk) {
+    double t[2 * NS + 2];
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) {
+        t[k] = th[k];
+        alive = alive && isfinite(t[k]);  // emcee refuses non-finite coordinates anyway
+    }
+    const double a_v = t[NS];
+    const double plx = t[2 * NS + 1];
+    const double *rad = &t[NS + 1];
+    int st = MSX_W_OK;
+    double lp = 0.0;
+    if (alive && mode == MSX_MODE_LOGPOST) {
+        // box (mft6.py:1227 binary, :1347 triple)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) alive = alive && !(t[s] > P.tmax) && !(t[s] < P.tmin) && !(rad[s] < 0.05);
+        if (NS == 2) alive = alive && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);
+        else alive = alive && !(plx < 1.0 / 1000) && !(plx > 1.0 / 4);
+        if (alive && P.use_av) {
+            if (a_v < 0.0) {
+                alive = false;  // mft6.py:1229
+            } else if (P.nav > 0) {
+                const double d = 1.0 / plx;  // pc, mft6.py:1233
+                int b = wave_count_le(T.av_edges, P.nav + 1, d, lane) - 1;
+                b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
+                double sig = T.av_sig[b];
+                if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
+                const double z = (a_v - T.av_mu[b]) / sig;
+                lp += -0.5 * (z * z);
+            }
+        }
+        if (alive && P.has_prior) {
+#pragma unroll
+            for (int k = 0; k < 2 * NS + 2; ++k) {
+                if (P.pmean[k] != 0.0) {  // mft6.py:1258
+                    const double z = (t[k] - P.pmean[k]) / P.psig[k];
+                    lp += -0.5 * (z * z);
+                }
+            }
+        }
+        if (alive && P.rad_prior) {  // mft6.py:1262-1269
+            double mr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!(t[s] >= T.iso_t[0]) || !(t[s] <= T.iso_t[P.niso - 1])) { st = MSX_W_VALUEERROR; mr[s] = 1.0; continue; }
+                const int cnt = wave_count_le(T.iso_t, P.niso, t[s], lane);
+                const double lum = interp_from_count(T.iso_t, T.iso_l, P.niso, t[s], cnt);
+                const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
+                const double t2 = t[s] * t[s];
+                mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double target = (s == 0) ? mr[0] : mr[s] / mr[0];
+                const double z = (rad[s] - target) / (0.02 * target);
+                lp += -0.5 * (z * z);
+            }
+        }
+    }
+    if (st != MSX_W_OK || !alive) {
+        if (lane == 0) D.status = (st != MSX_W_OK) ? st : MSX_W_REJECT;
+        return;
+    }
+    // A1 + A2 + A4
+    int node[NS * 4];
+    double w[NS * 4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!(t[s] >= T.iso_t[0]) || !(t[s] <= T.iso_t[P.niso - 1])) { st = MSX_W_VALUEERROR; break; }
+        const int cnt = wave_count_le(T.iso_t, P.niso, t[s], lane);
+        const double lg = interp_from_count(T.iso_t, T.iso_g, P.niso, t[s], cnt);  // mft6.py:1149
+        int t1, t2, g1, g2;
+        double te1, te2, ge1, ge2;
+        st = wave_bracket(T.teff_nodes, P.nt, t[s], lane, &t1, &t2, &te1, &te2);
+        if (st == MSX_W_OK) st = wave_bracket(T.logg_nodes, P.ng, lg, lane, &g1, &g2, &ge1, &ge2);
+        if (st != MSX_W_OK) break;
+        const int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+        if (!P.present[n11] || !P.present[n12] || !P.present[n21] || !P.present[n22]) { st = MSX_W_KEYERROR; break; }
+        const double a = (g1 == g2) ? 0.0 : (lg - ge1) / (ge2 - ge1);
+        const double b = (t1 == t2) ? 0.0 : (t[s] - te1) / (te2 - te1);
+        const double di = 1.0 / plx;  // mft6.py:690
+        const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
+        const double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+        const double sc = q * q;
+        node[4 * s + 0] = n11; w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
+        node[4 * s + 1] = n12; w[4 * s + 1] = (1.0 - b) * a * sc;
+        node[4 * s + 2] = n21; w[4 * s + 2] = b * (1.0 - a) * sc;
+        node[4 * s + 3] = n22; w[4 * s + 3] = b * a * sc;
+    }
+    if (st != MSX_W_OK) {
+        if (lane == 0) D.status = st;
+        return;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NS * 4; ++c) { D.node[c] = node[c]; D.w[c] = w[c]; }
+    }
+    // same-wave LDS hand-off (lane 0 -> all lanes): LDS ops of one wave complete in order; the fence
+    // keeps the compiler from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // A5/A6: one (filter, star) or one photometric band per lane; magnitudes land in LDS
+    const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
+    const int nb = P.nc + P.np;
+    const int njobs = P.nc * NS + P.np;
+    if (lane < njobs) {
+        double val;
+        if (lane < P.nc * NS) {
+            const int f = lane / NS, s = lane - f * NS;
+            double m = 0.0;
+            for (int c = 0; c < 4; ++c) m += D.w[4 * s + c] * P.band_tab[(int64_t)D.node[4 * s + c] * nb + f];
+            val = -2.5 * log10(m);  // mft6.py:733
+        } else {
+            const int f = lane - P.nc * NS;
+            double flux = 0.0;
+            for (int c = 0; c < NS * 4; ++c) flux += D.w[c] * P.band_tab[(int64_t)D.node[c] * nb + P.nc + f];
+            val = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+        }
+        D.mag[lane] = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double chi = 0.0;
+        for (int f = 0; f < P.nc; ++f) {
+            int sec = 1;
+            if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+            const double con = D.mag[f * NS + sec] - D.mag[f * NS];  // mft6.py:741
+            const double z = con - P.cmag[f];
+            chi += (z * z) / (P.cerr[f] * P.cerr[f]);  // mft6.py:120,1182
+        }
+        for (int f = 0; f < P.np; ++f) {
+            const double mag = D.mag[P.nc * NS + f];
+            const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
+            const double z = mred - P.pmag[f];
+            chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
+        }
+        D.chi_extra = chi;
+        D.redc = redden ? -0.4 * kLog2Of10 * a_v : 0.0;
+        D.lp = lp;
+        D.status = MSX_W_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 0, fast form: every small table is loaded ONCE into registers of wave 0 (one batch of
+// independent loads), searches are ballots on registers and element fetches are v_readlane with a
+// uniform index -- no dependent memory round trips.  Same arithmetic as build_recipe_wave.
+// Limits (checked by the caller): niso <= 256, nt, ng <= 64, nt*ng <= 128, nav+1 <= 128.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pick4(const double (&r)[4], int idx) {  // idx uniform, 0..255
+    const int k = idx >> 6;
+    const double v = (k == 0) ? r[0] : (k == 1) ? r[1] : (k == 2) ? r[2] : r[3];
+    return readlane_f64(v, idx & 63);
+}
+__device__ __forceinline__ double pick2(const double (&r)[2], int idx) {  // idx uniform, 0..127
+    return readlane_f64((idx >> 6) ? r[1] : r[0], idx & 63);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// np.interp on the register-resident isochrone; caller checked the range
+__device__ __forceinline__ double iso_interp_regs(const double (&xs)[4], const double (&ys)[4], int n, double x) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(xs[k] <= x));  // pads are +inf
+    const int j = uni(cnt) - 1;
+    if (j >= n - 1) return pick4(ys, n - 1);
+    const double x0 = pick4(xs, j), y0 = pick4(ys, j);
+    if (x0 == x) return y0;
+    const double slope = (pick4(ys, j + 1) - y0) / (pick4(xs, j + 1) - x0);
+    return slope * (x - x0) + y0;
+}
+
+// sorted-node bracket on a register-resident node list (lane i holds nodes[i], pads +inf)
+__device__ __forceinline__ int bracket_regs(double nodes, int n, double v, int *i1, int *i2, double *e1, double *e2) {
+    const int j = uni(__popcll(__ballot(nodes <= v))) - 1;
+    int best;
+    if (j < 0) best = 0;
+    else if (j >= n - 1) best = n - 1;
+    else best = (fabs(readlane_f64(nodes, j + 1) - v) < fabs(readlane_f64(nodes, j) - v)) ? j + 1 : j;
+    best = uni(best);
+    const double nb = readlane_f64(nodes, best);
+    int other;
+    if (nb == v) other = best;
+    else if (nb > v) other = best - 1;
+    else other = best + 1;
+    if (other == -1) other = n - 1;
+    if (other >= n) return MSX_W_INDEXERROR;
+    other = uni(other);
+    *i1 = best;
+    *i2 = other;
+    *e1 = nb;
+    *e2 = readlane_f64(nodes, other);
+    return MSX_W_OK;
+}
+
+template <int NS>
+__device__ void build_recipe_regs(const DevProblem &P, int mode, const double *__restrict__ th, WalkerDesc &D,
+                                  int lane, int64_t wk) {
+    // ---- one batch of independent loads -------------------------------------------------------------
+    double t[2 * NS + 2];
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) t[k] = th[k];
+    double isot[4], isog[4], isol[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + kWave * k;
+        const bool ok = i < P.niso;
+        isot[k] = ok ? P.iso_t[i] : INFINITY;
+        isog[k] = ok ? P.iso_g[i] : 0.0;
+        isol[k] = (ok && P.rad_prior) ? P.iso_l[i] : 0.0;
+    }
+    const double tn = lane < P.nt ? P.teff_nodes[lane] : INFINITY;
+    const double gn = lane < P.ng ? P.logg_nodes[lane] : INFINITY;
+    const int nn = P.nt * P.ng;
+    const int pres0 = lane < nn ? (int)P.present[lane] : 0;
+    const int pres1 = lane + kWave < nn ? (int)P.present[lane + kWave] : 0;
+    double ave[2], avm[2], avs[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + kWave * k;
+        ave[k] = (P.use_av && i < P.nav + 1 && P.nav > 0) ? P.av_edges[i] : INFINITY;
+        avm[k] = (P.use_av && i < P.nav) ? P.av_mu[i] : 0.0;
+        avs[k] = (P.use_av && i < P.nav) ? P.av_sig[i] : 0.0;
+    }
+    MSX_STAMP(P, wk, 9);
+    // ---- prior gate (f1) -----------------------------------------------------------------------------
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(t[k]);  // emcee refuses non-finite coords
+    const double a_v = t[NS];
+    const double plx = t[2 * NS + 1];
+    const double *rad = &t[NS + 1];
+    const double iso_lo = pick4(isot, 0), iso_hi = pick4(isot, P.niso - 1);
+    int st = MSX_W_OK;
+    double lp = 0.0;
+    if (alive && mode == MSX_MODE_LOGPOST) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) alive = alive && !(t[s] > P.tmax) && !(t[s] < P.tmin) && !(rad[s] < 0.05);
+        if (NS == 2) alive = alive && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);  // mft6.py:1227
+        else alive = alive && !(plx < 1.0 / 1000) && !(plx > 1.0 / 4);  // mft6.py:1347
+        if (alive && P.use_av) {
+            if (a_v < 0.0) {
+                alive = false;  // mft6.py:1229
+            } else if (P.nav > 0) {
+                const double d = 1.0 / plx;  // pc, mft6.py:1233
+                int b = uni(__popcll(__ballot(ave[0] <= d)) + __popcll(__ballot(ave[1] <= d))) - 1;
+                b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
+                double sig = pick2(avs, b);
+                if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
+                const double z = (a_v - pick2(avm, b)) / sig;
+                lp += -0.5 * (z * z);
+            }
+        }
+        if (alive && P.has_prior) {
+#pragma unroll
+            for (int k = 0; k < 2 * NS + 2; ++k) {
+                if (P.pmean[k] != 0.0) {  // mft6.py:1258
+                    const double z = (t[k] - P.pmean[k]) / P.psig[k];
+                    lp += -0.5 * (z * z);
+                }
+            }
+        }
+        if (alive && P.rad_prior) {  // mft6.py:1262-1269
+            double mr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; mr[s] = 1.0; continue; }
+                const double lum = iso_interp_regs(isot, isol, P.niso, t[s]);
+                const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
+                const double t2 = t[s] * t[s];
+                mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double target = (s == 0) ? mr[0] : mr[s] / mr[0];
+                const double z = (rad[s] - target) / (0.02 * target);
+                lp += -0.5 * (z * z);
+            }
+        }
+    }
+    if (st != MSX_W_OK || !alive) {
+        if (lane == 0) D.status = (st != MSX_W_OK) ? st : MSX_W_REJECT;
+        return;
+    }
+    MSX_STAMP(P, wk, 10);
+    // ---- A1 + A2 + A4 -----------------------------------------------------------------------------------
+    int node[NS * 4];
+    double w[NS * 4];
+    const double di = 1.0 / plx;  // mft6.py:690
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; break; }
+        const double lg = iso_interp_regs(isot, isog, P.niso, t[s]);  // mft6.py:1149
+        int t1, t2, g1, g2;
+        double te1, te2, ge1, ge2;
+        st = bracket_regs(tn, P.nt, t[s], &t1, &t2, &te1, &te2);
+        if (st == MSX_W_OK) st = bracket_regs(gn, P.ng, lg, &g1, &g2, &ge1, &ge2);
+        if (st != MSX_W_OK) break;
+        const int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+        bool have = true;
+        const int four[4] = {n11, n12, n21, n22};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int nd = uni(four[c]);
+            have = have && (__builtin_amdgcn_readlane(nd < kWave ? pres0 : pres1, nd & 63) != 0);
+        }
+        if (!have) { st = MSX_W_KEYERROR; break; }
+        const double a = (g1 == g2) ? 0.0 : (lg - ge1) / (ge2 - ge1);
+        const double b = (t1 == t2) ? 0.0 : (t[s] - te1) / (te2 - te1);
+        const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
+        const double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+        const double sc = q * q;
+        node[4 * s + 0] = n11; w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
+        node[4 * s + 1] = n12; w[4 * s + 1] = (1.0 - b) * a * sc;
+        node[4 * s + 2] = n21; w[4 * s + 2] = b * (1.0 - a) * sc;
+        node[4 * s + 3] = n22; w[4 * s + 3] = b * a * sc;
+    }
+    if (st != MSX_W_OK) {
+        if (lane == 0) D.status = st;
+        return;
+    }
+    MSX_STAMP(P, wk, 11);
+    // ---- A5/A6: one (filter, star) or one photometric band per lane ---------------------------------
+    const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
+    const int nb = P.nc + P.np;
+    const int njobs = P.nc * NS + P.np;
+    double val = 0.0;
+    if (lane < njobs) {
+        if (lane < P.nc * NS) {
+            const int f = lane / NS, s = lane - f * NS;
+            double m = 0.0;
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss) {  // registers cannot be indexed by a lane-varying s: select
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc += w[4 * ss + c] * P.band_tab[(int64_t)node[4 * ss + c] * nb + f];
+                m = (ss == s) ? acc : m;
+            }
+            val = -2.5 * log10(m);  // mft6.py:733
+        } else {
+            const int f = lane - P.nc * NS;
+            double flux = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) flux += w[c] * P.band_tab[(int64_t)node[c] * nb + P.nc + f];
+            val = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+        }
+    }
+    MSX_STAMP(P, wk, 12);
+    double chi = 0.0;
+    for (int f = 0; f < P.nc; ++f) {
+        int sec = 1;
+        if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+        const double con = readlane_f64(val, f * NS + sec) - readlane_f64(val, f * NS);  // mft6.py:741
+        const double z = con - P.cmag[f];
+        chi += (z * z) / (P.cerr[f] * P.cerr[f]);  // mft6.py:120,1182
+    }
+    for (int f = 0; f < P.np; ++f) {
+        const double mag = readlane_f64(val, P.nc * NS + f);
+        const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
+        const double z = mred - P.pmag[f];
+        chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NS * 4; ++c) { D.node[c] = node[c]; D.w[c] = w[c]; }
+        D.chi_extra = chi;
+        D.redc = redden ? -0.4 * kLog2Of10 * a_v : 0.0;
+        D.lp = lp;
+        D.status = MSX_W_OK;
+    }
+    MSX_STAMP(P, wk, 13);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block scratch.  Every reduction site has its own slots so that one barrier per reduction suffices
+// (fixed order everywhere: lanes via shuffles, then waves 0..nw-1 serially -> deterministic).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBins = 1024;  // linear value bins of the median select
 struct BlockScratch {
-    double d[4][kMaxWaves];
-    unsigned long long u[2][kMaxWaves];
-    unsigned int hist[256];
+    double q[3][kMaxWaves];
+    unsigned long long kmin[kMaxWaves], kmax[kMaxWaves];
+    unsigned long long above[kMaxWaves];
+    double chi[kMaxWaves];
+    unsigned int wave_tot[kMaxWaves];
+    unsigned int hist[kBins];
     unsigned long long cand[kSelectFinish];
-    unsigned long long sel_prefix;
     unsigned long long sel_result[2];
-    unsigned int sel_bin, sel_k, sel_cnt, cand_n;
+    unsigned int sel_bin, sel_k, sel_cnt, cand_n, has_second;
     unsigned int cnt_le;
 };
 
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], BlockScratch &S) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// Exact k-th smallest (0-based) of the keys of model[0..npix) by MSB radix passes; the general,
+// always-terminating fallback of the median.  Uses hist[0..256).  All threads must call it.
+__device__ unsigned long long radix_select(const double *model, int npix, unsigned int k, unsigned long long kmin,
+                                           unsigned long long kmax, BlockScratch &S) {
+    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    if (kmin == kmax) return kmin;
+    const int hb = 63 - __clzll((long long)(kmin ^ kmax));  // highest differing bit
+    int shift = hb + 1;
+    unsigned long long pmask = (shift >= 64) ? 0ull : ~((1ull << shift) - 1ull);
+    unsigned long long pval = kmin & pmask;
+    unsigned long long v1 = kmin;
+    bool done = false;
+    while (shift > 0 && !done) {
+        const int bits = shift < 8 ? shift : 8;
+        shift -= bits;
+        const unsigned int dmask = (1u << bits) - 1u;
+        if (tid < 256) S.hist[tid] = 0;
+        __syncthreads();
+        for (int p = tid; p < npix; p += B) {
+            const unsigned long long key = key_of(model[p]);
+            if ((key & pmask) == pval) atomicAdd(&S.hist[(unsigned int)(key >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {  // locate the bin holding rank k: 4 bins per lane + wave inclusive scan
+            const unsigned int c0 = S.hist[4 * lane], c1 = S.hist[4 * lane + 1], c2 = S.hist[4 * lane + 2],
+                               c3 = S.hist[4 * lane + 3];
+            const unsigned int tot = c0 + c1 + c2 + c3;
+            unsigned int inc = tot;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double r = wave_sum(v[i]);
-        if (lane == 0) S.d[i][wave] = r;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_up(inc, o, kWave);
+                if (lane >= o) inc += t;
+            }
+            const unsigned long long ball = __ballot(inc > k);
+            const int L = __ffsll((long long)ball) - 1;
+            if (lane == L) {
+                unsigned int kk = k - (inc - tot);
+                unsigned int bin, cnt;
+                if (kk < c0) { bin = 0; cnt = c0; }
+                else if ((kk -= c0) < c1) { bin = 1; cnt = c1; }
+                else if ((kk -= c1) < c2) { bin = 2; cnt = c2; }
+                else { kk -= c2; bin = 3; cnt = c3; }
+                S.sel_bin = 4 * L + bin;
+                S.sel_k = kk;
+                S.sel_cnt = cnt;
+                S.cand_n = 0;
+            }
+        }
+        __syncthreads();
+        k = S.sel_k;
+        const unsigned int cnt = S.sel_cnt;
+        pval |= ((unsigned long long)S.sel_bin) << shift;
+        pmask |= ((unsigned long long)dmask) << shift;
+        if (shift == 0) {
+            v1 = pval;  // every remaining candidate equals the prefix
+            done = true;
+        } else if (cnt <= (unsigned int)kSelectFinish) {
+            for (int p = tid; p < npix; p += B) {
+                const unsigned long long key = key_of(model[p]);
+                if ((key & pmask) == pval) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+            }
+            __syncthreads();
+            if (tid < (int)cnt) {
+                const unsigned long long mine = S.cand[tid];
+                unsigned int r = 0;
+                for (unsigned int j = 0; j < cnt; ++j) {
+                    const unsigned long long o = S.cand[j];
+                    r += (o < mine) || (o == mine && j < (unsigned int)tid);
+                }
+                if (r == k) S.sel_result[0] = mine;
+            }
+            __syncthreads();
+            v1 = S.sel_result[0];
+            done = true;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double r = 0.0;
-        for (int w = 0; w < nw; ++w) r += S.d[i][w];
-        v[i] = r;
-    }
-    __syncthreads();
+    return v1;
 }
 
 // ------------------------------------------------------------------------------------------------
 // THE HOT KERNEL: one workgroup per walker.
+//   phase 0  wave 0 builds the walker's recipe on 64 lanes (prior gate, A1, A2, A4, A5, A6)
+//   phase A  blend + redden + resample into LDS; fit sums; value range           (A2, A4, A7, A8.1)
+//   phase B  exact median: 1024 linear value bins -> <=256 candidates -> all-pairs rank
+//            (falls back to the bitwise radix select for adversarial distributions)     (A8.2)
+//   phase C  continuum fit coefficients, chi^2                                          (A8.3, A9)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 
-template <int NS>
+template <int NS, int U>
 __global__ void __launch_bounds__(1024)
 logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
@@ -349,33 +870,18 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
     const int lane = tid & 63, wave = tid >> 6, nw = B >> 6;
     const int npix = (int)P.npix;
 
-    // ---- phase 0: one lane builds the walker's recipe (prior gate, A1, A2, A4, A5, A6) ----------
-    if (tid == 0) {
-        const double *th = theta + wk * ndim;
-        D.status = MSX_W_OK;
-        D.lp = 0.0;
-        bool alive = true;
-        for (int k = 0; k < ndim; ++k)
-            if (!isfinite(th[k])) alive = false;  // emcee refuses non-finite coordinates anyway
-        int st = MSX_W_OK;
-        if (alive && mode == MSX_MODE_LOGPOST) {
-            double lp = 0.0;
-            alive = log_prior(P, th, ndim, &lp, &st);
-            D.lp = lp;
-        }
-        if (st != MSX_W_OK) {
-            D.status = st;
-        } else if (!alive) {
-            D.status = MSX_W_REJECT;
+    MSX_STAMP(P, wk, 0);
+    MSX_STAMP(P, wk, 8);
+    for (int i = tid; i < kBins; i += B) S.hist[i] = 0;
+    if (wave == 0) {
+        // register-resident tables when they fit one wave (the usual case), else the generic walk
+        const bool fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave &&
+                          P.nav + 1 <= 2 * kWave;
+        if (fast) {
+            build_recipe_regs<NS>(P, mode, theta + wk * ndim, D, lane, wk);
         } else {
-            double lg[MSX_MAX_SPEC];
-            bool ok = true;
-            for (int s = 0; s < NS; ++s) ok = ok && table_interp(P.iso_t, P.iso_g, P.niso, th[s], &lg[s]);  // A1
-            if (!ok) {
-                D.status = MSX_W_VALUEERROR;
-            } else {
-                build_desc(P, th, lg, th + NS + 1, true, th[2 * NS + 1], th[NS], &D);
-            }
+            const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
+            build_recipe_wave<NS>(P, T, mode, theta + wk * ndim, ndim, D, lane, wk);
         }
     }
     __syncthreads();
@@ -386,57 +892,87 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
         }
         return;
     }
+    MSX_STAMP(P, wk, 1);
 
-    // ---- phase A: blend 4 corners x NS stars at the two bracketing samples of each pixel, redden,
-    //      resample (A2+A4+A7+A8.1); accumulate the fit sums of data/model and the key range --------
+    // ---- phase A ------------------------------------------------------------------------------------
     const double2 *rows[NS * 4];
     double w[NS * 4];
 #pragma unroll
     for (int c = 0; c < NS * 4; ++c) {
-        rows[c] = P.pairs + (int64_t)D.node[c] * npix;
+        rows[c] = P.pairs + (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
         w[c] = D.w[c];
     }
     const double redc = D.redc;
     const bool redden = redc != 0.0;
     double q[3] = {0.0, 0.0, 0.0};
     unsigned long long kmin = ~0ull, kmax = 0ull;
-    for (int p = tid; p < npix; p += B) {
-        double ylo = 0.0, yhi = 0.0;
+    for (int base = 0; base < npix; base += B * U) {
+        double2 v[U][NS * 4];
+        double2 kk[U];
+        double tt[U], ff[U], uu[U];
+        int pp[U];
 #pragma unroll
-        for (int c = 0; c < NS * 4; ++c) {
-            const double2 v = rows[c][p];
-            ylo = fma(w[c], v.x, ylo);
-            yhi = fma(w[c], v.y, yhi);
+        for (int u = 0; u < U; ++u) {
+            const int p = base + u * B + tid;
+            pp[u] = p < npix ? p : npix - 1;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) v[u][c] = rows[c][pp[u]];
         }
-        if (redden) {
-            const double2 k = P.pix_k[p];
-            ylo *= exp2(redc * k.x);  // 10^(-0.4 A_V k)                mft6.py:62-63
-            yhi *= exp2(redc * k.y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kk[u] = redden ? P.pix_k[pp[u]] : make_double2(0.0, 0.0);
+            tt[u] = P.pix_t[pp[u]];
+            ff[u] = P.pix_flux[pp[u]];
+            uu[u] = P.pix_u[pp[u]];
         }
-        const double m = fma(yhi - ylo, P.pix_t[p], ylo);  // mft6.py:1169-1170
-        model[p] = m;
-        const double f = P.pix_flux[p] / m;  // frac before the median scale, mft6.py:194
-        const double u = P.pix_u[p];
-        q[0] += f;
-        q[1] += f * u;
-        q[2] += f * (u * u);
-        const unsigned long long key = key_of(m);
-        kmin = key < kmin ? key : kmin;
-        kmax = key > kmax ? key : kmax;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double ylo = 0.0, yhi = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) {
+                ylo = fma(w[c], v[u][c].x, ylo);
+                yhi = fma(w[c], v[u][c].y, yhi);
+            }
+            if (redden) {
+                ylo *= exp2(redc * kk[u].x);  // 10^(-0.4 A_V k)                mft6.py:62-63
+                yhi *= exp2(redc * kk[u].y);
+            }
+            const double m = fma(yhi - ylo, tt[u], ylo);  // mft6.py:1169-1170
+            if (base + u * B + tid < npix) {
+                model[pp[u]] = m;
+                const double f = ff[u] / m;  // frac before the median scale, mft6.py:194
+                q[0] += f;
+                q[1] += f * uu[u];
+                q[2] += f * (uu[u] * uu[u]);
+                const unsigned long long key = key_of(m);
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+            }
+        }
     }
-    block_sum<3>(q, S);
+    MSX_STAMP(P, wk, 2);
     {
-        unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
-        if (lane == 0) { S.u[0][wave] = a; S.u[1][wave] = b; }
-        __syncthreads();
-        kmin = S.u[0][0]; kmax = S.u[1][0];
-        for (int i = 1; i < nw; ++i) {
-            kmin = S.u[0][i] < kmin ? S.u[0][i] : kmin;
-            kmax = S.u[1][i] > kmax ? S.u[1][i] : kmax;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r = wave_sum(q[i]);
+            if (lane == 0) S.q[i][wave] = r;
         }
+        const unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
+        if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double r = 0.0;
+            for (int x = 0; x < nw; ++x) r += S.q[i][x];
+            q[i] = r;
+        }
+        kmin = S.kmin[0]; kmax = S.kmax[0];
+        for (int x = 1; x < nw; ++x) {
+            kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
+            kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
+        }
     }
-
+    MSX_STAMP(P, wk, 3);
     // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
     if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
         if (tid == 0) {
@@ -446,108 +982,121 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
         return;
     }
 
-    // ---- phase B: exact median of model[0..npix) (np.median, mft6.py:1173) by radix select --------
-    // k1 = lower middle (0-based); for even npix the median is the mean of ranks k1 and k1+1.
+    // ---- phase B: exact median (np.median, mft6.py:1173) -----------------------------------------------
+    // k1 = lower middle rank (0-based); for even npix the median averages ranks k1 and k1+1.
     const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
     const bool need_two = (npix & 1) == 0;
-    unsigned long long v1 = kmin;
+    unsigned long long v1 = kmin, v2 = kmin;
     if (kmin != kmax) {
-        int hb = 63 - __clzll((long long)(kmin ^ kmax));  // highest differing bit
-        int shift = hb + 1;
-        unsigned long long pmask = (shift >= 64) ? 0ull : ~((1ull << shift) - 1ull);
-        unsigned long long pval = kmin & pmask;
-        unsigned int k = k1;
-        bool done = false;
-        while (shift > 0 && !done) {
-            const int bits = shift < 8 ? shift : 8;
-            shift -= bits;
-            const unsigned int dmask = (1u << bits) - 1u;
-            if (tid < 256) S.hist[tid] = 0;
-            __syncthreads();
+        const double vmin = val_of(kmin), vmax = val_of(kmax);
+        // monotone map value -> bin: (x - vmin) * scale is non-decreasing in x, so every key in a lower
+        // bin is <= every key in a higher bin and ranks can be resolved bin by bin.
+        const double scale = (double)kBins / (vmax - vmin);
+        const bool lin_ok = isfinite(scale) && scale > 0.0;
+        bool solved = false;
+        if (lin_ok) {
             for (int p = tid; p < npix; p += B) {
-                const unsigned long long key = key_of(model[p]);
-                if ((key & pmask) == pval) atomicAdd(&S.hist[(unsigned int)(key >> shift) & dmask], 1u);
+                int bin = (int)((model[p] - vmin) * scale);
+                bin = bin > kBins - 1 ? kBins - 1 : bin;
+                atomicAdd(&S.hist[bin], 1u);
             }
             __syncthreads();
-            if (wave == 0) {  // locate the bin holding rank k: 4 bins per lane + wave inclusive scan
-                unsigned int c0 = S.hist[4 * lane], c1 = S.hist[4 * lane + 1], c2 = S.hist[4 * lane + 2],
-                             c3 = S.hist[4 * lane + 3];
-                unsigned int tot = c0 + c1 + c2 + c3, inc = tot;
+            // block scan over the bins: thread t owns bins [t*per, (t+1)*per)
+            const int per = kBins / B > 0 ? kBins / B : 1;
+            unsigned int own = 0;
+            if (tid * per < kBins)
+                for (int i = 0; i < per; ++i) own += S.hist[tid * per + i];
+            unsigned int inc = own;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    unsigned int t = __shfl_up(inc, o, kWave);
-                    if (lane >= o) inc += t;
-                }
-                const unsigned long long ball = __ballot(inc > k);
-                const int L = __ffsll((long long)ball) - 1;
-                if (lane == L) {
-                    unsigned int kk = k - (inc - tot);
-                    unsigned int bin, cnt;
-                    if (kk < c0) { bin = 0; cnt = c0; }
-                    else if ((kk -= c0) < c1) { bin = 1; cnt = c1; }
-                    else if ((kk -= c1) < c2) { bin = 2; cnt = c2; }
-                    else { kk -= c2; bin = 3; cnt = c3; }
-                    S.sel_bin = 4 * L + bin;
-                    S.sel_k = kk;
-                    S.sel_cnt = cnt;
-                    S.cand_n = 0;
-                }
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_up(inc, o, kWave);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) S.wave_tot[wave] = inc;
+            __syncthreads();
+            unsigned int before = 0;
+            for (int x = 0; x < wave; ++x) before += S.wave_tot[x];
+            const unsigned int excl = before + inc - own;
+            if (own > 0 && excl <= k1 && k1 < excl + own) {  // exactly one thread
+                unsigned int kk = k1 - excl;
+                int bin = tid * per;
+                unsigned int cnt = S.hist[bin];
+                while (kk >= cnt) { kk -= cnt; ++bin; cnt = S.hist[bin]; }
+                S.sel_bin = (unsigned int)bin;
+                S.sel_k = kk;
+                S.sel_cnt = cnt;
+                S.cand_n = 0;
+                S.has_second = 0;
             }
             __syncthreads();
-            k = S.sel_k;
-            const unsigned int cnt = S.sel_cnt;
-            pval |= ((unsigned long long)S.sel_bin) << shift;
-            pmask |= ((unsigned long long)dmask) << shift;
-            if (shift == 0) {
-                v1 = pval;  // every remaining candidate equals the prefix
-                done = true;
-            } else if (cnt <= (unsigned int)kSelectFinish) {
-                // finish: gather the candidates and rank them all-pairs (ties broken by slot)
+            const unsigned int cnt = S.sel_cnt, kk = S.sel_k;
+            const int sel = (int)S.sel_bin;
+            if (cnt <= (unsigned int)kSelectFinish) {
+                // gather the candidates of the selected bin; keep the smallest key of the higher bins
+                unsigned long long above = ~0ull;
                 for (int p = tid; p < npix; p += B) {
-                    const unsigned long long key = key_of(model[p]);
-                    if ((key & pmask) == pval) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+                    const double x = model[p];
+                    int bin = (int)((x - vmin) * scale);
+                    bin = bin > kBins - 1 ? kBins - 1 : bin;
+                    const unsigned long long key = key_of(x);
+                    if (bin == sel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+                    else if (bin > sel && key < above) above = key;
                 }
+                above = wave_min_u64(above);
+                if (lane == 0) S.above[wave] = above;
                 __syncthreads();
-                if (tid < (int)cnt) {
+                if (tid < (int)cnt) {  // all-pairs rank, ties broken by slot
                     const unsigned long long mine = S.cand[tid];
                     unsigned int r = 0;
                     for (unsigned int j = 0; j < cnt; ++j) {
                         const unsigned long long o = S.cand[j];
                         r += (o < mine) || (o == mine && j < (unsigned int)tid);
                     }
-                    if (r == k) S.sel_result[0] = mine;
+                    if (r == kk) S.sel_result[0] = mine;
+                    if (r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
                 }
                 __syncthreads();
                 v1 = S.sel_result[0];
-                done = true;
+                if (S.has_second) {
+                    v2 = S.sel_result[1];
+                } else {
+                    v2 = S.above[0];
+                    for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+                }
+                solved = true;
             }
+        }
+        if (!solved) {  // adversarial value distribution: bitwise radix select (always terminates)
             __syncthreads();
-        }
-    }
-    double med_model = val_of(v1);
-    if (need_two && kmin != kmax) {
-        // rank k1+1: equals v1 when v1 is duplicated past rank k1, else the smallest key above v1
-        unsigned int cle = 0;
-        unsigned long long nxt = ~0ull;
-        for (int p = tid; p < npix; p += B) {
-            const unsigned long long key = key_of(model[p]);
-            cle += key <= v1;
-            if (key > v1 && key < nxt) nxt = key;
-        }
-        if (tid == 0) S.cnt_le = 0;
-        __syncthreads();
-        unsigned int wc = cle;
+            v1 = radix_select(model, npix, k1, kmin, kmax, S);
+            v2 = v1;
+            if (need_two) {
+                // rank k1+1: equals v1 when v1 is duplicated past rank k1, else the smallest key above v1
+                unsigned int cle = 0;
+                unsigned long long nxt = ~0ull;
+                for (int p = tid; p < npix; p += B) {
+                    const unsigned long long key = key_of(model[p]);
+                    cle += key <= v1;
+                    if (key > v1 && key < nxt) nxt = key;
+                }
+                if (tid == 0) S.cnt_le = 0;
+                __syncthreads();
+                unsigned int wc = cle;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wc += __shfl_down(wc, o, kWave);
-        nxt = wave_min_u64(nxt);
-        if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.u[0][wave] = nxt; }
-        __syncthreads();
-        unsigned long long v2 = S.u[0][0];
-        for (int i = 1; i < nw; ++i) v2 = S.u[0][i] < v2 ? S.u[0][i] : v2;
-        if (S.cnt_le >= k1 + 2) v2 = v1;
-        med_model = (val_of(v1) + val_of(v2)) / 2.0;  // np.median: mean of the two middle values
-        __syncthreads();
+                for (int o = 32; o > 0; o >>= 1) wc += __shfl_down(wc, o, kWave);
+                nxt = wave_min_u64(nxt);
+                if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.above[wave] = nxt; }
+                __syncthreads();
+                v2 = S.above[0];
+                for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+                if (S.cnt_le >= k1 + 2) v2 = v1;
+            }
+        }
     }
+    // np.median: mean of the two middle values for even npix
+    const double med_model = need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+    MSX_STAMP(P, wk, 4);
+    MSX_STAMP(P, wk, 5);
 
     // ---- phase C: median scale, quadratic continuum fit, chi^2 (A8.2, A8.3, A9) ------------------
     const double scale = P.median_flux / med_model;  // mft6.py:1173
@@ -555,7 +1104,7 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
-    double chi[1] = {0.0};
+    double chi = 0.0;
     for (int p = tid; p < npix; p += B) {
         const double ms = model[p] * scale;
         const double u = P.pix_u[p];
@@ -563,11 +1112,17 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
         const double dn = P.pix_flux[p] / poly;  // mft6.py:196
         const double r = ms - dn;
         const double e = P.pix_err[p];
-        chi[0] += (r * r) / (e * e);  // mft6.py:120
+        chi += (r * r) / (e * e);  // mft6.py:120
     }
-    block_sum<1>(chi, S);
+    MSX_STAMP(P, wk, 6);
+    chi = wave_sum(chi);
+    if (lane == 0) S.chi[wave] = chi;
+    __syncthreads();
+    MSX_STAMP(P, wk, 7);
     if (tid == 0) {
-        const double iic = chi[0] / (double)npix;  // mft6.py:1179
+        double tot = 0.0;
+        for (int x = 0; x < nw; ++x) tot += S.chi[x];
+        const double iic = tot / (double)npix;  // mft6.py:1179
         const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191
         double out;
         if (mode == MSX_MODE_CHISQ) out = total;  // mft6.py:1198-1199
@@ -576,6 +1131,7 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
         status[wk] = MSX_W_OK;
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // staging kernels
@@ -1104,14 +1660,31 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     // the hot kernel may need more than the default 64 KiB of dynamic LDS
     c->max_dyn_lds = (int)need_lds;
     if (need_lds > 48 * 1024) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)need_lds));
-        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)need_lds));
     }
+#ifdef MSX_STAMPS
+    {
+        unsigned long long *st = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * 65536)); tr.push_back(st);
+        HIP_TRY(c, hipMemset(st, 0, sizeof(unsigned long long) * 16 * 65536));
+        P.stamps = st;
+    }
+#endif
     c->problem_staged = true;
     return MSX_OK;
 }
+
+#ifdef MSX_STAMPS
+int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
+    if (!c || !c->problem_staged || n > 65536) return MSX_ERR_INVALID;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out, c->P.stamps, sizeof(unsigned long long) * 16 * n, hipMemcpyDeviceToHost));
+    return MSX_OK;
+}
+#endif
 
 int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
                           int32_t *d_status, void *hip_stream, int32_t block_threads) {
@@ -1123,15 +1696,15 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (mode < 0 || mode > 2) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad mode");
     if (n == 0) return MSX_OK;
     int B = block_threads > 0 ? block_threads : pick_block(c, n, c->P.npix);
-    if (B % 64 != 0 || B < 64 || B > 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be a multiple of 64 in [64,1024]");
-    // the bin scan of the radix select uses lanes of wave 0 and tid < 256 to clear the histogram
-    if (B < 256) return fail(c, MSX_ERR_INVALID, "block_threads must be >= 256");
+    // the median's bin scan assigns kBins/B bins to each thread and the radix fallback clears its
+    // 256-bin histogram with tid < 256
+    if (B != 256 && B != 512 && B != 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be 256, 512 or 1024");
     hipStream_t s = (hipStream_t)hip_stream;
     const size_t lds = sizeof(double) * (size_t)c->P.npix;
     if (c->P.nspec == 2)
-        hipLaunchKernelGGL(logprob_kernel<2>, dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        hipLaunchKernelGGL((logprob_kernel<2, 2>), dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
     else
-        hipLaunchKernelGGL(logprob_kernel<3>, dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        hipLaunchKernelGGL((logprob_kernel<3, 1>), dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
     HIP_TRY(c, hipGetLastError());
     return MSX_OK;
 }

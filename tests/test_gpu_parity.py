@@ -167,3 +167,85 @@ def test_median_edge_cases():
         want = np.array([orc.loglikelihood(list(t), c.fr, 2, data, err, r, c.specs, c.ctm, c.ptm, c.tmi, c.tma,
                                            c.matrix, bandlib=c.bandlib) for t in c.theta[:8]])
         assert rel_err(got, want).max() < TIGHT, npix
+
+
+def test_median_radix_fallback_on_heavily_duplicated_values():
+    """A step-function grid with A_V = 0 gives thousands of bit-identical model values, so the
+    1024-bin stage finds > 256 candidates and the kernel must take the bitwise radix-select path."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import synth
+    from oracle import mft6_oracle as orc
+    teffs = np.arange(3000, 3500, 100)
+    loggs = np.array([4.5, 5.0, 5.5])
+    wl = np.arange(5400, 9100, 0.2)
+    flux = np.empty((len(teffs), len(loggs), len(wl)))
+    for i, t in enumerate(teffs):
+        for j, g in enumerate(loggs):
+            flux[i, j] = np.where(wl < 7000.0, 1.0e5, 3.0e5) * (1 + 0.01 * i + 0.02 * j) \
+                + np.where((wl > 7500) & (wl < 7600), 1.0e5 * np.sin(wl), 0.0)
+    specs = synth.grid_to_specs(teffs, loggs, wl, flux)
+    matrix = synth.make_isochrone_matrix()
+    ctm = [[list(np.linspace(6000, 8800, 40))], [list(np.ones(40))], [0], [7400.0]]
+    ptm = [[], [], [], []]
+    fr = [[1.0], [0.1], ['x'], [], [], []]
+    for npix in (2048, 2047):
+        wl_um = np.linspace(0.56, 0.88, npix)
+        rng = np.random.default_rng(4)
+        data = [wl_um, 1 + 0.05 * rng.normal(size=npix)]
+        err = np.full(npix, 0.05)
+        r = [wl_um.min(), wl_um.max()]
+        eng = Engine(0)
+        eng.stage_specs(specs)
+        eng.stage_problem(data, err, fr, r, ctm, ptm, 6000.0, 8800.0, matrix, nspec=2)
+        th = np.array([[3250.0, 3120.0, 0.0, 0.5, 0.4, 2e-3], [3300.0, 3049.0, 0.0, 0.7, 0.9, 3e-3],
+                       [3250.0, 3120.0, 0.3, 0.5, 0.4, 2e-3]])
+        got = eng.loglikelihood(th)
+        want = np.array([orc.loglikelihood(list(t), fr, 2, data, err, r, specs, ctm, ptm, 6000.0, 8800.0, matrix)
+                         for t in th])
+        assert rel_err(got, want).max() < TIGHT, npix
+
+
+@pytest.mark.parametrize('block', [256, 512, 1024])
+def test_every_workgroup_size_gives_identical_bits(block, engB):
+    import torch
+    from mcmc_spec_amd import _lib
+    c = golden_case('B')
+    ref = engB.loglikelihood(c.theta)
+    dev = torch.device('cuda', 0)
+    th = torch.from_numpy(np.ascontiguousarray(c.theta)).to(dev)
+    lp = torch.empty(len(c.theta), dtype=torch.float64, device=dev)
+    st = torch.empty(len(c.theta), dtype=torch.int32, device=dev)
+    engB.ctx.logprob_batch_dev(th.data_ptr(), len(c.theta), 6, lp.data_ptr(), st.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream, _lib.MODE_LOGLIKE, block)
+    torch.cuda.synchronize()
+    assert rel_err(lp.cpu().numpy(), c.g['B_loglike']).max() < TIGHT
+    assert int(st.abs().sum()) == 0
+    del ref
+
+
+def test_generic_recipe_path_for_large_tables():
+    """Tables too large for the register-resident recipe (here a 300-bin A_V table) take the generic
+    memory-walking path; results must not change."""
+    from oracle import mft6_oracle as orc
+    c = golden_case('B')
+    edges = np.linspace(4.0, 3000.0, 301)
+    mu = 0.05 + 0.0007 * np.arange(300)
+    sig = np.where(np.arange(300) % 7 == 0, 0.0, 0.04)  # sigma == 0 -> 0.05 (mft6.py:1237)
+
+    def avp(d):
+        b = int(np.clip(np.searchsorted(edges, d, side='right') - 1, 0, 299))
+        return mu[b], sig[b]
+
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega), av_table=(edges, mu, sig), tmin=c.tmin, tmax=c.tmax,
+                      prior=c.prior, rad_prior=True)
+    got = eng.logposterior(c.g['theta_post'])
+    want = np.array([orc.logposterior(list(t), c.fr, 2, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma,
+                                      c.tmin, c.tmax, c.matrix, avp, prior=c.prior, rad_prior=True,
+                                      bandlib=c.bandlib) for t in c.g['theta_post']])
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    assert rel_err(got, want).max() < TIGHT

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-clock shares of the hot kernel (build with -DMSX_STAMPS, never shipped).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
+    MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 256 --block 1024
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--walkers', type=int, default=256)
+    ap.add_argument('--block', type=int, default=0)
+    ap.add_argument('--npix', type=int, default=4096)
+    args = ap.parse_args()
+    import torch
+    from bench import build_workload
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    W = build_workload(eng, args.npix, False)
+    dev = torch.device('cuda', 0)
+    n = args.walkers
+    th = torch.from_numpy(synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+    lp = torch.empty(n, dtype=torch.float64, device=dev)
+    st = torch.empty(n, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(20):
+        eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), s, _lib.MODE_LOGPOST, args.block)
+    torch.cuda.synchronize()
+    out = np.zeros((n, 16), dtype=np.uint64)
+    fn = eng.ctx.lib.msx_diag_read_stamps
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    fn.restype = C.c_int
+    assert fn(eng.ctx.h, n, out.ctypes.data) == 0
+    d = np.diff(out[:, :8].astype(np.int64), axis=1)
+    names = ['phase0 recipe', 'phaseA blend', 'reduce q/minmax', 'radix select', 'second rank', 'phaseC chi2', 'reduce chi2']
+    tot = (out[:, 7] - out[:, 0]).astype(np.int64)
+    print('walkers {} block {}: median total {} cycles'.format(n, args.block or 'auto', int(np.median(tot))))
+    for i, nm in enumerate(names):
+        print('  {:18s} median {:8d} cycles  ({:5.1f} %)'.format(nm, int(np.median(d[:, i])), 100 * np.median(d[:, i]) / np.median(tot)))
+    e = out[:, [0, 8, 9, 10, 11, 12, 13, 1]].astype(np.int64)
+    de = np.diff(e, axis=1)
+    for i, nm in enumerate(['stage tables+barrier', 'theta load', 'prior', 'iso+bracket', 'band loads+log10', 'chi combine', 'barrier']):
+        print('    phase0/{:22s} median {:8d} cycles'.format(nm, int(np.median(de[:, i]))))
+    span = int(out[:, 7].max() - out[:, 0].min())
+    print('  first start -> last end: {} cycles'.format(span))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Batch-size x workgroup-size sweep of the hot kernel (kernel time from HIP events on the launch stream)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--npix', type=int, default=4096)
+    ap.add_argument('--phot', action='store_true')
+    ap.add_argument('--walkers', default='128,256,512,1024,2048,4096,16384')
+    ap.add_argument('--blocks', default='256,512,1024')
+    ap.add_argument('--iters', type=int, default=50)
+    args = ap.parse_args()
+    import torch
+    from bench import build_workload
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+    dev = torch.device('cuda', 0)
+    eng = Engine(0)
+    W = build_workload(eng, args.npix, args.phot)
+    b_alg = 2 * 4 * W['nwin'] * 8 + 56
+    stream = torch.cuda.current_stream(dev)
+    rows = []
+    for n in [int(x) for x in args.walkers.split(',')]:
+        th = torch.from_numpy(synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+        lp = torch.empty(n, dtype=torch.float64, device=dev)
+        st = torch.empty(n, dtype=torch.int32, device=dev)
+        for B in [int(x) for x in args.blocks.split(',')]:
+            def go():
+                eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), stream.cuda_stream,
+                                          _lib.MODE_LOGPOST, B)
+            for _ in range(5):
+                go()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.iters):
+                go()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            row = dict(walkers=n, block=B, kernel_us=ms * 1e3, evals_per_s=n / (ms * 1e-3),
+                       alg_GBps=n * b_alg / (ms * 1e-3) / 1e9)
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == '__main__':
+    main()
