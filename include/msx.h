@@ -39,6 +39,7 @@ extern "C" {
 #define MSX_MODE_LOGLIKE 0      /* loglikelihood   (mft6.py:1139-1205)                              */
 #define MSX_MODE_LOGPOST 1      /* logposterior = logprior gate + loglikelihood (mft6.py:1459-1470) */
 #define MSX_MODE_CHISQ 2        /* loglikelihood(optimize=True): returns total chi^2 (mft6.py:1198) */
+#define MSX_MODE_LOGPRIOR 3     /* logprior alone (mft6.py:1207-1272); needs no spectrum pass       */
 
 #define MSX_MAX_SPEC 3
 #define MSX_MAX_BANDS 8

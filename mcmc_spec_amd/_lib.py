@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('MSX_LIB') or os.path.join(_HERE, 'libmsx.so')
 MSX_OK = 0
 MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
 W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR = 0, 1, 2, 3, 4
-MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ = 0, 1, 2
+MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)

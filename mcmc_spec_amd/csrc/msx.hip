@@ -381,7 +381,7 @@ __device__ void build_recipe_wave(const DevProblem &P, const RecipeTabs &T, int 
     const double *rad = &t[NS + 1];
     int st = MSX_W_OK;
     double lp = 0.0;
-    if (alive && mode == MSX_MODE_LOGPOST) {
+    if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) {
         // box (mft6.py:1227 binary, :1347 triple)
 #pragma unroll
         for (int s = 0; s < NS; ++s) alive = alive && !(t[s] > P.tmax) && !(t[s] < P.tmin) && !(rad[s] < 0.05);
@@ -430,6 +430,10 @@ __device__ void build_recipe_wave(const DevProblem &P, const RecipeTabs &T, int 
     }
     if (st != MSX_W_OK || !alive) {
         if (lane == 0) D.status = (st != MSX_W_OK) ? st : MSX_W_REJECT;
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {
+        if (lane == 0) { D.lp = lp; D.status = MSX_W_OK; }
         return;
     }
     // A1 + A2 + A4
@@ -610,7 +614,7 @@ __device__ void build_recipe_regs(const DevProblem &P, int mode, const double *_
     const double iso_lo = pick4(isot, 0), iso_hi = pick4(isot, P.niso - 1);
     int st = MSX_W_OK;
     double lp = 0.0;
-    if (alive && mode == MSX_MODE_LOGPOST) {
+    if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) alive = alive && !(t[s] > P.tmax) && !(t[s] < P.tmin) && !(rad[s] < 0.05);
         if (NS == 2) alive = alive && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);  // mft6.py:1227
@@ -657,6 +661,10 @@ __device__ void build_recipe_regs(const DevProblem &P, int mode, const double *_
     }
     if (st != MSX_W_OK || !alive) {
         if (lane == 0) D.status = (st != MSX_W_OK) ? st : MSX_W_REJECT;
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {
+        if (lane == 0) { D.lp = lp; D.status = MSX_W_OK; }
         return;
     }
     MSX_STAMP(P, wk, 10);
@@ -889,6 +897,13 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
         if (tid == 0) {
             logp[wk] = (D.status == MSX_W_REJECT) ? -INFINITY : NAN;
             status[wk] = D.status;
+        }
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {  // logprior alone (mft6.py:1207-1272): the gate already ran
+        if (tid == 0) {
+            logp[wk] = D.lp;
+            status[wk] = MSX_W_OK;
         }
         return;
     }
@@ -1693,7 +1708,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (n < 0 || !d_theta || !d_logp || !d_status) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad arguments");
     if (ndim != 2 * c->P.nspec + 2)
         return fail(c, MSX_ERR_INVALID, "P0 doesn't match what I was expecting (ndim must be 2*nspec+2)");
-    if (mode < 0 || mode > 2) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad mode");
+    if (mode < 0 || mode > 3) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad mode");
     if (n == 0) return MSX_OK;
     int B = block_threads > 0 ? block_threads : pick_block(c, n, c->P.npix);
     // the median's bin scan assigns kBins/B bins to each thread and the radix fallback clears its

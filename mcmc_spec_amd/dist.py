@@ -1,0 +1,65 @@
+"""Walker sharding across the GPUs of one node.
+
+Walkers are independent (no cross-walker term anywhere in mft6.py:1139-1205), so rank r evaluates the
+contiguous block ``[r*m, (r+1)*m)`` of the ``(n, ndim)`` coordinate array with ``m = ceil(n / G)`` and the
+log-probabilities are combined by ONE collective: ``all_gather_into_tensor`` of ``m`` float64 per rank
+(backend ``nccl`` = RCCL over xGMI on the GPU box; ``gloo`` in the CPU tests).  The ragged tail is padded
+with copies of the last walker so no sentinel reaches the kernel; the pad is dropped after the gather.
+The staged grid/tables are replicated on every GPU.  Every rank must call with the same ``coords``
+(replicated sampler with a shared seed) and gets the same full vector back, bit-identical to a 1-GPU
+evaluation of the same walkers because each walker's value does not depend on its batch.
+
+One process per GPU, launched with ``python -m torch.distributed.run``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous block partition with equal block length m = ceil(n / world).  Returns (lo, hi, m)."""
+    m = -(-n // world)
+    lo = min(rank * m, n)
+    hi = min(lo + m, n)
+    return lo, hi, m
+
+
+class ShardedLogProb:
+    """Wrap a local batch evaluator into an emcee-style vectorised ``log_prob_fn`` over a process group.
+
+    ``local_eval(coords_block) -> float64[len(block)]`` is the per-rank evaluator
+    (``Engine.logposterior`` on this rank's GPU).  ``device`` is the torch device that holds the
+    gather buffers (``cuda:LOCAL_RANK`` for nccl, ``cpu`` for gloo)."""
+
+    def __init__(self, local_eval, group=None, device='cpu'):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.local_eval = local_eval
+        self.group = group
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def __call__(self, coords, *args, **kwargs):
+        torch = self.torch
+        coords = np.atleast_2d(np.asarray(coords, dtype=float))
+        n = len(coords)
+        if self.world == 1:
+            return np.asarray(self.local_eval(coords, *args, **kwargs), dtype=float)
+        lo, hi, m = shard_bounds(n, self.world, self.rank)
+        block = coords[lo:hi]
+        if len(block) < m:  # ragged tail (or an empty shard): pad with the last walker, dropped below
+            pad = np.repeat(coords[-1:], m - len(block), axis=0)
+            block = np.concatenate([block, pad], axis=0)
+        local = np.asarray(self.local_eval(block, *args, **kwargs), dtype=float)
+        send = torch.from_numpy(np.ascontiguousarray(local)).to(self.device)
+        recv = torch.empty(m * self.world, dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        out = recv.cpu().numpy()
+        # rank r's valid entries are the first (hi_r - lo_r) of its block
+        parts = []
+        for r in range(self.world):
+            l, h, _ = shard_bounds(n, self.world, r)
+            parts.append(out[r * m: r * m + (h - l)])
+        return np.concatenate(parts)

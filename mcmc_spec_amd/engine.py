@@ -83,6 +83,9 @@ class Engine:
     def logposterior(self, theta):
         return self._eval(theta, _lib.MODE_LOGPOST)
 
+    def logprior(self, theta):
+        return self._eval(theta, _lib.MODE_LOGPRIOR)
+
     def loglikelihood(self, theta, optimize=False):
         return self._eval(theta, _lib.MODE_CHISQ if optimize else _lib.MODE_LOGLIKE)
 

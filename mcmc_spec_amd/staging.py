@@ -240,6 +240,7 @@ def build_problem(ctx, grid_wl, data, err, fr, r, ctm, ptm, tmi, tma, matrix, ns
     P.rad_prior = int(bool(rad_prior))
     P.has_prior_list = has
     st.window = (j0, nwin)
+    st.r, st.tmi, st.tma = [float(x) for x in r], float(tmi), float(tma)
     st.phot_cwl = np.array(phot_cwl)
     st.nc, st.nph = nc, nph
     return st

@@ -1,0 +1,78 @@
+"""CPU: the N > 1 walker-sharding path with a world_size-2 gloo process group.  The per-rank evaluator
+is the ORACLE here (test infrastructure standing in for the GPU engine): what is under test is the
+partition / pad / all-gather logic of mcmc_spec_amd.dist, which must reproduce the 1-rank vector
+bit for bit for every ragged size."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import common
+from mcmc_spec_amd.dist import shard_bounds
+
+
+def test_shard_bounds_cover_exactly_once():
+    for n in (0, 1, 5, 16, 17, 255, 256):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                lo, hi, m = shard_bounds(n, w, r)
+                assert 0 <= lo <= hi <= n and hi - lo <= m
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+
+
+def _worker(rank, world, port, sizes, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, common.ROOT)
+    sys.path.insert(0, os.path.join(common.ROOT, 'tests'))
+    import warnings
+    warnings.filterwarnings('ignore')
+    import torch.distributed as dist
+    from mcmc_spec_amd.dist import ShardedLogProb
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    c = common.golden_case('B')
+    calls = []
+
+    def local_eval(block):
+        calls.append(len(block))
+        return np.array([common.oracle_logpost(c, t) for t in block])
+
+    f = ShardedLogProb(local_eval, device='cpu')
+    out = {}
+    for n in sizes:
+        out[n] = f(c.g['theta_post'][:n])
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out, calls))
+
+
+@pytest.mark.timeout(300)
+def test_world2_gather_equals_single_rank_for_ragged_sizes():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    sizes = [1, 2, 5, 8]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    c = common.golden_case('B')
+    import warnings
+    warnings.filterwarnings('ignore')
+    for n in sizes:
+        want = np.array([common.oracle_logpost(c, t) for t in c.g['theta_post'][:n]])
+        for rank, out, calls in res:
+            assert np.array_equal(out[n], want), (n, rank)
+    # each rank evaluated only its own (padded) block: ceil(n/2) walkers per call
+    for rank, out, calls in res:
+        assert calls == [-(-n // 2) for n in sizes]

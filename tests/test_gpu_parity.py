@@ -249,3 +249,84 @@ def test_generic_recipe_path_for_large_tables():
                                       bandlib=c.bandlib) for t in c.g['theta_post']])
     assert np.array_equal(np.isinf(got), np.isinf(want))
     assert rel_err(got, want).max() < TIGHT
+
+
+# ------------------------------------------------------------------------------------------------
+# the drop-in module: reference signatures, identity cache, sampler protocol (config 1 plumbing)
+# ------------------------------------------------------------------------------------------------
+def _dropin(c):
+    import mcmc_spec_amd.mft6 as m
+    from mcmc_spec_amd import bands
+    m.clear_cache()
+    m.set_band_library(bands.make_bands(c.tables, *c.vega))
+    m.set_av_prior(*common.av_table_exact())
+    return m
+
+
+def test_dropin_signatures_match_reference_golden():
+    c = golden_case('A')
+    m = _dropin(c)
+    args = [c.fr, 2, 0, c.data, c.err, 1700, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, None]
+    th = c.g['theta_post']
+    # logposterior(p0, fr, nspec, ndust, data, err, broadening, r, specs, ctm, ptm, tmi, tma, vs, tmin, tmax,
+    #              matrix, ra, dec, **kwargs) -- positional exactly like mft6.py:1491-1492
+    post_args = args + [c.tmin, c.tmax, c.matrix, 10.0, 20.0]
+    kw = dict(dust=False, norm=True, prior=c.prior, a=True, models='btsettl', dist_fit=True, rad_prior=True)
+    got = m.logposterior(th, *post_args, **kw)
+    want = c.g['A_logpost_radprior']
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and rel_err(got, want).max() < TIGHT
+    one = m.logposterior(list(th[0]), *post_args, **kw)
+    assert isinstance(one, float) and one == got[0]
+    ll = m.loglikelihood(c.theta, *(args + [c.matrix]))
+    assert rel_err(ll, c.g['A_loglike']).max() < TIGHT
+    chi = m.loglikelihood(c.theta[0], *(args + [c.matrix]), optimize=True)
+    assert abs(chi + 2 * c.g['A_loglike'][0]) < 1e-9 * abs(chi)
+    lp = m.logprior(th, 2, 0, c.tmin, c.tmax, c.matrix, 10.0, 20.0, prior=c.prior, ext=True, dist_fit=True,
+                    rad_prior=True)
+    wantp = c.g['A_logprior_radprior']
+    assert np.array_equal(np.isinf(lp), np.isinf(wantp)) and rel_err(lp, wantp).max() < 1e-12
+    with pytest.raises(ValueError):
+        m.logposterior(np.zeros(7), *post_args, **kw)
+
+
+def test_dropin_make_composite_and_broaden():
+    from oracle import mft6_oracle as orc
+    c = golden_case('B')
+    m = _dropin(c)
+    p = c.theta[0]
+    lg = [float(orc.get_logg(t, c.matrix)) for t in p[:2]]
+    wl, spec, con, pcw, ph = m.make_composite(p[:2], lg, p[3:5], p[5], c.fr[2], c.fr[5], c.r, c.specs, c.ctm, c.ptm,
+                                              c.tmi, c.tma, None, nspec=2)
+    assert len(wl) == c.g['B_mc_wl_ends'][2] and rel_err(spec[::211], c.g['B_mc_spec_sub']).max() < 1e-13
+    assert rel_err(con, c.g['B_mc_contrast']).max() < 1e-11 and rel_err(ph, c.g['B_mc_phot']).max() < 1e-11
+    assert np.allclose(pcw, [np.mean(w) for w in c.ptm[0]])
+    # distance=False branch (mft6.py:701-703): secondary scaled by rad[0]^2 only
+    w2, s2, con2, _, _ = m.make_composite(p[:2], lg, p[3:5], False, c.fr[2], c.fr[5], c.r, c.specs, c.ctm, c.ptm,
+                                          c.tmi, c.tma, None, nspec=2)
+    wo, so, cono, _, _, _ = orc.make_composite(p[:2], lg, p[3:5], False, c.fr[2], c.fr[5], c.r, c.specs, c.ctm, c.ptm,
+                                               c.tmi, c.tma, bandlib=c.bandlib)
+    assert rel_err(s2, so).max() < 1e-13 and rel_err(con2, cono).max() < 1e-11
+    wl_b = np.arange(6450.0, 8400.0, 0.2)
+    f = 1 + 0.2 * np.cos(wl_b / 3.0)
+    ww, bb = m.broaden(wl_b, f, 1700)
+    assert rel_err(bb, orc.broaden(wl_b, f, 1700)[1]).max() < 1e-12
+
+
+def test_config1_plumbing_sampler_over_the_gpu_logposterior():
+    """BASELINE config 1 shape: binary fit on Data/synth_spec_3850_3025.txt (golden dataset A), 32 walkers,
+    emcee protocol with vectorize=True -> one fused launch per half-ensemble.  Pass = chain runs, every
+    log-prob finite and equal to the oracle's at the final state."""
+    from mcmc_spec_amd.sampler import EnsembleSampler
+    c = golden_case('A')
+    m = _dropin(c)
+    args = [c.fr, 2, 0, c.data, c.err, 1700, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, None, c.tmin, c.tmax, c.matrix,
+            10.0, 20.0]
+    kw = dict(prior=c.prior, a=True, dist_fit=True, rad_prior=False)
+    s = EnsembleSampler(32, 6, m.logposterior, args=args, kwargs=kw, vectorize=True, seed=1)
+    rng = np.random.default_rng(1)
+    p0 = c.theta[0] + rng.normal(size=(32, 6)) * np.array([20, 20, 0.01, 0.01, 0.01, 1e-5])
+    st = s.run_mcmc(p0, 100)
+    assert s.chain.shape == (32, 100, 6) and np.all(np.isfinite(st.log_prob))
+    want = np.array([oracle_logpost(c, t) for t in st.coords[:6]])
+    assert rel_err(st.log_prob[:6], want).max() < TOL
+    assert s.acceptance_fraction.mean() > 0.02

@@ -1,0 +1,72 @@
+"""CPU: the emcee-protocol sampler on analytic targets."""
+import numpy as np
+import pytest
+
+import common  # noqa: F401
+from mcmc_spec_amd.sampler import EnsembleSampler, State, run_reference_protocol
+
+
+def lnp_gauss(x, mu, isig):
+    x = np.atleast_2d(x)
+    return -0.5 * np.sum(((x - mu) * isig) ** 2, axis=1)
+
+
+def lnp_gauss_one(x, mu, isig):
+    return float(-0.5 * np.sum(((x - mu) * isig) ** 2))
+
+
+def test_recovers_gaussian_moments_vectorised():
+    mu, sig = np.array([1.0, -2.0, 0.5]), np.array([0.5, 2.0, 1.0])
+    s = EnsembleSampler(32, 3, lnp_gauss, args=[mu, 1 / sig], vectorize=True, seed=1)
+    p0 = mu + 0.1 * np.random.default_rng(0).normal(size=(32, 3))
+    st = s.run_mcmc(p0, 300)
+    s.reset()
+    s.run_mcmc(st, 1500)
+    flat = s.get_chain(flat=True)
+    assert np.allclose(flat.mean(0), mu, atol=0.12)
+    assert np.allclose(flat.std(0), sig, rtol=0.12)
+    assert 0.2 < s.acceptance_fraction.mean() < 0.8
+    assert s.chain.shape == (32, 1500, 3)
+    tau = s.get_autocorr_time(quiet=True)
+    assert tau.shape == (3,) and np.all(tau > 1) and np.all(tau < 200)
+
+
+def test_scalar_and_vector_paths_walk_the_same_chain():
+    mu, isig = np.zeros(2), np.ones(2)
+    p0 = np.random.default_rng(3).normal(size=(8, 2))
+    a = EnsembleSampler(8, 2, lnp_gauss, args=[mu, isig], vectorize=True, seed=5)
+    b = EnsembleSampler(8, 2, lnp_gauss_one, args=[mu, isig], vectorize=False, seed=5)
+    a.run_mcmc(p0, 20)
+    b.run_mcmc(p0, 20)
+    assert np.array_equal(a.chain, b.chain)
+
+
+def test_rejections_and_error_conventions():
+    def box(x):
+        x = np.atleast_2d(x)
+        return np.where(np.all(np.abs(x) < 1, axis=1), 0.0, -np.inf)
+    s = EnsembleSampler(8, 2, box, vectorize=True, seed=2)
+    p0 = np.random.default_rng(1).uniform(-0.5, 0.5, size=(8, 2))
+    s.run_mcmc(p0, 200)
+    assert np.all(np.abs(s.get_chain(flat=True)) < 1)          # -inf proposals are never accepted
+    with pytest.raises(ValueError):
+        EnsembleSampler(8, 2, lambda x: np.full(len(x), np.nan), vectorize=True).run_mcmc(p0, 1)
+    bad = p0.copy()
+    bad[0, 0] = np.inf
+    with pytest.raises(ValueError):
+        s.run_mcmc(bad, 1)
+    with pytest.raises(ValueError):
+        EnsembleSampler(3, 2, box)
+    st = s.get_last_sample()
+    assert isinstance(st, State) and st.coords.shape == (8, 2)
+
+
+def test_reference_driver_protocol_writes_the_reference_files(tmp_path):
+    mu, isig = np.zeros(2), np.ones(2)
+    s = EnsembleSampler(8, 2, lnp_gauss, args=[mu, isig], vectorize=True, seed=9)
+    p0 = np.random.default_rng(2).normal(size=(8, 2))
+    samples = run_reference_protocol(s, p0, nburn=21, nsteps=60, nthin=10, dirname=str(tmp_path), fname='t')
+    assert samples.shape[1] == 2 and samples.shape[0] % 8 == 0
+    assert (tmp_path / 'samples.txt').exists() and (tmp_path / 't_0_burnin.txt').exists()
+    assert (tmp_path / 't_20_burnin.txt').exists() and (tmp_path / 't_0_results.txt').exists()
+    assert np.loadtxt(tmp_path / 'samples.txt').shape == samples.shape
