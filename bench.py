@@ -218,6 +218,13 @@ def main():
         peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md); measured stream copy reported beside it
         achieved = n * b_alg / (kern_ms * 1e-3) / 1e9
         copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r1_logprob_traffic.json')
+        if os.path.exists(tpath):  # PMC counters need rocprofv3 around the process: taken from the committed pass
+            tj = json.load(open(tpath))
+            if tj.get('config') == {'walkers': n, 'npix': args.npix, 'phot': bool(args.phot)}:
+                traffic = tj.get('hbm_bytes_per_launch')
+                traffic_src = 'profiles/r1_logprob_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)'
         out = {
             'metric': 'walker log-likelihood evals/sec (whole node)',
             'value': n * world * args.steps / dt, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
@@ -230,15 +237,17 @@ def main():
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': nwin, 'grid': '26x4x135000 f64 synthetic',
                        'block_threads': args.block or 'auto'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
-                         'traffic': None, 'kernel': 'logprob_kernel<2>', 'kernel_ms': kern_ms,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'logprob_kernel<2,2>',
+                         'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': n * b_alg,
                          'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
                          'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
                          'note': NWIN_DOC},
             'walker_error_statuses': bad,
         }
         if want_cpu:
-            g, st = eng.ctx.logprob_batch(thetas[0].cpu().numpy(), _lib.MODE_LOGPOST)
-            out['cpu_baseline'] = cpu_baseline(W, thetas[0].cpu().numpy(), g, args.cpu_budget, args.cpu_procs)
+            th_cpu = synth.draw_walkers(8192, seed=77, tmin=W['tmin'], tmax=W['tmax'])
+            g, st = eng.ctx.logprob_batch(th_cpu, _lib.MODE_LOGPOST)
+            out['cpu_baseline'] = cpu_baseline(W, th_cpu, g, args.cpu_budget, args.cpu_procs)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
