@@ -1292,10 +1292,18 @@ __global__ void composite_kernel(DevProblem P, const WalkerDesc *__restrict__ Dp
     spec[i] = total;
 }
 
-__global__ void copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n4; i += stride) dst[i] = src[i];
+__global__ void __launch_bounds__(256)
+copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
+    // 4 independent 16-B loads in flight per lane, then 4 stores; grid-stride over 1024-element tiles
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x; base < n4; base += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (base + 256 * k < n4) ? src[base + 256 * k] : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (base + 256 * k < n4) dst[base + 256 * k] = v[k];
+    }
 }
 
 }  // namespace
@@ -1797,7 +1805,7 @@ int msx_stream_copy_gbps(msx_ctx *c, int64_t bytes, int32_t iters, double *gbps_
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
-    const int blocks = c->prop.multiProcessorCount * 8;
+    const int blocks = c->prop.multiProcessorCount * 8;  // 2048 workgroups of 256 threads
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copy_float4_kernel, dim3(blocks), dim3(256), 0, c->stream, a, b, n4);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(copy_float4_kernel, dim3(blocks), dim3(256), 0, c->stream, a, b, n4);

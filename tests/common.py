@@ -93,9 +93,15 @@ def golden_case(which):
         c.ptm = synth.synthetic_phot_filters()
         c.fr = [synth.EXAMPLE_CMAG, synth.EXAMPLE_CERR, np.array(['lp600', 'Kp']), np.array(synth.EXAMPLE_PMAG),
                 synth.EXAMPLE_PERR, np.array(['sdss,r', 'sdss,i', 'sdss,z', 'j', 'h', 'k'])]
+    if which == 'C':  # triple system on dataset B: 4 contrast filters, first half secondary, second half tertiary
+        c.nspec = 3
+        c.theta = g['theta3']
+        c.ctm = [x + x for x in c.ctm]
+        c.fr = [[2.08, 1.3, 3.1, 2.2], [0.14, 0.02, 0.2, 0.05], np.array(['lp600', 'Kp', 'lp600', 'Kp']), c.fr[3], c.fr[4],
+                c.fr[5]]
     c.tmi, c.tma = tm_extrema(c.ctm, c.ptm)
     c.r = [min(c.data[0]), max(c.data[0])]
-    c.prior = [*np.zeros(10), 2.0732e-3, 0.0277e-3]
+    c.prior = [*np.zeros(10), 2.0732e-3, 0.0277e-3] if c.nspec == 2 else [*np.zeros(14), 2.0732e-3, 0.0277e-3]
     c.tmin, c.tmax = 3000.0, 4200.0
     _cache[key] = c
     return c

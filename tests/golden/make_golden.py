@@ -291,6 +291,47 @@ def main():
             out['A_logprior_' + tag] = np.array(lp_ref)
             out['A_logpost_' + tag] = np.array(po_ref)
 
+        # ------------------------------------------------------------ triple system (ndim 8), dataset B
+        # contrast list follows the reference's own triple example ['880','Kp','880','Kp'] (mft6.py:3632):
+        # first half of the filters = secondary - primary, second half = tertiary - primary (mft6.py:747-749)
+        ctm4 = [ctm_syn[0] + ctm_syn[0], ctm_syn[1] + ctm_syn[1], ctm_syn[2] + ctm_syn[2], ctm_syn[3] + ctm_syn[3]]
+        frC = [[2.08, 1.3, 3.1, 2.2], [0.14, 0.02, 0.2, 0.05], np.array(['lp600', 'Kp', 'lp600', 'Kp']),
+               np.array(synth.EXAMPLE_PMAG), synth.EXAMPLE_PERR, np.array(['sdss,r', 'sdss,i', 'sdss,z', 'j', 'h', 'k'])]
+        th3 = []
+        for t in theta[:14]:
+            th3.append([t[0], t[1], max(3001.0, t[1] - 150.0 + 40.0 * len(th3)) if t[1] > 3200 else 3001.0 + 13.0 * len(th3),
+                        t[2], t[3], t[4], 0.6 * t[4], t[5]])
+        th3 = np.array(th3)
+        th3_bad = np.array([[3850.0, 3400.0, 2999.0, 0.1, 0.5, 0.4, 0.3, 2e-3], [3850.0, 3400.0, 3100.0, 0.1, 0.5, 0.4, 0.04, 2e-3],
+                            [3850.0, 3400.0, 3100.0, 0.1, 0.5, 0.4, 0.3, 1 / 1001.0], [3850.0, 3400.0, 3100.0, -0.1, 0.5, 0.4, 0.3, 2e-3]])
+        out['theta3'] = np.vstack([th3, th3_bad])
+        prior3 = [*np.zeros(14), 2.0732e-3, 0.0277e-3]
+        rB = [min(wb), max(wb)]
+        ll3, lp3, po3 = [], [], []
+        for pq in out['theta3']:
+            lp = mft6.logprior(list(pq), 3, 0, 3000.0, 4200.0, matrix, 10.0, 20.0, prior=prior3, ext=True,
+                               dist_fit=True, rad_prior=True)
+            lo = orc.logprior(list(pq), 3, 3000.0, 4200.0, matrix, av_prior, prior=prior3, rad_prior=True)
+            assert (lp == lo) or abs(lp - lo) <= 1e-13 * abs(lp), (lp, lo)
+            lp3.append(lp)
+            po = mft6.logposterior(list(pq), frC, 3, 0, [wb, sb], eb, 1700, rB, specs, ctm4, ptm6, tmiB, tmaB, None,
+                                   3000.0, 4200.0, matrix, 10.0, 20.0, prior=prior3, rad_prior=True)
+            oo = orc.logposterior(list(pq), frC, 3, [wb, sb], eb, rB, specs, ctm4, ptm6, tmiB, tmaB, 3000.0, 4200.0,
+                                  matrix, av_prior, prior=prior3, rad_prior=True, bandlib=bandlib)
+            assert (po == oo) or abs(po - oo) <= 1e-13 * abs(po), (po, oo)
+            po3.append(po)
+            if np.isfinite(lp):
+                v = mft6.loglikelihood(list(pq), frC, 3, 0, [wb, sb], eb, 1700, rB, specs, ctm4, ptm6, tmiB, tmaB, None,
+                                       matrix)
+                o = orc.loglikelihood(list(pq), frC, 3, [wb, sb], eb, rB, specs, ctm4, ptm6, tmiB, tmaB, matrix,
+                                      bandlib=bandlib)
+                assert v == o or abs(v - o) <= 1e-13 * abs(v), (v, o)
+                ll3.append(v)
+            else:
+                ll3.append(np.nan)
+        out['C_loglike'], out['C_logprior'], out['C_logpost'] = np.array(ll3), np.array(lp3), np.array(po3)
+        print('triple: {} walkers, {} inside the box'.format(len(po3), int(np.isfinite(po3).sum())))
+
         # ------------------------------------------------------------ small helpers
         xm, xd, xv = rng.uniform(1, 2, 50), rng.uniform(1, 2, 50), rng.uniform(0.01, 0.02, 50)
         out['chisq_in'] = np.array([xm, xd, xv])

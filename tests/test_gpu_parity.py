@@ -20,7 +20,7 @@ def make_engine(c, rad_prior=False, with_prior=True):
     eng = Engine(0)
     eng.stage_specs(c.specs)
     bl = bands.make_bands(c.tables, *c.vega)
-    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2, bands=bl,
+    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=c.nspec, bands=bl,
                       av_table=common.av_table_exact() if with_prior else None, tmin=c.tmin, tmax=c.tmax,
                       prior=c.prior if with_prior else 0, rad_prior=rad_prior)
     return eng
@@ -330,3 +330,19 @@ def test_config1_plumbing_sampler_over_the_gpu_logposterior():
     want = np.array([oracle_logpost(c, t) for t in st.coords[:6]])
     assert rel_err(st.log_prob[:6], want).max() < TOL
     assert s.acceptance_fraction.mean() > 0.02
+
+
+def test_triple_system_ndim8_matches_reference_golden():
+    """nspec = 3 (ndim 8): three components, contrast list split secondary/tertiary (mft6.py:746-751),
+    triple prior box (mft6.py:1347) with rad_prior=True (the only ndim-8 prior path that returns a value)."""
+    c = golden_case('C')
+    eng = make_engine(c, rad_prior=True)
+    g = c.g
+    got = eng.logposterior(c.theta)
+    want = g['C_logpost']
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and rel_err(got, want).max() < TIGHT
+    ok = np.isfinite(g['C_loglike'])
+    ll = eng.loglikelihood(c.theta[ok])
+    assert rel_err(ll, g['C_loglike'][ok]).max() < TIGHT
+    lp = eng.logprior(c.theta)
+    assert np.array_equal(np.isinf(lp), np.isinf(g['C_logprior'])) and rel_err(lp, g['C_logprior']).max() < 1e-12

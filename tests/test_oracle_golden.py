@@ -106,3 +106,16 @@ def test_ccm89_known_values():
     assert abs(k - (0.574 - 0.527 / 3.1) * 0.5**1.61) < 1e-15
     f = orc.extinct(np.array([5500.0, 8000.0]), np.array([1.0, 1.0]), 0.5)
     assert np.all(f < 1) and f[0] < f[1]
+
+
+def test_triple_system_ndim8():
+    c = golden_case('C')
+    g = c.g
+    for i, th in enumerate(c.theta):
+        lp = orc.logprior(list(th), 3, c.tmin, c.tmax, c.matrix, common.av_prior, prior=c.prior, rad_prior=True)
+        assert lp == g['C_logprior'][i] or abs(lp - g['C_logprior'][i]) < 1e-13 * abs(lp)
+    for i in (0, 5, 13, 15):
+        po = oracle_logpost(c, c.theta[i], rad_prior=True)
+        want = g['C_logpost'][i]
+        assert (po == want) or abs(po - want) < 1e-13 * abs(want)
+    assert np.all(np.isinf(g['C_logpost'][-4:]))
