@@ -105,6 +105,11 @@ int msx_stage_grid(msx_ctx *ctx, const double *wl, int64_t nwl, const double *te
  * a_v = 1, mft6.py:62); the per-grid-sample table is built inside msx_stage_grid with R_V = 3.1.  */
 int msx_ccm89_k(msx_ctx *ctx, const double *wl, int64_t n, double rv, double *out);
 
+/* ---- f3: the resample step of the grid loader: interp1d(x, y)(xq), x sorted ascending, host buffers
+ * (mft6.py:369-371).  MSX_ERR_RANGE when a query lies outside [x[0], x[n-1]] (scipy raises ValueError). */
+int msx_resample_linear(msx_ctx *ctx, const double *x, const double *y, int64_t n, const double *xq, int64_t m,
+                        double *out);
+
 /* ---- A3: instrumental broadening (pyasl.instrBroadGaussFast + edge patches, mft6.py:124-152) -- */
 /* one spectrum, host buffers; used by the drop-in `broaden()`                                     */
 int msx_broaden(msx_ctx *ctx, const double *wl, const double *flux, int64_t n, double resolution,

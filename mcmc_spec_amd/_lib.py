@@ -81,6 +81,7 @@ def load():
         'msx_device_info': (C.c_int, [vp, _ip, C.c_char_p, C.c_int]),
         'msx_stage_grid': (C.c_int, [vp, _dp, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp, C.POINTER(C.c_uint8)]),
         'msx_ccm89_k': (C.c_int, [vp, _dp, C.c_int64, C.c_double, _dp]),
+        'msx_resample_linear': (C.c_int, [vp, _dp, _dp, C.c_int64, _dp, C.c_int64, _dp]),
         'msx_broaden': (C.c_int, [vp, _dp, _dp, C.c_int64, C.c_double, C.c_double, _dp]),
         'msx_broaden_grid': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_double, C.c_double]),
         'msx_read_node': (C.c_int, [vp, C.c_int32, C.c_int32, _dp]),
@@ -101,6 +102,7 @@ def load():
 
 
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
+            'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
             'msx_logprob_batch_dev', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
@@ -182,6 +184,12 @@ class Context:
         wl = as_f64(np.atleast_1d(wl))
         out = np.empty_like(wl)
         self.check(self.lib.msx_ccm89_k(self.h, dptr(wl), len(wl), float(rv), dptr(out)))
+        return out
+
+    def resample_linear(self, x, y, xq):
+        x, y, xq = as_f64(x), as_f64(y), as_f64(xq)
+        out = np.empty_like(xq)
+        self.check(self.lib.msx_resample_linear(self.h, dptr(x), dptr(y), len(x), dptr(xq), len(xq), dptr(out)))
         return out
 
     def broaden(self, wl, flux, resolution, maxsig=5.0):

@@ -1255,6 +1255,30 @@ broaden_conv_kernel(const double *__restrict__ in, int64_t in_stride, double *__
     }
 }
 
+// f3: linear resample of one tabulated spectrum (x sorted ascending) onto query wavelengths with
+// np.interp / scipy interp1d(kind='linear') arithmetic (mft6.py:369-371): one thread per query.
+__global__ void resample_kernel(const double *__restrict__ xs, const double *__restrict__ ys, int64_t n,
+                                const double *__restrict__ xq, int64_t m, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double x = xq[i];
+    int64_t lo = 0, hi = n;  // first index with xs > x
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    const int64_t j = lo - 1;
+    double r;
+    if (j < 0) r = NAN;  // caller range-checks; unreachable
+    else if (j >= n - 1) r = ys[n - 1];
+    else if (xs[j] == x) r = ys[j];
+    else {
+        const double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
+        r = slope * (x - xs[j]) + ys[j];
+    }
+    out[i] = r;
+}
+
 // edge patches broad[0:5] = broad[5]; broad[n-10:n] = broad[n-11] (mft6.py:129-130) while copying
 __global__ void broaden_patch_kernel(const double *__restrict__ tmp, int64_t tmp_stride, double *__restrict__ dst,
                                      int64_t dst_stride, int64_t n) {
@@ -1514,6 +1538,36 @@ int msx_ccm89_k(msx_ctx *c, const double *wl, int64_t n, double rv, double *out)
     HIP_TRY(c, hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
     (void)hipFree(d_in);
     (void)hipFree(d_out);
+    return MSX_OK;
+}
+
+int msx_resample_linear(msx_ctx *c, const double *x, const double *y, int64_t n, const double *xq, int64_t m,
+                        double *out) {
+    if (!c || !x || !y || !xq || !out || n < 2 || m < 0) return fail(c, MSX_ERR_INVALID, "msx_resample_linear: bad arguments");
+    if (m == 0) return MSX_OK;
+    for (int64_t i = 1; i < n; ++i)
+        if (!(x[i] >= x[i - 1])) return fail(c, MSX_ERR_INVALID, "msx_resample_linear: x must be sorted ascending");
+    double qmin = INFINITY, qmax = -INFINITY;
+    for (int64_t i = 0; i < m; ++i) { qmin = xq[i] < qmin ? xq[i] : qmin; qmax = xq[i] > qmax ? xq[i] : qmax; }
+    if (qmin < x[0]) return fail(c, MSX_ERR_RANGE, "A value in x_new is below the interpolation range's minimum value.");
+    if (qmax > x[n - 1]) return fail(c, MSX_ERR_RANGE, "A value in x_new is above the interpolation range's maximum value.");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *d_x = nullptr, *d_y = nullptr, *d_q = nullptr, *d_o = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_x, sizeof(double) * n));
+    HIP_TRY(c, hipMalloc((void **)&d_y, sizeof(double) * n));
+    HIP_TRY(c, hipMalloc((void **)&d_q, sizeof(double) * m));
+    HIP_TRY(c, hipMalloc((void **)&d_o, sizeof(double) * m));
+    hipError_t e = hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_y, y, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_q, xq, sizeof(double) * m, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d_x, d_y, n, d_q, m, d_o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_o, sizeof(double) * m, hipMemcpyDeviceToHost);
+    (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_q); (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(c, MSX_ERR_HIP, hipGetErrorString(e));
     return MSX_OK;
 }
 

@@ -249,3 +249,24 @@ EXAMPLE_CMAG = [2.08, 1.3]  # param_koi2298.txt:27
 EXAMPLE_CERR = [0.14, 0.02]  # param_koi2298.txt:28
 EXAMPLE_PMAG = [13.815, 13.505, 13.355, 12.323, 11.826, 11.735]  # param_koi2298.txt:31
 EXAMPLE_PERR = [0.1, 0.1, 0.1, 0.026, 0.022, 0.019]  # param_koi2298.txt:32
+
+
+def write_btsettl_text_grid(grid_dir, teffs=(3000, 3100, 3200, 3300), loggs=(4.5, 5.0), lo=4850.0, hi=9150.0,
+                            seed=21):
+    """Write BT-Settl-format text files ``lte{TTT}-{g}-0.0a+0.0.BT-Settl.spec.7.txt`` (mft6.py:251): two
+    space-separated columns, wavelength [A] on an irregular grid (steps 0.05-0.35 A), flux.  Existing
+    files in ``grid_dir`` are overwritten.  Returns ``grid_dir``."""
+    import os
+    os.makedirs(grid_dir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    for t in teffs:
+        for g in loggs:
+            steps = rng.uniform(0.05, 0.35, int((hi - lo) / 0.2) + 200)
+            x = lo + np.cumsum(steps)
+            x = x[x < hi]
+            y = planck_surface_flux(x, float(t)) * (1.0 + 0.3 * np.sin(x / (3.0 + g)) * np.cos(x / 41.0))
+            name = 'lte{}-{}-0.0a+0.0.BT-Settl.spec.7.txt'.format(str(int(t / 1e2)).zfill(3), str(float(g)))
+            with open(os.path.join(grid_dir, name), 'w') as fh:
+                for a, b in zip(x, y):
+                    fh.write('{:.6f} {:.10e}\n'.format(a, b))
+    return grid_dir

@@ -405,3 +405,38 @@ def logposterior(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, tmin, t
     lh = loglikelihood(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, matrix, av=a,
                        bandlib=bandlib, temps=temps, lgs=lgs)
     return lp + lh
+
+
+# ------------------------------------------------------------------------------------- f3: loader
+def spec_interpolator(w, trange, lgrange, specrange, resolution=10000, grid_dir='BT-Settl_M-0.0a+0.0'):
+    """``spec_interpolator(..., models='btsettl')`` (mft6.py:323-385): read two-column BT-Settl text
+    files ``lte{TTT}-{g}-0.0a+0.0.BT-Settl.spec.7.txt``, keep samples within +-100 A of ``specrange``,
+    linearly resample every node onto ``np.arange(min, max, 0.2)``, broaden the data window
+    ``[min(w), max(w)]`` and splice.  ``w`` and ``specrange`` in Angstrom."""
+    from glob import glob
+    import os
+    files = glob(os.path.join(grid_dir, 'lte*'))
+    t, l = [], []
+    for f in files:  # mft6.py:330-340
+        base = os.path.basename(f)
+        nu = int(float(base.split('-')[0].split('e')[1]) * 1e2)
+        mu = float(base.split('-')[1])
+        if nu not in t and min(trange) <= nu <= max(trange):
+            t.append(nu)
+        if mu not in l and min(lgrange) <= mu <= max(lgrange):
+            l.append(mu)
+    wl = np.arange(min(specrange), max(specrange), 0.2)  # mft6.py:343
+    raw = {}
+    for tt in t:
+        for ll in l:
+            name = os.path.join(grid_dir, 'lte{}-{}-0.0a+0.0.BT-Settl.spec.7.txt'.format(str(int(tt / 1e2)).zfill(3), str(ll)))
+            xs, ys = [], []
+            with open(name) as fh:  # mft6.py:353-357
+                for line in fh:
+                    li = line.split(' ')
+                    if min(specrange) - 100 <= float(li[0]) <= max(specrange) + 100:
+                        xs.append(float(li[0]))
+                        ys.append(float(li[1]))
+            raw['{}, {}'.format(tt, ll)] = interp1d(np.array(xs), np.array(ys))(wl)  # mft6.py:369-371
+    raw['wl'] = wl
+    return broaden_specs_window(raw, w, resolution)  # mft6.py:373-383

@@ -107,6 +107,13 @@ def scratch_grid_dir(teffs, loggs):
     return d
 
 
+def write_btsettl_files(root, seed=21):
+    """Small synthetic BT-Settl-format text files (two space-separated columns, irregular wavelength
+    steps) for Teff 3000..3300 x logg 4.5, 5.0 -- the loader test regenerates them from the same seed."""
+    from mcmc_spec_amd import synth as sy
+    return sy.write_btsettl_text_grid(os.path.join(root, 'BT-Settl_M-0.0a+0.0'), seed=seed)
+
+
 def load_reference_filter_tables():
     """Real contrast filter tables as the reference reads them (mft6.py:598-600, 631-634)."""
     lp = np.genfromtxt(os.path.join(REF, 'bps/lp600.csv'), delimiter=',')
@@ -331,6 +338,25 @@ def main():
                 ll3.append(np.nan)
         out['C_loglike'], out['C_logprior'], out['C_logpost'] = np.array(ll3), np.array(lp3), np.array(po3)
         print('triple: {} walkers, {} inside the box'.format(len(po3), int(np.isfinite(po3).sum())))
+
+        # ------------------------------------------------------------ f3: the grid loader on text files
+        os.chdir(tempfile.mkdtemp(prefix='msx_golden_loader_'))  # a directory holding ONLY the text files
+        gdir = write_btsettl_files(os.getcwd(), seed=21)
+        mft6.pyasl = types.SimpleNamespace(instrBroadGaussFast=lambda wl_, f_, res_, maxsig=5:
+                                           orc.instr_broad_gauss_fast(wl_, f_, res_, maxsig=maxsig))
+        import io
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            sp_ref = mft6.spec_interpolator([6000.0, 8000.0], [3000, 3200], [4, 5.5], [5000, 9000], resolution=1700)
+        sp_orc = orc.spec_interpolator([6000.0, 8000.0], [3000, 3200], [4, 5.5], [5000, 9000], resolution=1700,
+                                       grid_dir=gdir)
+        assert sorted(sp_ref.keys()) == sorted(sp_orc.keys())
+        for k in sp_ref:
+            assert np.array_equal(sp_ref[k], sp_orc[k]), k
+        out['L_keys'] = np.array(sorted(k for k in sp_ref if k != 'wl'))
+        out['L_wl_ends'] = np.array([sp_ref['wl'][0], sp_ref['wl'][-1], len(sp_ref['wl'])])
+        out['L_sub'] = np.array([sp_ref[k][::53] for k in out['L_keys']])
+        print('loader: {} nodes x {} samples'.format(len(out['L_keys']), len(sp_ref['wl'])))
 
         # ------------------------------------------------------------ small helpers
         xm, xd, xv = rng.uniform(1, 2, 50), rng.uniform(1, 2, 50), rng.uniform(0.01, 0.02, 50)

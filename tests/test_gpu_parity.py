@@ -346,3 +346,27 @@ def test_triple_system_ndim8_matches_reference_golden():
     assert rel_err(ll, g['C_loglike'][ok]).max() < TIGHT
     lp = eng.logprior(c.theta)
     assert np.array_equal(np.isinf(lp), np.isinf(g['C_logprior'])) and rel_err(lp, g['C_logprior']).max() < 1e-12
+
+
+def test_loader_spec_interpolator_matches_reference_golden(tmp_path):
+    """f3: text files -> resample -> stage -> broaden on the device, against the reference's own
+    spec_interpolator output (golden) on the same synthetic BT-Settl-format files."""
+    from mcmc_spec_amd import loader, synth
+    import mcmc_spec_amd.mft6 as m
+    g = golden_case('A').g
+    gdir = synth.write_btsettl_text_grid(str(tmp_path / 'BT-Settl_M-0.0a+0.0'), seed=21)
+    m.clear_cache()
+    specs = loader.spec_interpolator([6000.0, 8000.0], [3000, 3200], [4, 5.5], [5000, 9000], resolution=1700,
+                                     grid_dir=gdir, cache=str(tmp_path / 'grid_cache.npz'))
+    keys = sorted(k for k in specs if k != 'wl')
+    assert keys == list(g['L_keys'])
+    assert [specs['wl'][0], specs['wl'][-1], len(specs['wl'])] == list(g['L_wl_ends'])
+    for k, want in zip(keys, g['L_sub']):
+        assert rel_err(specs[k][::53], want).max() < 1e-12, k
+    # second call is served from the binary cache and stages the same bits
+    again = loader.spec_interpolator([6000.0, 8000.0], [3000, 3200], [4, 5.5], [5000, 9000], resolution=1700,
+                                     grid_dir=gdir, cache=str(tmp_path / 'grid_cache.npz'))
+    assert all(np.array_equal(again[k], specs[k]) for k in specs)
+    assert m._engine_for(specs) is specs.engine  # the drop-in API reuses the staged grid
+    with pytest.raises(ValueError):  # resample range check = interp1d's ValueError
+        specs.engine.ctx.resample_linear(np.array([1.0, 2.0, 3.0]), np.ones(3), np.array([0.5]))
