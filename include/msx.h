@@ -40,6 +40,8 @@ extern "C" {
 #define MSX_MODE_LOGPOST 1      /* logposterior = logprior gate + loglikelihood (mft6.py:1459-1470) */
 #define MSX_MODE_CHISQ 2        /* loglikelihood(optimize=True): returns total chi^2 (mft6.py:1198) */
 #define MSX_MODE_LOGPRIOR 3     /* logprior alone (mft6.py:1207-1272); needs no spectrum pass       */
+#define MSX_MODE_OPT_STEP 4     /* fit_spec proposal chi^2 (mft6.py:997-1028); via msx_opt_step      */
+#define MSX_MODE_OPT_INIT 5     /* fit_spec initial guess (mft6.py:871-907); via msx_opt_init        */
 
 #define MSX_MAX_SPEC 3
 #define MSX_MAX_BANDS 8
@@ -129,6 +131,18 @@ int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n
 /* same with device pointers on a caller stream; does not synchronise.  block_threads = 0 -> auto  */
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
+
+/* ---- f4: the pre-optimiser's chi^2 (fit_spec, mft6.py:856-1137) on the same kernel --------------- */
+/* msx_opt_init: one chain per row of theta0 [nchains][ndim].  Normalises the data against each chain's
+ * initial (un-reddened) model like mft6.py:884-889, keeps the normalised vector and its median on the
+ * device, and returns the initial likelihood chi^2 = 3*iic*(n_c+n_p) + contrast + phot (mft6.py:893-904;
+ * the opt_prior terms of :910-929 are added by the host driver).                                        */
+int msx_opt_init(msx_ctx *ctx, const double *theta0, int64_t nchains, int32_t ndim, double *chi2_out,
+                 int32_t *status_out);
+/* msx_opt_step: proposal i belongs to chain[i]; returns the chi^2 of mft6.py:1011-1028 (no per-proposal
+ * continuum fit, spectrum weight 3) against that chain's stored data vector.                            */
+int msx_opt_step(msx_ctx *ctx, const double *theta, const int32_t *chain, int64_t n, int32_t ndim,
+                 double *chi2_out, int32_t *status_out);
 
 /* ---- A4-A6: make_composite (mft6.py:651-831, plot=False) -------------------------------------- */
 /* teff/logg/rad are [nspec]; use_distance = 0 mirrors `distance=False` (mft6.py:701-703).         */

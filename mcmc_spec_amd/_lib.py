@@ -88,6 +88,8 @@ def load():
         'msx_stage_problem': (C.c_int, [vp, C.POINTER(MsxProblem)]),
         'msx_logprob_batch': (C.c_int, [vp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_logprob_batch_dev': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32]),
+        'msx_opt_init': (C.c_int, [vp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
+        'msx_opt_step': (C.c_int, [vp, _dp, C.POINTER(C.c_int32), C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_make_composite': (C.c_int, [vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp,
                                          C.POINTER(C.c_int32)]),
         'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
@@ -104,7 +106,7 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
+            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
 
 def as_f64(a):
@@ -225,6 +227,23 @@ class Context:
         self.check(self.lib.msx_logprob_batch_dev(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim),
                                                   C.c_void_p(d_logp_ptr), C.c_void_p(d_status_ptr),
                                                   C.c_void_p(stream_ptr), int(block_threads)))
+
+    def opt_init(self, theta0):
+        theta0 = as_f64(theta0)
+        n, ndim = theta0.shape
+        chi, status = np.empty(n), np.empty(n, dtype=np.int32)
+        self.check(self.lib.msx_opt_init(self.h, dptr(theta0), n, ndim, dptr(chi),
+                                         status.ctypes.data_as(C.POINTER(C.c_int32))))
+        return chi, status
+
+    def opt_step(self, theta, chain):
+        theta = as_f64(theta)
+        chain = np.ascontiguousarray(chain, dtype=np.int32)
+        n, ndim = theta.shape
+        chi, status = np.empty(n), np.empty(n, dtype=np.int32)
+        self.check(self.lib.msx_opt_step(self.h, dptr(theta), chain.ctypes.data_as(C.POINTER(C.c_int32)), n, ndim,
+                                         dptr(chi), status.ctypes.data_as(C.POINTER(C.c_int32))))
+        return chi, status
 
     def make_composite(self, teff, logg, rad, use_distance, plx, win_n, nc, nph):
         teff, logg, rad = as_f64(teff), as_f64(logg), as_f64(rad)

@@ -81,6 +81,10 @@ struct DevProblem {
     double pmean[MSX_MAX_DIM], psig[MSX_MAX_DIM];
     int32_t use_av, dist_fit, rad_prior, has_prior;
     int32_t nspec;
+    // pre-optimiser (f4): per-chain normalised data vectors / their medians, walker -> chain map
+    double *opt_flux;          // [nchains][npix]
+    double *opt_med;           // [nchains]
+    const int32_t *opt_chain;  // [n] (OPT_STEP launches)
 #ifdef MSX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
 #endif
@@ -109,6 +113,17 @@ struct WalkerDesc {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
+// When is the composite (and its photometry) reddened?
+//   loglikelihood / logposterior : `av == True and extinct_guess > 0`                 mft6.py:1161
+//   fit_spec, proposals          : `var_par[1] > 0`                                    mft6.py:1002
+//   fit_spec, initial guess      : never (the extinct() call is commented out and the chi^2 uses the
+//                                  un-reddened `phot`)                                 mft6.py:880,901
+__device__ __forceinline__ bool redden_rule(int mode, int use_av, double a_v) {
+    if (mode == MSX_MODE_OPT_INIT) return false;
+    if (mode == MSX_MODE_OPT_STEP) return a_v > 0.0;
+    return use_av && a_v > 0.0;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
@@ -475,7 +490,7 @@ __device__ void build_recipe_wave(const DevProblem &P, const RecipeTabs &T, int 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // A5/A6: one (filter, star) or one photometric band per lane; magnitudes land in LDS
-    const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
+    const bool redden = redden_rule(mode, P.use_av, a_v);
     const int nb = P.nc + P.np;
     const int njobs = P.nc * NS + P.np;
     if (lane < njobs) {
@@ -706,7 +721,7 @@ __device__ void build_recipe_regs(const DevProblem &P, int mode, const double *_
     }
     MSX_STAMP(P, wk, 11);
     // ---- A5/A6: one (filter, star) or one photometric band per lane ---------------------------------
-    const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
+    const bool redden = redden_rule(mode, P.use_av, a_v);
     const int nb = P.nc + P.np;
     const int njobs = P.nc * NS + P.np;
     double val = 0.0;
@@ -855,6 +870,131 @@ __device__ unsigned long long radix_select(const double *model, int npix, unsign
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact np.median of v[0..npix) held in LDS, given the min / max keys of the vector.  All threads of
+// the block call it; S.hist[0..kBins) must be zero on entry (it is left dirty).
+//   1024 linear value bins between min and max (a monotone map, so ranks resolve bin by bin) -> block
+//   scan -> the <= 256 candidates of the median's bin are ranked all-pairs; the upper middle value
+//   comes from the same ranking or from the minimum of the higher bins.  Distributions that defeat
+//   the binning (heavy duplication, infinities) fall back to the bitwise radix select.
+// ------------------------------------------------------------------------------------------------
+__device__ double block_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
+                               BlockScratch &S) {
+    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    // k1 = lower middle rank (0-based); for even npix the median averages ranks k1 and k1+1.
+    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
+    const bool need_two = (npix & 1) == 0;
+    unsigned long long v1 = kmin, v2 = kmin;
+    if (kmin != kmax) {
+        const double vmin = val_of(kmin), vmax = val_of(kmax);
+        // monotone map value -> bin: (x - vmin) * scale is non-decreasing in x, so every key in a lower
+        // bin is <= every key in a higher bin and ranks can be resolved bin by bin.
+        const double scale = (double)kBins / (vmax - vmin);
+        const bool lin_ok = isfinite(scale) && scale > 0.0;
+        bool solved = false;
+        if (lin_ok) {
+            for (int p = tid; p < npix; p += B) {
+                int bin = (int)((model[p] - vmin) * scale);
+                bin = bin > kBins - 1 ? kBins - 1 : bin;
+                atomicAdd(&S.hist[bin], 1u);
+            }
+            __syncthreads();
+            // block scan over the bins: thread t owns bins [t*per, (t+1)*per)
+            const int per = kBins / B > 0 ? kBins / B : 1;
+            unsigned int own = 0;
+            if (tid * per < kBins)
+                for (int i = 0; i < per; ++i) own += S.hist[tid * per + i];
+            unsigned int inc = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_up(inc, o, kWave);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) S.wave_tot[wave] = inc;
+            __syncthreads();
+            unsigned int before = 0;
+            for (int x = 0; x < wave; ++x) before += S.wave_tot[x];
+            const unsigned int excl = before + inc - own;
+            if (own > 0 && excl <= k1 && k1 < excl + own) {  // exactly one thread
+                unsigned int kk = k1 - excl;
+                int bin = tid * per;
+                unsigned int cnt = S.hist[bin];
+                while (kk >= cnt) { kk -= cnt; ++bin; cnt = S.hist[bin]; }
+                S.sel_bin = (unsigned int)bin;
+                S.sel_k = kk;
+                S.sel_cnt = cnt;
+                S.cand_n = 0;
+                S.has_second = 0;
+            }
+            __syncthreads();
+            const unsigned int cnt = S.sel_cnt, kk = S.sel_k;
+            const int sel = (int)S.sel_bin;
+            if (cnt <= (unsigned int)kSelectFinish) {
+                // gather the candidates of the selected bin; keep the smallest key of the higher bins
+                unsigned long long above = ~0ull;
+                for (int p = tid; p < npix; p += B) {
+                    const double x = model[p];
+                    int bin = (int)((x - vmin) * scale);
+                    bin = bin > kBins - 1 ? kBins - 1 : bin;
+                    const unsigned long long key = key_of(x);
+                    if (bin == sel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+                    else if (bin > sel && key < above) above = key;
+                }
+                above = wave_min_u64(above);
+                if (lane == 0) S.above[wave] = above;
+                __syncthreads();
+                if (tid < (int)cnt) {  // all-pairs rank, ties broken by slot
+                    const unsigned long long mine = S.cand[tid];
+                    unsigned int r = 0;
+                    for (unsigned int j = 0; j < cnt; ++j) {
+                        const unsigned long long o = S.cand[j];
+                        r += (o < mine) || (o == mine && j < (unsigned int)tid);
+                    }
+                    if (r == kk) S.sel_result[0] = mine;
+                    if (r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
+                }
+                __syncthreads();
+                v1 = S.sel_result[0];
+                if (S.has_second) {
+                    v2 = S.sel_result[1];
+                } else {
+                    v2 = S.above[0];
+                    for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+                }
+                solved = true;
+            }
+        }
+        if (!solved) {  // adversarial value distribution: bitwise radix select (always terminates)
+            __syncthreads();
+            v1 = radix_select(model, npix, k1, kmin, kmax, S);
+            v2 = v1;
+            if (need_two) {
+                // rank k1+1: equals v1 when v1 is duplicated past rank k1, else the smallest key above v1
+                unsigned int cle = 0;
+                unsigned long long nxt = ~0ull;
+                for (int p = tid; p < npix; p += B) {
+                    const unsigned long long key = key_of(model[p]);
+                    cle += key <= v1;
+                    if (key > v1 && key < nxt) nxt = key;
+                }
+                if (tid == 0) S.cnt_le = 0;
+                __syncthreads();
+                unsigned int wc = cle;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wc += __shfl_down(wc, o, kWave);
+                nxt = wave_min_u64(nxt);
+                if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.above[wave] = nxt; }
+                __syncthreads();
+                v2 = S.above[0];
+                for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+                if (S.cnt_le >= k1 + 2) v2 = v1;
+            }
+        }
+    }
+    // np.median: mean of the two middle values for even npix
+    return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // THE HOT KERNEL: one workgroup per walker.
 //   phase 0  wave 0 builds the walker's recipe on 64 lanes (prior gate, A1, A2, A4, A5, A6)
 //   phase A  blend + redden + resample into LDS; fit sums; value range           (A2, A4, A7, A8.1)
@@ -991,156 +1131,83 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
     // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
     if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
         if (tid == 0) {
-            logp[wk] = (mode == MSX_MODE_CHISQ) ? NAN : -INFINITY;
+            logp[wk] = (mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT) ? NAN : -INFINITY;
+            if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
             status[wk] = MSX_W_OK;
         }
         return;
     }
 
     // ---- phase B: exact median (np.median, mft6.py:1173) -----------------------------------------------
-    // k1 = lower middle rank (0-based); for even npix the median averages ranks k1 and k1+1.
-    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
-    const bool need_two = (npix & 1) == 0;
-    unsigned long long v1 = kmin, v2 = kmin;
-    if (kmin != kmax) {
-        const double vmin = val_of(kmin), vmax = val_of(kmax);
-        // monotone map value -> bin: (x - vmin) * scale is non-decreasing in x, so every key in a lower
-        // bin is <= every key in a higher bin and ranks can be resolved bin by bin.
-        const double scale = (double)kBins / (vmax - vmin);
-        const bool lin_ok = isfinite(scale) && scale > 0.0;
-        bool solved = false;
-        if (lin_ok) {
-            for (int p = tid; p < npix; p += B) {
-                int bin = (int)((model[p] - vmin) * scale);
-                bin = bin > kBins - 1 ? kBins - 1 : bin;
-                atomicAdd(&S.hist[bin], 1u);
-            }
-            __syncthreads();
-            // block scan over the bins: thread t owns bins [t*per, (t+1)*per)
-            const int per = kBins / B > 0 ? kBins / B : 1;
-            unsigned int own = 0;
-            if (tid * per < kBins)
-                for (int i = 0; i < per; ++i) own += S.hist[tid * per + i];
-            unsigned int inc = own;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned int t = __shfl_up(inc, o, kWave);
-                if (lane >= o) inc += t;
-            }
-            if (lane == 63) S.wave_tot[wave] = inc;
-            __syncthreads();
-            unsigned int before = 0;
-            for (int x = 0; x < wave; ++x) before += S.wave_tot[x];
-            const unsigned int excl = before + inc - own;
-            if (own > 0 && excl <= k1 && k1 < excl + own) {  // exactly one thread
-                unsigned int kk = k1 - excl;
-                int bin = tid * per;
-                unsigned int cnt = S.hist[bin];
-                while (kk >= cnt) { kk -= cnt; ++bin; cnt = S.hist[bin]; }
-                S.sel_bin = (unsigned int)bin;
-                S.sel_k = kk;
-                S.sel_cnt = cnt;
-                S.cand_n = 0;
-                S.has_second = 0;
-            }
-            __syncthreads();
-            const unsigned int cnt = S.sel_cnt, kk = S.sel_k;
-            const int sel = (int)S.sel_bin;
-            if (cnt <= (unsigned int)kSelectFinish) {
-                // gather the candidates of the selected bin; keep the smallest key of the higher bins
-                unsigned long long above = ~0ull;
-                for (int p = tid; p < npix; p += B) {
-                    const double x = model[p];
-                    int bin = (int)((x - vmin) * scale);
-                    bin = bin > kBins - 1 ? kBins - 1 : bin;
-                    const unsigned long long key = key_of(x);
-                    if (bin == sel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
-                    else if (bin > sel && key < above) above = key;
-                }
-                above = wave_min_u64(above);
-                if (lane == 0) S.above[wave] = above;
-                __syncthreads();
-                if (tid < (int)cnt) {  // all-pairs rank, ties broken by slot
-                    const unsigned long long mine = S.cand[tid];
-                    unsigned int r = 0;
-                    for (unsigned int j = 0; j < cnt; ++j) {
-                        const unsigned long long o = S.cand[j];
-                        r += (o < mine) || (o == mine && j < (unsigned int)tid);
-                    }
-                    if (r == kk) S.sel_result[0] = mine;
-                    if (r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
-                }
-                __syncthreads();
-                v1 = S.sel_result[0];
-                if (S.has_second) {
-                    v2 = S.sel_result[1];
-                } else {
-                    v2 = S.above[0];
-                    for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
-                }
-                solved = true;
-            }
-        }
-        if (!solved) {  // adversarial value distribution: bitwise radix select (always terminates)
-            __syncthreads();
-            v1 = radix_select(model, npix, k1, kmin, kmax, S);
-            v2 = v1;
-            if (need_two) {
-                // rank k1+1: equals v1 when v1 is duplicated past rank k1, else the smallest key above v1
-                unsigned int cle = 0;
-                unsigned long long nxt = ~0ull;
-                for (int p = tid; p < npix; p += B) {
-                    const unsigned long long key = key_of(model[p]);
-                    cle += key <= v1;
-                    if (key > v1 && key < nxt) nxt = key;
-                }
-                if (tid == 0) S.cnt_le = 0;
-                __syncthreads();
-                unsigned int wc = cle;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) wc += __shfl_down(wc, o, kWave);
-                nxt = wave_min_u64(nxt);
-                if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.above[wave] = nxt; }
-                __syncthreads();
-                v2 = S.above[0];
-                for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
-                if (S.cnt_le >= k1 + 2) v2 = v1;
-            }
-        }
-    }
-    // np.median: mean of the two middle values for even npix
-    const double med_model = need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+    const double med_model = block_median(model, npix, kmin, kmax, S);
     MSX_STAMP(P, wk, 4);
     MSX_STAMP(P, wk, 5);
 
     // ---- phase C: median scale, quadratic continuum fit, chi^2 (A8.2, A8.3, A9) ------------------
-    const double scale = P.median_flux / med_model;  // mft6.py:1173
+    // Pre-optimiser variants (fit_spec, mft6.py:856-1137): OPT_INIT normalises the data against the
+    // chain's initial model like the hot path does and KEEPS the normalised vector + its median
+    // (:888-889); OPT_STEP compares every proposal with that stored vector, with no per-proposal
+    // continuum fit (:1011-1015).  Both weight the spectrum term by 3 (:893,:1015).
+    const bool opt_step = mode == MSX_MODE_OPT_STEP, opt_init = mode == MSX_MODE_OPT_INIT;
+    const int64_t chain = opt_step ? (int64_t)P.opt_chain[wk] : wk;
+    const double *__restrict__ dflux = opt_step ? P.opt_flux + chain * npix : P.pix_flux;
+    const double med_data = opt_step ? P.opt_med[chain] : P.median_flux;
+    const double scale = med_data / med_model;  // mft6.py:1173 / :1011
     double coef[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
     double chi = 0.0;
+    unsigned long long dmin = ~0ull, dmax = 0ull;
     for (int p = tid; p < npix; p += B) {
         const double ms = model[p] * scale;
-        const double u = P.pix_u[p];
-        const double poly = fma(fma(coef[2], u, coef[1]), u, coef[0]);
-        const double dn = P.pix_flux[p] / poly;  // mft6.py:196
+        double dn;
+        if (opt_step) {
+            dn = dflux[p];
+        } else {
+            const double u = P.pix_u[p];
+            const double poly = fma(fma(coef[2], u, coef[1]), u, coef[0]);
+            dn = dflux[p] / poly;  // mft6.py:196
+        }
         const double r = ms - dn;
         const double e = P.pix_err[p];
         chi += (r * r) / (e * e);  // mft6.py:120
+        if (opt_init) {
+            P.opt_flux[wk * npix + p] = dn;
+            model[p] = dn;  // the model value is dead now; reuse the LDS vector for median(data')
+            const unsigned long long key = key_of(dn);
+            dmin = key < dmin ? key : dmin;
+            dmax = key > dmax ? key : dmax;
+        }
     }
     MSX_STAMP(P, wk, 6);
     chi = wave_sum(chi);
     if (lane == 0) S.chi[wave] = chi;
+    if (opt_init) {
+        const unsigned long long a = wave_min_u64(dmin), b = wave_max_u64(dmax);
+        if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
+        for (int i = tid; i < kBins; i += B) S.hist[i] = 0;
+    }
     __syncthreads();
     MSX_STAMP(P, wk, 7);
+    double tot = 0.0;
+    for (int x = 0; x < nw; ++x) tot += S.chi[x];
+    if (opt_init) {
+        dmin = S.kmin[0]; dmax = S.kmax[0];
+        for (int x = 1; x < nw; ++x) {
+            dmin = S.kmin[x] < dmin ? S.kmin[x] : dmin;
+            dmax = S.kmax[x] > dmax ? S.kmax[x] : dmax;
+        }
+        const bool bad = dmax > key_of(INFINITY) || dmin < key_of(-INFINITY);
+        const double md = bad ? NAN : block_median(model, npix, dmin, dmax, S);  // np.median(flux), :1011
+        if (tid == 0) P.opt_med[wk] = md;
+    }
     if (tid == 0) {
-        double tot = 0.0;
-        for (int x = 0; x < nw; ++x) tot += S.chi[x];
-        const double iic = tot / (double)npix;  // mft6.py:1179
-        const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191
+        double iic = tot / (double)npix;  // mft6.py:1179
+        if (opt_step || opt_init) iic = iic * 3;  // mft6.py:893,1015
+        const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191 / :904 / :1028
         double out;
-        if (mode == MSX_MODE_CHISQ) out = total;  // mft6.py:1198-1199
+        if (mode == MSX_MODE_CHISQ || opt_step || opt_init) out = total;  // mft6.py:1198-1199
         else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
         logp[wk] = out;
         status[wk] = MSX_W_OK;
@@ -1358,6 +1425,9 @@ struct msx_ctx {
     double *d_misc = nullptr;  // composite args / desc / small outputs
     double *d_spec = nullptr;
     int64_t cap_spec = 0;
+    double *d_opt_flux = nullptr, *d_opt_med = nullptr;
+    int32_t *d_opt_chain = nullptr;
+    int64_t opt_chains = 0, cap_chain = 0;
     int max_dyn_lds = 0;
 };
 
@@ -1394,6 +1464,10 @@ void free_problem(msx_ctx *c) {
     for (void *p : c->prob_allocs) (void)hipFree(p);
     c->prob_allocs.clear();
     c->problem_staged = false;
+    if (c->d_opt_flux) (void)hipFree(c->d_opt_flux);
+    if (c->d_opt_med) (void)hipFree(c->d_opt_med);
+    c->d_opt_flux = c->d_opt_med = nullptr;
+    c->opt_chains = 0;
 }
 
 void free_grid(msx_ctx *c) {
@@ -1475,7 +1549,7 @@ void msx_destroy(msx_ctx *c) {
     (void)hipSetDevice(c->device);
     free_problem(c);
     free_grid(c);
-    void *ptrs[] = {c->d_theta, c->d_logp, c->d_status, c->d_misc, c->d_spec};
+    void *ptrs[] = {c->d_theta, c->d_logp, c->d_status, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1770,7 +1844,9 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (n < 0 || !d_theta || !d_logp || !d_status) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad arguments");
     if (ndim != 2 * c->P.nspec + 2)
         return fail(c, MSX_ERR_INVALID, "P0 doesn't match what I was expecting (ndim must be 2*nspec+2)");
-    if (mode < 0 || mode > 3) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad mode");
+    if (mode < 0 || mode > 5) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad mode");
+    if ((mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT) && !c->P.opt_flux)
+        return fail(c, MSX_ERR_STATE, "optimiser modes go through msx_opt_init / msx_opt_step");
     if (n == 0) return MSX_OK;
     int B = block_threads > 0 ? block_threads : pick_block(c, n, c->P.npix);
     // the median's bin scan assigns kBins/B bins to each thread and the radix fallback clears its
@@ -1810,6 +1886,43 @@ int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, 
     HIP_TRY(c, hipMemcpyAsync(status_out, c->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MSX_OK;
+}
+
+int msx_opt_init(msx_ctx *c, const double *theta0, int64_t nchains, int32_t ndim, double *chi2_out,
+                 int32_t *status_out) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_opt_init: no problem staged");
+    if (!theta0 || !chi2_out || !status_out || nchains < 1) return fail(c, MSX_ERR_INVALID, "msx_opt_init: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->d_opt_flux) (void)hipFree(c->d_opt_flux);
+    if (c->d_opt_med) (void)hipFree(c->d_opt_med);
+    c->d_opt_flux = c->d_opt_med = nullptr; c->opt_chains = 0;
+    c->P.opt_flux = c->P.opt_med = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_opt_flux, sizeof(double) * nchains * c->P.npix));
+    HIP_TRY(c, hipMalloc((void **)&c->d_opt_med, sizeof(double) * nchains));
+    c->opt_chains = nchains;
+    c->P.opt_flux = c->d_opt_flux; c->P.opt_med = c->d_opt_med; c->P.opt_chain = nullptr;
+    return msx_logprob_batch(c, MSX_MODE_OPT_INIT, theta0, nchains, ndim, chi2_out, status_out);
+}
+
+int msx_opt_step(msx_ctx *c, const double *theta, const int32_t *chain, int64_t n, int32_t ndim, double *chi2_out,
+                 int32_t *status_out) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!c->problem_staged || !c->P.opt_flux) return fail(c, MSX_ERR_STATE, "msx_opt_step: call msx_opt_init first");
+    if (!theta || !chain || !chi2_out || !status_out || n < 0) return fail(c, MSX_ERR_INVALID, "msx_opt_step: bad arguments");
+    if (n == 0) return MSX_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (chain[i] < 0 || chain[i] >= c->opt_chains) return fail(c, MSX_ERR_INVALID, "msx_opt_step: chain index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > c->cap_chain) {
+        if (c->d_opt_chain) (void)hipFree(c->d_opt_chain);
+        c->d_opt_chain = nullptr; c->cap_chain = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_opt_chain, sizeof(int32_t) * std::max<int64_t>(n, 1024)));
+        c->cap_chain = std::max<int64_t>(n, 1024);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_opt_chain, chain, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    c->P.opt_chain = c->d_opt_chain;
+    return msx_logprob_batch(c, MSX_MODE_OPT_STEP, theta, n, ndim, chi2_out, status_out);
 }
 
 int msx_make_composite(msx_ctx *c, const double *teff, const double *logg, const double *rad, int32_t use_distance,

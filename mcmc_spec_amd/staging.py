@@ -252,3 +252,13 @@ def isochrone_logg(teff, matrix):
     if np.any(np.asarray(teff) < x[0]) or np.any(np.asarray(teff) > x[-1]):
         raise ValueError('A value in x_new is outside the interpolation range (isochrone Teff)')
     return np.interp(teff, x, g)
+
+
+def isochrone_radius(teff, matrix):
+    """Host-side Stefan-Boltzmann radius [Rsun] from the isochrone luminosity (get_radius, mft6.py:66-85)."""
+    x, _, lum = sorted_isochrone(np.asarray(matrix))
+    if np.any(np.asarray(teff) < x[0]) or np.any(np.asarray(teff) > x[-1]):
+        raise ValueError('A value in x_new is outside the interpolation range (isochrone Teff)')
+    lm = np.interp(teff, x, lum)
+    sigma_sb, lsun, rsun = 5.670374e-5, 3.839e33, 6.957e10
+    return np.sqrt(lm * lsun / (4 * np.pi * sigma_sb * np.asarray(teff, dtype=float) ** 4)) / rsun

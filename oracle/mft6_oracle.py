@@ -440,3 +440,53 @@ def spec_interpolator(w, trange, lgrange, specrange, resolution=10000, grid_dir=
             raw['{}, {}'.format(tt, ll)] = interp1d(np.array(xs), np.array(ys))(wl)  # mft6.py:369-371
     raw['wl'] = wl
     return broaden_specs_window(raw, w, resolution)  # mft6.py:373-383
+
+
+# ------------------------------------------------------------------------ f4: pre-optimiser chi^2
+def opt_prior(vals, pval, psig):
+    """mft6.py:833-854 (chi^2-form Gaussian terms; entries with pval == 0 are skipped in the list branch)."""
+    pp = []
+    if len(pval) == 1 or type(pval) == float:
+        try:
+            pp.append(((float(vals) - float(pval)) / float(psig)) ** 2)
+        except Exception:
+            pp.append(((vals[0] - pval[0]) / psig[0]) ** 2)
+    else:
+        for k, p in enumerate(pval):
+            if p != 0:
+                pp.append(((vals[k] - pval[k]) / (psig[k])) ** 2)
+    return np.sum(pp)
+
+
+def fit_spec_init(wl_aa, flux, err, reg, t_guess, rad_guess, plx, fr, specs, ctm, ptm, tmi, tma, matrix, nspec=2,
+                  bandlib=None):
+    """The initial guess of ``fit_spec`` (mft6.py:871-907): un-reddened composite, data normalised ONCE
+    against it.  Returns (likelihood chi^2 with spectrum weight 3, normalised data vector)."""
+    lg = [get_logg(t, matrix) for t in t_guess]
+    wave1, cspec, contrast, phot_cwl, phot, _ = make_composite(t_guess, lg, rad_guess, plx, fr[2], fr[5], reg, specs,
+                                                               ctm, ptm, tmi, tma, nspec=nspec, bandlib=bandlib)
+    model = interp1d(wave1, cspec)(wl_aa)  # mft6.py:884-885 (no extinct: :880 is commented out)
+    model = model * (np.median(flux) / np.median(model))  # mft6.py:888
+    flux_n = norm_spec(wl_aa, model, flux)  # mft6.py:889
+    iic = np.sum(chisq(model, flux_n, err)) / len(flux_n) * 3  # mft6.py:892-893
+    chi_c = chisq(contrast, fr[0], fr[1])
+    ip = chisq(phot, fr[3], fr[4])  # mft6.py:901 uses the UN-reddened photometry
+    return np.sum((iic * (len(chi_c) + len(ip)), np.sum(chi_c), np.sum(ip))), flux_n
+
+
+def fit_spec_proposal(wl_aa, flux_n, err, reg, teff, a_v, rad, plx, fr, specs, ctm, ptm, tmi, tma, matrix, nspec=2,
+                      bandlib=None):
+    """Likelihood chi^2 of one proposal inside ``fit_spec`` (mft6.py:997-1028): reddened if A_V > 0,
+    median-scaled to the already-normalised data, NO per-proposal continuum fit, spectrum weight 3."""
+    lg = [get_logg(v, matrix) for v in teff]
+    wave1, cspec, contrast, phot_cwl, phot, _ = make_composite(teff, lg, rad, float(plx), fr[2], fr[5], reg, specs, ctm,
+                                                               ptm, tmi, tma, nspec=nspec, bandlib=bandlib)
+    if a_v > 0:  # mft6.py:1002-1004
+        cspec = extinct(wave1, cspec, a_v)
+        phot = -2.5 * np.log10(extinct(phot_cwl, 10 ** (-0.4 * phot), a_v))
+    model = interp1d(wave1, cspec)(wl_aa)
+    model = model * (np.median(flux_n) / np.median(model))  # mft6.py:1011
+    ttc = np.sum(chisq(model, flux_n, err)) / len(flux_n) * 3  # mft6.py:1014-1015
+    chi_c = chisq(contrast, fr[0], fr[1])
+    chi_p = chisq(phot, fr[3], fr[4])
+    return np.sum((ttc * (len(chi_c) + len(chi_p)), np.sum(chi_c), np.sum(chi_p)))  # mft6.py:1028

@@ -86,6 +86,33 @@ def av_prior(dist_pc):
     return np.mean(s), np.std(s)
 
 
+class _NumpyCompat:
+    """``mft6.fit_spec`` stacks ragged rows with ``np.vstack((sp, gi))`` (mft6.py:1066), which old NumPy
+    turned into an object array and NumPy >= 1.24 refuses.  This proxy restores exactly that behaviour
+    (object rows) and forwards everything else to the installed NumPy untouched -- no arithmetic is
+    involved, ``sp`` is only bookkeeping that fit_spec writes to ``params{n}.txt``."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def vstack(tup):
+        try:
+            return np.vstack(tup)
+        except ValueError:
+            rows = []
+            for a in tup:
+                if isinstance(a, np.ndarray) and a.dtype == object and a.ndim == 2:
+                    rows += [list(r) for r in a]
+                else:
+                    rows.append(list(a))
+            out = np.empty((len(rows), len(rows[0])), dtype=object)
+            for i, r in enumerate(rows):
+                for j, x in enumerate(r):
+                    out[i, j] = x
+            return out
+
+
 def patch_third_party(mft6, bandlib):
     mft6.extinction = types.SimpleNamespace(
         ccm89=lambda wl, av, rv: orc.ccm89(wl, av, rv),
@@ -338,6 +365,47 @@ def main():
                 ll3.append(np.nan)
         out['C_loglike'], out['C_logprior'], out['C_logpost'] = np.array(ll3), np.array(lp3), np.array(po3)
         print('triple: {} walkers, {} inside the box'.format(len(po3), int(np.isfinite(po3).sum())))
+
+        # ------------------------------------------------------------ f4: fit_spec (pre-optimiser), dataset B
+        # The reference draws its proposals from the unseeded global RNG (make_varied_param, mft6.py:211-228);
+        # to get a reproducible trajectory the draw is redirected to a seeded Generator with the same call
+        # pattern.  Everything else -- bounds, counters, repair loops, accept rule, chi^2 -- is fit_spec itself.
+        prng = np.random.default_rng(123)
+        mft6.make_varied_param = lambda init, sig: [prng.normal(init[n], sig[n]) for n in range(len(init))]
+        outdir = tempfile.mkdtemp(prefix='msx_golden_fit_')
+        mft6.np = _NumpyCompat()
+        steps = 24
+        start = dict(t=[3700.0, 3200.0], av=0.2, rad=[0.6, 0.45], plx=2.2e-3)
+        best, cs = mft6.fit_spec(0, outdir, wb.copy(), sb.copy(), eb, [min(wb), max(wb)], list(start['t']),
+                                 [start['av'], 0.106, 0.01], list(start['rad']), frB, specs, [3000.0, 4200.0],
+                                 [start['plx'], 2.0732e-3, 0.0277e-3], ctm_syn, ptm6, tmiB, tmaB, None, matrix, 10.0, 20.0,
+                                 nspec=2, steps=steps, dist_fit=True, rad_prior=True)
+        out['D_start'] = np.array(start['t'] + [start['av']] + start['rad'] + [start['plx']])
+        out['D_steps'] = np.array([steps])
+        out['D_best'] = np.array([float(x) for x in best.split()])
+        out['D_best_chi'] = np.array([cs])
+        out['D_params'] = np.atleast_2d(np.genfromtxt(os.path.join(outdir, 'params0.txt')))
+        # chisq0.txt holds `savechi[n] savetest[n]`; savetest starts with four non-chi^2 entries
+        # ([t_guess, lg_guess, extinct_guess, rad_guess], mft6.py:939), so column 2 is the test chi^2 of
+        # proposal n-3 from line 4 on and a list / scalar guess before that (kept as NaN here).
+        rows = []
+        for line in open(os.path.join(outdir, 'chisq0.txt')):
+            tok = line.split()
+            try:
+                second = float(' '.join(tok[1:]))
+            except ValueError:
+                second = np.nan
+            rows.append([float(tok[0]), second])
+        out['D_chisq'] = np.array(rows)
+        # oracle restatement of the two chi^2 kernels of fit_spec on the first proposals
+        chi0, flux_n = orc.fit_spec_init(wb * 1e4, sb, eb, [min(wb), max(wb)], start['t'], start['rad'], start['plx'],
+                                         frB, specs, ctm_syn, ptm6, tmiB, tmaB, matrix, bandlib=bandlib)
+        out['D_init_like'] = np.array([chi0])
+        out['D_flux_norm_sub'] = flux_n[::7]
+        print('fit_spec: {} evaluated proposals, best chi^2 {:.6g} (initial likelihood chi^2 {:.6g})'.format(
+            len(out['D_chisq']), cs, chi0))
+
+        mft6.np = np
 
         # ------------------------------------------------------------ f3: the grid loader on text files
         os.chdir(tempfile.mkdtemp(prefix='msx_golden_loader_'))  # a directory holding ONLY the text files

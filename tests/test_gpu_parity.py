@@ -370,3 +370,59 @@ def test_loader_spec_interpolator_matches_reference_golden(tmp_path):
     assert m._engine_for(specs) is specs.engine  # the drop-in API reuses the staged grid
     with pytest.raises(ValueError):  # resample range check = interp1d's ValueError
         specs.engine.ctx.resample_linear(np.array([1.0, 2.0, 3.0]), np.ones(3), np.array([0.5]))
+
+
+def test_fit_spec_trajectory_matches_the_reference(tmp_path):
+    """f4: the reference's fit_spec was run with its proposal draws redirected to a seeded Generator
+    (tests/golden/make_golden.py); the batched GPU optimiser with the same seed must walk the same
+    trajectory: same accepted parameters, same running-best chi^2, same test chi^2 per proposal."""
+    from mcmc_spec_amd import bands, optimizer
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    g = c.g
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    # initial-guess kernel vs the oracle's restatement
+    from oracle import mft6_oracle as orc
+    st = g['D_start']
+    like0, _ = eng.ctx.opt_init(st[None, :])
+    assert rel_err(like0[0], g['D_init_like'][0]) < TIGHT
+    res = optimizer.fit_spec_batch(eng, st[None, :], [3000.0, 4200.0], (2.0732e-3, 0.0277e-3), c.matrix,
+                                   common.av_table_exact(), nspec=2, steps=int(g['D_steps'][0]), dist_fit=True,
+                                   rad_prior=True, rngs=[np.random.default_rng(123)], dirname=str(tmp_path))
+    line, best_chi, ch = res[0]
+    ref = g['D_chisq']
+    assert len(ch.savechi) - 1 == len(ref)
+    assert rel_err(np.array(ch.savechi[1:]), ref[:, 0]).max() < TIGHT          # running best after each proposal
+    # the reference's file pairs savechi[n] with savetest[n] whose first four entries are guesses, not chi^2
+    assert rel_err(np.array(ch.savetest[:len(ref) - 3]), ref[3:, 1]).max() < TIGHT
+    assert rel_err(best_chi, g['D_best_chi'][0]) < TIGHT
+    assert rel_err(np.array([float(x) for x in line.split()]), g['D_best']).max() < 1e-12
+    got_params = np.loadtxt(tmp_path / 'params0.txt')
+    assert got_params.shape == g['D_params'].shape and rel_err(got_params, g['D_params']).max() < 1e-12
+    # a proposal chi^2 straight against the oracle restatement of mft6.py:997-1028
+    _, flux_n = orc.fit_spec_init(c.data[0] * 1e4, c.data[1], c.err, c.r, st[:2], st[3:5], st[5], c.fr, c.specs, c.ctm,
+                                  c.ptm, c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    th = c.theta[:6]
+    got, _ = eng.ctx.opt_step(th, np.zeros(len(th), dtype=np.int32))
+    want = np.array([orc.fit_spec_proposal(c.data[0] * 1e4, flux_n, c.err, c.r, t[:2], t[2], t[3:5], t[5], c.fr, c.specs,
+                                           c.ctm, c.ptm, c.tmi, c.tma, c.matrix, bandlib=c.bandlib) for t in th])
+    assert rel_err(got, want).max() < TIGHT
+
+
+def test_optimize_fit_batched_descends_and_writes_reference_files(tmp_path):
+    from mcmc_spec_amd import optimizer
+    c = golden_case('B')
+    m = _dropin(c)
+    out = optimizer.optimize_fit(str(tmp_path), c.data, c.err, c.specs, 24, c.fr, [2.0732e-3, 0.0277e-3], [0.106, 0.01],
+                                 1700, c.ctm, c.ptm, c.tmi, c.tma, None, c.matrix, 10.0, 20.0, nspec=2, nstep=30,
+                                 dist_fit=True, rad_prior=False, seed=4)
+    assert len(out) == 24
+    cs = np.loadtxt(tmp_path / 'optimize_cs.txt')
+    pars = np.loadtxt(tmp_path / 'optimize_res.txt')
+    assert cs.shape == (24,) and pars.shape == (24, 6)
+    for line, best, ch in out:
+        assert best <= ch.savechi[0] and np.all(np.diff(ch.savechi) <= 0)   # running best never increases
+    assert (tmp_path / 'params0.txt').exists() and (tmp_path / 'chisq23.txt').exists()

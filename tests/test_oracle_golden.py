@@ -119,3 +119,25 @@ def test_triple_system_ndim8():
         want = g['C_logpost'][i]
         assert (po == want) or abs(po - want) < 1e-13 * abs(want)
     assert np.all(np.isinf(g['C_logpost'][-4:]))
+
+
+def test_fit_spec_pieces_against_reference_trajectory():
+    """f4: the oracle's restatement of fit_spec's two chi^2 computations reproduces the reference's own
+    numbers: initial chi^2 (first savechi minus the opt_prior terms is checked through the total) and the
+    test chi^2 of the first accepted proposal."""
+    c = golden_case('B')
+    g = c.g
+    st = g['D_start']
+    chi0, flux_n = orc.fit_spec_init(c.data[0] * 1e4, c.data[1], c.err, c.r, st[:2], st[3:5], st[5], c.fr, c.specs,
+                                     c.ctm, c.ptm, c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert chi0 == g['D_init_like'][0] and np.array_equal(flux_n[::7], g['D_flux_norm_sub'])
+    # proposal 1 of the reference run = params row 0 when accepted; rebuild its total with the prior terms
+    row = g['D_params'][2]  # first row that differs from the start = an accepted proposal
+    like = orc.fit_spec_proposal(c.data[0] * 1e4, flux_n, c.err, c.r, row[:2], row[2], row[3:5], row[5], c.fr, c.specs,
+                                 c.ctm, c.ptm, c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    mu, sg = common.av_prior(1.0 / row[5])
+    mr = [float(orc.get_radius(t, c.matrix)) for t in row[:2]]
+    si_rad = [0.1 * r for r in st[3:5]]  # coarse radius steps are the sigma of the radius prior (mft6.py:1042)
+    total = like + ((row[2] - mu) / sg) ** 2 + ((row[5] - 2.0732e-3) / 0.0277e-3) ** 2 \
+        + ((row[3] - mr[0]) / si_rad[0]) ** 2 + ((row[4] - mr[1] / mr[0]) / si_rad[1]) ** 2
+    assert abs(total - g['D_chisq'][2, 0]) < 1e-9 * total
