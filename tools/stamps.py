@@ -50,6 +50,15 @@ def main():
     de = np.diff(e, axis=1)
     for i, nm in enumerate(['stage tables+barrier', 'theta load', 'prior', 'iso+bracket', 'band loads+log10', 'chi combine', 'barrier']):
         print('    phase0/{:22s} median {:8d} cycles'.format(nm, int(np.median(de[:, i]))))
+    med = np.zeros((n, 8), dtype=np.uint64)
+    fm = eng.ctx.lib.msx_diag_read_med_stamps
+    fm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    fm.restype = C.c_int
+    assert fm(eng.ctx.h, n, med.ctypes.data) == 0
+    dm = np.diff(med[:, :5].astype(np.int64), axis=1)
+    for i, nm in enumerate(['hist fill+barrier', 'bin scan (2 barriers)', 'gather+barrier', 'all-pairs rank+barrier']):
+        print('    median/{:24s} median {:8d} cycles'.format(nm, int(np.median(dm[:, i]))))
+    print('    median/candidates: median {} max {}'.format(int(np.median(med[:, 6])), int(med[:, 6].max())))
     span = int(out[:, 7].max() - out[:, 0].min())
     print('  first start -> last end: {} cycles'.format(span))
 
