@@ -61,7 +61,7 @@ struct DevProblem {
     // pixel tables (A8)
     const double2 *pairs;  // [nt*ng][npix] {flux[lo], flux[lo+1]}
     const double2 *pix_k;  // [npix] {k[lo], k[lo+1]}
-    const double *pix_t, *pix_u, *pix_flux, *pix_err;
+    const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
     int64_t npix;
     double median_flux;
     double minv[9];
@@ -70,6 +70,7 @@ struct DevProblem {
     const double *band_tab;  // [nt*ng][nc+np]
     double cmag[MSX_MAX_BANDS], cerr[MSX_MAX_BANDS];
     double pmag[MSX_MAX_BANDS], perr[MSX_MAX_BANDS], pzero[MSX_MAX_BANDS], pk[MSX_MAX_BANDS];
+    double civar[MSX_MAX_BANDS], pivar[MSX_MAX_BANDS];  // 1/cerr^2, 1/perr^2
     int64_t win_j0, win_n;
     // isochrone (A1)
     int32_t niso;
@@ -787,13 +788,13 @@ __device__ void recipe_band_terms(const DevProblem &P, int mode, const double *_
         if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
         const double con = readlane_f64(val, f * NS + sec) - readlane_f64(val, f * NS);  // mft6.py:741
         const double z = con - P.cmag[f];
-        chi += (z * z) / (P.cerr[f] * P.cerr[f]);  // mft6.py:120,1182
+        chi += (z * z) * P.civar[f];  // mft6.py:120,1182
     }
     for (int f = 0; f < P.np; ++f) {
         const double mag = readlane_f64(val, P.nc * NS + f);
         const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
         const double z = mred - P.pmag[f];
-        chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
+        chi += (z * z) * P.pivar[f];  // mft6.py:1188
     }
     if (lane == 0) D.chi_extra = chi;
 }
@@ -1110,8 +1111,11 @@ __device__ double block_median(const double *model, int npix, unsigned long long
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 
-template <int NS, int U>
-__global__ void __launch_bounds__(1024)
+// MAXT = largest workgroup the variant is launched with.  The 512-thread variants may use up to 256
+// VGPRs (the two-pixels-per-trip body wants ~146: no spills, 3 waves per SIMD); the 1024-thread variants
+// are capped at 128 VGPRs by the hardware and use one pixel per trip.
+template <int NS, int U, int MAXT>
+__global__ void __launch_bounds__(MAXT, 1)
 logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
     __shared__ WalkerDesc D;
@@ -1207,8 +1211,15 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
                 yhi = fma(w[c], v[u][c].y, yhi);
             }
             if (redden) {
-                ylo *= exp2(redc * kk[u].x);  // 10^(-0.4 A_V k)                mft6.py:62-63
-                yhi *= exp2(redc * kk[u].y);
+                const double elo = exp2(redc * kk[u].x);  // 10^(-0.4 A_V k)     mft6.py:62-63
+                // neighbouring grid samples: y = ln2 * c * (k_hi - k_lo) is tiny, so e^y from four series
+                // terms is exact to < 1e-17 for |y| < 1e-3; anything larger takes the full exp2
+                const double y = 0.6931471805599453 * (redc * (kk[u].y - kk[u].x));
+                const double ehi = (fabs(y) < 1e-3)
+                                       ? elo * fma(y, fma(y, fma(y, fma(y, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0)
+                                       : exp2(redc * kk[u].y);
+                ylo *= elo;
+                yhi *= ehi;
             }
             const double m = fma(yhi - ylo, tt[u], ylo);  // mft6.py:1169-1170
             if (base + u * B + tid < npix) {
@@ -1279,12 +1290,12 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
             if (!on) return;
             double u[4], f[4], e[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { u[k] = P.pix_u[pp[k]]; f[k] = P.pix_flux[pp[k]]; e[k] = P.pix_err[pp[k]]; }
+            for (int k = 0; k < 4; ++k) { u[k] = P.pix_u[pp[k]]; f[k] = P.pix_flux[pp[k]]; e[k] = P.pix_ivar[pp[k]]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double poly = fma(fma(c2, u[k], c1), u[k], c0);
                 const double r = xv[k] - f[k] / poly;  // (model - data/P); mft6.py:196,120 up to scale^2
-                const double t = (r * r) / (e[k] * e[k]);
+                const double t = (r * r) * e[k];
                 acc += ok[k] ? t : 0.0;
             }
         }
@@ -1346,8 +1357,7 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
             dn = dflux[p] / poly;  // mft6.py:196
         }
         const double r = ms - dn;
-        const double e = P.pix_err[p];
-        chi += (r * r) / (e * e);  // mft6.py:120
+        chi += (r * r) * P.pix_ivar[p];  // mft6.py:120
         if (opt_init) {
             P.opt_flux[wk * npix + p] = dn;
             model[p] = dn;  // the model value is dead now; reuse the LDS vector for median(data')
@@ -1703,7 +1713,9 @@ int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
     // several workgroups share a CU (LDS permitting).
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     if (npix >= 8192) return 1024;
-    if (n < 4 * cus) return 512;  // measured: 22.4 us vs 23.6 (1024) / 25.6 (256) at 256 walkers x 4096 px
+    // 512 threads when one workgroup per CU is all there is (22.1 us vs 24.4 at 256 walkers x 4096 px);
+    // beyond that 256-thread workgroups pack 3 per CU (146 VGPRs) and win (32 vs 40 us at 512 walkers)
+    if (n <= cus) return 512;
     return 256;
 }
 
@@ -1935,9 +1947,10 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     P.npix = p->npix; P.median_flux = p->median_flux; P.nspec = p->nspec;
     memcpy(P.minv, p->fit_minv, sizeof(P.minv));
     P.nc = p->n_contrast; P.np = p->n_phot;
-    for (int i = 0; i < P.nc; ++i) { P.cmag[i] = p->cmag[i]; P.cerr[i] = p->cerr[i]; }
+    for (int i = 0; i < P.nc; ++i) { P.cmag[i] = p->cmag[i]; P.cerr[i] = p->cerr[i]; P.civar[i] = 1.0 / (p->cerr[i] * p->cerr[i]); }
     for (int i = 0; i < P.np; ++i) {
         P.pmag[i] = p->pmag[i]; P.perr[i] = p->perr[i]; P.pzero[i] = p->phot_zero[i]; P.pk[i] = p->phot_k[i];
+        P.pivar[i] = 1.0 / (p->perr[i] * p->perr[i]);
     }
     P.win_j0 = p->win_j0; P.win_n = p->win_n;
     P.niso = p->niso; P.nav = p->nav; P.tmin = p->tmin; P.tmax = p->tmax;
@@ -1949,7 +1962,12 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     if ((rc = dev_alloc_copy(c, &tr, p->pix_t, p->npix, &d))) return rc; P.pix_t = d;
     if ((rc = dev_alloc_copy(c, &tr, p->pix_u, p->npix, &d))) return rc; P.pix_u = d;
     if ((rc = dev_alloc_copy(c, &tr, p->pix_flux, p->npix, &d))) return rc; P.pix_flux = d;
-    if ((rc = dev_alloc_copy(c, &tr, p->pix_err, p->npix, &d))) return rc; P.pix_err = d;
+    {
+        std::vector<double> ivar(p->npix);
+        for (int64_t i = 0; i < p->npix; ++i) ivar[i] = 1.0 / (p->pix_err[i] * p->pix_err[i]);
+        if ((rc = dev_alloc_copy(c, &tr, ivar.data(), p->npix, &d))) return rc;
+        P.pix_ivar = d;
+    }
     if ((rc = dev_alloc_copy(c, &tr, p->iso_teff, (int64_t)p->niso, &d))) return rc; P.iso_t = d;
     if ((rc = dev_alloc_copy(c, &tr, p->iso_logg, (int64_t)p->niso, &d))) return rc; P.iso_g = d;
     if ((rc = dev_alloc_copy(c, &tr, p->iso_lum, (int64_t)p->niso, &d))) return rc; P.iso_l = d;
@@ -1992,19 +2010,11 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     // the hot kernel may need more than the default 64 KiB of dynamic LDS
     c->max_dyn_lds = (int)need_lds;
     if (need_lds > 48 * 1024) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)need_lds));
-        HIP_TRY(c, hipFuncSetAttribute((const void *)logprob_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)need_lds));
+        const void *variants[] = {(const void *)logprob_kernel<2, 2, 512>, (const void *)logprob_kernel<2, 1, 1024>,
+                                  (const void *)logprob_kernel<3, 1, 512>, (const void *)logprob_kernel<3, 1, 1024>};
+        for (const void *k : variants)
+            HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_lds));
     }
-#ifdef MSX_STAMPS
-    {
-        unsigned long long *st = nullptr;
-        HIP_TRY(c, hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * 65536)); tr.push_back(st);
-        HIP_TRY(c, hipMemset(st, 0, sizeof(unsigned long long) * 16 * 65536));
-        P.stamps = st;
-    }
-#endif
     c->problem_staged = true;
     return MSX_OK;
 }
@@ -2041,10 +2051,14 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (B != 256 && B != 512 && B != 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be 256, 512 or 1024");
     hipStream_t s = (hipStream_t)hip_stream;
     const size_t lds = sizeof(double) * (size_t)c->P.npix;
-    if (c->P.nspec == 2)
-        hipLaunchKernelGGL((logprob_kernel<2, 2>), dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
-    else
-        hipLaunchKernelGGL((logprob_kernel<3, 1>), dim3((unsigned)n), dim3(B), lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+    const dim3 g((unsigned)n), b((unsigned)B);
+    if (c->P.nspec == 2) {
+        if (B <= 512) hipLaunchKernelGGL((logprob_kernel<2, 2, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        else hipLaunchKernelGGL((logprob_kernel<2, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+    } else {
+        if (B <= 512) hipLaunchKernelGGL((logprob_kernel<3, 1, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        else hipLaunchKernelGGL((logprob_kernel<3, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+    }
     HIP_TRY(c, hipGetLastError());
     return MSX_OK;
 }
