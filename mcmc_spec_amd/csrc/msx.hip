@@ -126,26 +126,80 @@ __device__ __forceinline__ bool redden_rule(int mode, int use_av, double a_v) {
     return use_av && a_v > 0.0;
 }
 
+// ---- cross-lane reductions on the DPP path (VALU speed) instead of ds_bpermute shuffles (an LDS round
+// trip, ~50-100 cycles each, per 32-bit half, per step).  Four DPP steps leave every lane of a 16-lane
+// row with its row's result; the four rows are then combined through v_readlane in a fixed order, so
+// every lane returns the same, run-to-run reproducible value.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const unsigned int lo = (unsigned int)dpp_i32<CTRL>((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)dpp_i32<CTRL>((int)(unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+constexpr int kDppQuadSwap1 = 0xB1;  // quad_perm:[1,0,3,2]
+constexpr int kDppQuadSwap2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int kDppRowRor4 = 0x124;   // row_ror:4
+constexpr int kDppRowRor8 = 0x128;   // row_ror:8
+
+__device__ __forceinline__ double lane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int l) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
-    return v;
+    v += dpp_f64<kDppQuadSwap1>(v);
+    v += dpp_f64<kDppQuadSwap2>(v);
+    v += dpp_f64<kDppRowRor4>(v);
+    v += dpp_f64<kDppRowRor8>(v);
+    return ((lane_f64(v, 0) + lane_f64(v, 16)) + lane_f64(v, 32)) + lane_f64(v, 48);
 }
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_down(v, o, kWave);
-        v = t < v ? t : v;
-    }
-    return v;
+    unsigned long long t;
+    t = dpp_u64<kDppQuadSwap1>(v); v = t < v ? t : v;
+    t = dpp_u64<kDppQuadSwap2>(v); v = t < v ? t : v;
+    t = dpp_u64<kDppRowRor4>(v); v = t < v ? t : v;
+    t = dpp_u64<kDppRowRor8>(v); v = t < v ? t : v;
+    const unsigned long long a = lane_u64(v, 0), b = lane_u64(v, 16), c = lane_u64(v, 32), d = lane_u64(v, 48);
+    const unsigned long long ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
 }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_down(v, o, kWave);
-        v = t > v ? t : v;
-    }
-    return v;
+    unsigned long long t;
+    t = dpp_u64<kDppQuadSwap1>(v); v = t > v ? t : v;
+    t = dpp_u64<kDppQuadSwap2>(v); v = t > v ? t : v;
+    t = dpp_u64<kDppRowRor4>(v); v = t > v ? t : v;
+    t = dpp_u64<kDppRowRor8>(v); v = t > v ? t : v;
+    const unsigned long long a = lane_u64(v, 0), b = lane_u64(v, 16), c = lane_u64(v, 32), d = lane_u64(v, 48);
+    const unsigned long long ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// inclusive prefix sum over the 64 lanes: DPP row_shr steps inside each row of 16, then the three row
+// carries through readlane
+__device__ __forceinline__ unsigned int wave_scan_u32(unsigned int v) {
+    const int lane = threadIdx.x & 63;
+    unsigned int x = v;
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)x, 15);
+    const unsigned int r1 = (unsigned int)__builtin_amdgcn_readlane((int)x, 31);
+    const unsigned int r2 = (unsigned int)__builtin_amdgcn_readlane((int)x, 47);
+    const int row = lane >> 4;
+    return x + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
 }
 
 // order-preserving map double -> uint64 (NaN with sign bit clear sorts above +inf, like np.sort)
@@ -844,12 +898,7 @@ __device__ unsigned long long radix_select(const double *model, int npix, unsign
             const unsigned int c0 = S.hist[4 * lane], c1 = S.hist[4 * lane + 1], c2 = S.hist[4 * lane + 2],
                                c3 = S.hist[4 * lane + 3];
             const unsigned int tot = c0 + c1 + c2 + c3;
-            unsigned int inc = tot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned int t = __shfl_up(inc, o, kWave);
-                if (lane >= o) inc += t;
-            }
+            const unsigned int inc = wave_scan_u32(tot);
             const unsigned long long ball = __ballot(inc > k);
             const int L = __ffsll((long long)ball) - 1;
             if (lane == L) {
@@ -984,12 +1033,7 @@ __device__ double block_median(const double *model, int npix, unsigned long long
                     const uint4 h = h4[i];
                     own += h.x + h.y + h.z + h.w;
                 }
-                unsigned int inc = own;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned int t = __shfl_up(inc, o, kWave);
-                    if (lane >= o) inc += t;
-                }
+                const unsigned int inc = wave_scan_u32(own);
                 const unsigned int excl = inc - own;
                 if (own > 0 && excl <= k1 && k1 < excl + own) {  // exactly one lane
                     unsigned int kk = k1 - excl;
@@ -1084,9 +1128,8 @@ __device__ double block_median(const double *model, int npix, unsigned long long
                 }
                 if (tid == 0) S.cnt_le = 0;
                 __syncthreads();
-                unsigned int wc = cle;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) wc += __shfl_down(wc, o, kWave);
+                const unsigned int wc0 = wave_scan_u32(cle);
+                const unsigned int wc = (unsigned int)__builtin_amdgcn_readlane((int)wc0, 63);
                 nxt = wave_min_u64(nxt);
                 if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.above[wave] = nxt; }
                 __syncthreads();
@@ -2015,6 +2058,14 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         for (const void *k : variants)
             HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_lds));
     }
+#ifdef MSX_STAMPS
+    {   // diagnostic build only: per-walker shader-clock stamps
+        unsigned long long *st = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * 65536)); tr.push_back(st);
+        HIP_TRY(c, hipMemset(st, 0, sizeof(unsigned long long) * 16 * 65536));
+        P.stamps = st;
+    }
+#endif
     c->problem_staged = true;
     return MSX_OK;
 }
