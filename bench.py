@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--phot', action='store_true', help='add the 6-band photometry term (config 4)')
     ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='N > 1: wait for each all-gather before the next launch (a single dependent chain)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--cpu-procs', type=int, default=0, help='CPU baseline pool width (0 = min(affinity, 16))')
     ap.add_argument('--copy-gib', type=float, default=1.0)
@@ -173,9 +175,12 @@ def main():
     nbatch = 4
     thetas = [torch.from_numpy(synth.draw_walkers(n, seed=3 + 1000 * rank + b, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
               for b in range(nbatch)]
-    logp = torch.empty(n, dtype=torch.float64, device=dev)
-    status = torch.empty(n, dtype=torch.int32, device=dev)
-    gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
+    # two output buffers: with N > 1 the all-gather of step i overlaps the kernel of step i+1 (the
+    # collective runs on RCCL's stream; a buffer is only reused after its all-gather has completed)
+    logp = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+    status = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [torch.empty(n * world, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    works = [None, None]
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
@@ -183,20 +188,38 @@ def main():
     import ctypes as C
     fn = eng.ctx.lib.msx_logprob_batch_dev
     h = eng.ctx.h
-    calls = [(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp.data_ptr()),
-              C.c_void_p(status.data_ptr()), C.c_void_p(sptr), args.block) for t in thetas]
+    calls = [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
+               C.c_void_p(status[b].data_ptr()), C.c_void_p(sptr), args.block) for b in range(2)] for t in thetas]
 
     def launch(i):
-        if fn(*calls[i % nbatch]) != 0:
+        if fn(*calls[i % nbatch][i & 1]) != 0:
             raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
 
-    def step(i):
-        launch(i)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, logp)
+    def gather(i):
+        b = i & 1
+        if args.no_overlap:
+            dist.all_gather_into_tensor(gathered[b], logp[b])
+        else:
+            works[b] = dist.all_gather_into_tensor(gathered[b], logp[b], async_op=True)
+
+    def reuse_guard(i):
+        b = i & 1
+        if works[b] is not None:  # stream-level wait (no host block): step i-2's all-gather read logp[b]
+            works[b].wait()
+            works[b] = None
+
+    def drain():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
 
     for i in range(args.warmup):
-        step(i)
+        reuse_guard(i)
+        launch(i)
+        if world > 1:
+            gather(i)
+    drain()
     # HIP events on the launch stream bracket every `ev_stride`-th launch inside the timed region: enough
     # samples for the kernel's average duration without serialising every launch behind two event packets
     ev_stride = 8
@@ -208,6 +231,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        reuse_guard(i)
         if i % ev_stride == 0:
             ev[i // ev_stride][0].record(stream)
             launch(i)
@@ -215,7 +239,8 @@ def main():
         else:
             launch(i)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, logp)
+            gather(i)
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -226,7 +251,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    bad = int((status > _lib.W_REJECT).sum().item())
+    bad = int((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item())
 
     if rank == 0:
         nwin = W['nwin']
@@ -249,7 +274,9 @@ def main():
             'config': {'workload': 'binary (T1=3850/T2=3025) {}-pixel spectrum{}, {} walkers per GPU per launch, '
                                    'logposterior (prior gate + likelihood){}'.format(
                                        args.npix, ' + 6-band photometry' if args.phot else ' + 2 contrast terms', n,
-                                       ', RCCL all-gather of log-probs' if world > 1 else ''),
+                                       (', RCCL all-gather of log-probs' + ('' if args.no_overlap else
+                                                                          ' overlapped with the next launch'))
+                                       if world > 1 else ''),
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': nwin, 'grid': '26x4x135000 f64 synthetic',
                        'block_threads': args.block or 'auto'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
