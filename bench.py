@@ -220,11 +220,12 @@ def main():
         if world > 1:
             gather(i)
     drain()
-    # HIP events on the launch stream bracket every `ev_stride`-th launch inside the timed region: enough
-    # samples for the kernel's average duration without serialising every launch behind two event packets
-    ev_stride = 8
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range((args.steps + ev_stride - 1) // ev_stride)]
+    # HIP events on the launch stream bracket runs of `ev_run` consecutive launches inside the timed region
+    # (an event pair around every single launch would put two extra packets between back-to-back kernels
+    # and inflate what it measures); kernel_ms = elapsed / ev_run, i.e. duration + the stream's launch gap
+    ev_run = 8
+    nev = args.steps // ev_run
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(nev, 1))]
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -232,14 +233,14 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         reuse_guard(i)
-        if i % ev_stride == 0:
-            ev[i // ev_stride][0].record(stream)
-            launch(i)
-            ev[i // ev_stride][1].record(stream)
-        else:
-            launch(i)
+        g, k = divmod(i, ev_run)
+        if k == 0 and g < nev:
+            ev[g][0].record(stream)
+        launch(i)
         if world > 1:
             gather(i)
+        if k == ev_run - 1 and g < nev:
+            ev[g][1].record(stream)
     drain()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -250,7 +251,16 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if nev > 0 and world == 1:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:nev]])) / ev_run
+    else:  # N > 1: collectives share the stream timeline; time the kernel alone after the timed region
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(ev_run):
+            launch(i)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        kern_ms = e0.elapsed_time(e1) / ev_run
     bad = int((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item())
 
     if rank == 0:
@@ -281,7 +291,7 @@ def main():
                        'block_threads': args.block or 'auto'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'logprob_kernel<2,2>',
-                         'kernel_ms': kern_ms, 'kernel_ms_samples': len(ev), 'algorithmic_bytes_per_launch': n * b_alg,
+                         'kernel_ms': kern_ms, 'kernel_ms_samples': nev * ev_run, 'algorithmic_bytes_per_launch': n * b_alg,
                          'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
                          'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
                          'note': NWIN_DOC},
