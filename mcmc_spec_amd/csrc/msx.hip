@@ -86,6 +86,7 @@ struct DevProblem {
     double *opt_flux;          // [nchains][npix]
     double *opt_med;           // [nchains]
     const int32_t *opt_chain;  // [n] (OPT_STEP launches)
+    double *model_scratch;     // [n][npix] only when the model vector does not fit LDS (GM kernel variants)
 #ifdef MSX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
 #endif
@@ -1157,16 +1158,16 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // MAXT = largest workgroup the variant is launched with.  The 512-thread variants may use up to 256
 // VGPRs (the two-pixels-per-trip body wants ~146: no spills, 3 waves per SIMD); the 1024-thread variants
 // are capped at 128 VGPRs by the hardware and use one pixel per trip.
-template <int NS, int U, int MAXT>
+// GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
+template <int NS, int U, int MAXT, bool GM = false>
 __global__ void __launch_bounds__(MAXT, 1)
 logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
-    double *model = reinterpret_cast<double *>(dyn_lds);  // [npix]
-
     const int64_t wk = blockIdx.x;
     if (wk >= n) return;
+    double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
     const int tid = threadIdx.x, B = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = B >> 6;
     const int npix = (int)P.npix;
@@ -1663,6 +1664,9 @@ struct msx_ctx {
     int32_t *d_opt_chain = nullptr;
     int64_t opt_chains = 0, cap_chain = 0;
     int max_dyn_lds = 0;
+    bool model_in_global = false;
+    double *d_model_scratch = nullptr;
+    int64_t cap_model_scratch = 0;  // doubles
 };
 
 namespace {
@@ -1785,7 +1789,8 @@ void msx_destroy(msx_ctx *c) {
     (void)hipSetDevice(c->device);
     free_problem(c);
     free_grid(c);
-    void *ptrs[] = {c->d_theta, c->d_logp, c->d_status, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain};
+    void *ptrs[] = {c->d_theta, c->d_logp, c->d_status, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain,
+                    c->d_model_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1971,8 +1976,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     if (p->win_j0 < 0 || p->win_n < 1 || p->win_j0 + p->win_n > c->nwl)
         return fail(c, MSX_ERR_RANGE, "composite window is outside the staged grid");
     const int64_t need_lds = (int64_t)sizeof(double) * p->npix;
-    if (need_lds > 150 * 1024)
-        return fail(c, MSX_ERR_RANGE, "npix too large for the LDS-resident model vector (max 19200 pixels)");
+    const bool model_in_global = need_lds > 150 * 1024;  // > 19,200 pixels: the GM kernel variants
     for (int64_t i = 0; i < p->npix; ++i)
         if (p->pix_lo[i] < 0 || p->pix_lo[i] + 1 >= c->nwl)
             return fail(c, MSX_ERR_RANGE, "A value in x_new is outside the interpolation range (data pixel vs model grid)");
@@ -2052,7 +2056,8 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // the hot kernel may need more than the default 64 KiB of dynamic LDS
     c->max_dyn_lds = (int)need_lds;
-    if (need_lds > 48 * 1024) {
+    c->model_in_global = model_in_global;
+    if (need_lds > 48 * 1024 && !model_in_global) {
         const void *variants[] = {(const void *)logprob_kernel<2, 2, 512>, (const void *)logprob_kernel<2, 1, 1024>,
                                   (const void *)logprob_kernel<3, 1, 512>, (const void *)logprob_kernel<3, 1, 1024>};
         for (const void *k : variants)
@@ -2102,6 +2107,27 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (B != 256 && B != 512 && B != 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be 256, 512 or 1024");
     hipStream_t s = (hipStream_t)hip_stream;
     const size_t lds = sizeof(double) * (size_t)c->P.npix;
+    if (c->model_in_global) {
+        // long spectra: model vector in global memory, no dynamic LDS, 1024 threads.  The scratch grows on
+        // demand (a synchronous hipMalloc: not capturable into a graph the first time a size is seen)
+        const int64_t need = n * c->P.npix;
+        if (need > c->cap_model_scratch) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            if (c->d_model_scratch) (void)hipFree(c->d_model_scratch);
+            c->d_model_scratch = nullptr; c->cap_model_scratch = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * need));
+            c->cap_model_scratch = need;
+        }
+        c->P.model_scratch = c->d_model_scratch;
+        const dim3 gg((unsigned)n), bb(1024);
+        if (c->P.nspec == 2)
+            hipLaunchKernelGGL((logprob_kernel<2, 1, 1024, true>), gg, bb, 0, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        else
+            hipLaunchKernelGGL((logprob_kernel<3, 1, 1024, true>), gg, bb, 0, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        HIP_TRY(c, hipGetLastError());
+        return MSX_OK;
+    }
     const dim3 g((unsigned)n), b((unsigned)B);
     if (c->P.nspec == 2) {
         if (B <= 512) hipLaunchKernelGGL((logprob_kernel<2, 2, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);

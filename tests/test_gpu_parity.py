@@ -426,3 +426,28 @@ def test_optimize_fit_batched_descends_and_writes_reference_files(tmp_path):
     for line, best, ch in out:
         assert best <= ch.savechi[0] and np.all(np.diff(ch.savechi) <= 0)   # running best never increases
     assert (tmp_path / 'params0.txt').exists() and (tmp_path / 'chisq23.txt').exists()
+
+
+def test_spectra_longer_than_lds_use_the_global_model_vector():
+    """21,951 pixels (the size of the reference's Data/synth_spec_3850_3600.txt) do not fit the 160 KiB LDS:
+    the kernel variant that keeps the model vector in global memory must give the same numbers."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    from oracle import mft6_oracle as orc
+    c = golden_case('B')
+    npix = 21951
+    rng = np.random.default_rng(8)
+    wl_um = np.sort(rng.uniform(0.5499, 2.3991, npix))
+    data = [wl_um, 1.0 + 0.1 * rng.normal(size=npix)]
+    err = np.full(npix, 0.1)
+    r = [wl_um.min(), wl_um.max()]
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    th = c.theta[:5]
+    got = eng.loglikelihood(th)
+    want = np.array([orc.loglikelihood(list(t), c.fr, 2, data, err, r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, c.matrix,
+                                       bandlib=c.bandlib) for t in th])
+    assert rel_err(got, want).max() < TIGHT
+    assert np.array_equal(eng.loglikelihood(th[::-1]), got[::-1])
