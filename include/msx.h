@@ -144,6 +144,19 @@ int msx_opt_init(msx_ctx *ctx, const double *theta0, int64_t nchains, int32_t nd
 int msx_opt_step(msx_ctx *ctx, const double *theta, const int32_t *chain, int64_t n, int32_t ndim,
                  double *chi2_out, int32_t *status_out);
 
+/* ---- f2 on the device: nsteps iterations of the affine-invariant stretch move (Goodman & Weare 2010, the
+ * default move of emcee 3; the loop the reference drives at mft6.py:1494-1524) with the walker state resident in
+ * HBM: per half-step a proposal kernel, the fused log-probability launch and an accept kernel, queued back to
+ * back with no host round trip.  The host supplies the randomness of every half-step h = 2*step + half, each an
+ * array of nw/2 entries: the active walkers sidx, the complementary half cidx, partner (index into cidx),
+ * z = ((a-1)u+1)^2/a, zfac = (ndim-1) ln z and logu = ln(u') for the accept test logu < zfac + lp(q) - lp(s).
+ * coords/logp are updated in place; chain_out [nsteps][nw][ndim] and logp_out [nsteps][nw] hold the state after
+ * every step; naccept[nw] accumulates; worst_status returns the largest MSX_W_* error seen (0 = none).        */
+int msx_sampler_run(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int64_t nsteps, double *coords, double *logp,
+                    const int32_t *sidx, const int32_t *cidx, const int32_t *partner, const double *zz,
+                    const double *zfac, const double *logu, double *chain_out, double *logp_out, int64_t *naccept,
+                    int32_t *worst_status);
+
 /* ---- A4-A6: make_composite (mft6.py:651-831, plot=False) -------------------------------------- */
 /* teff/logg/rad are [nspec]; use_distance = 0 mirrors `distance=False` (mft6.py:701-703).         */
 /* spec_out [win_n], contrast_out [n_contrast], phot_out [n_phot] (unreddened magnitudes).         */

@@ -90,6 +90,9 @@ def load():
         'msx_logprob_batch_dev': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32]),
         'msx_opt_init': (C.c_int, [vp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_opt_step': (C.c_int, [vp, _dp, C.POINTER(C.c_int32), C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
+        'msx_sampler_run': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp, _ip,
+                                      C.POINTER(C.c_int32)]),
         'msx_make_composite': (C.c_int, [vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp,
                                          C.POINTER(C.c_int32)]),
         'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
@@ -106,7 +109,7 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
+            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
 
 def as_f64(a):
@@ -244,6 +247,24 @@ class Context:
         self.check(self.lib.msx_opt_step(self.h, dptr(theta), chain.ctypes.data_as(C.POINTER(C.c_int32)), n, ndim,
                                          dptr(chi), status.ctypes.data_as(C.POINTER(C.c_int32))))
         return chi, status
+
+    def sampler_run(self, mode, coords, logp, sidx, cidx, partner, zz, zfac, logu):
+        """Run len(zz) stretch-move steps on the device.  coords [nw][ndim] and logp [nw] are updated in place;
+        returns (chain [nsteps][nw][ndim], logp_chain [nsteps][nw], naccept [nw], worst_status)."""
+        i32p = C.POINTER(C.c_int32)
+        nsteps = zz.shape[0]
+        nw, ndim = coords.shape
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (sidx, cidx, partner)]
+        dbl = [as_f64(a) for a in (zz, zfac, logu)]
+        chain = np.empty((nsteps, nw, ndim))
+        lpc = np.empty((nsteps, nw))
+        nacc = np.zeros(nw, dtype=np.int64)
+        worst = C.c_int32()
+        self.check(self.lib.msx_sampler_run(self.h, int(mode), nw, ndim, nsteps, dptr(coords), dptr(logp),
+                                            arrs[0].ctypes.data_as(i32p), arrs[1].ctypes.data_as(i32p),
+                                            arrs[2].ctypes.data_as(i32p), dptr(dbl[0]), dptr(dbl[1]), dptr(dbl[2]),
+                                            dptr(chain), dptr(lpc), iptr(nacc), C.byref(worst)))
+        return chain, lpc, nacc, worst.value
 
     def make_composite(self, teff, logg, rad, use_distance, plx, win_n, nc, nph):
         teff, logg, rad = as_f64(teff), as_f64(logg), as_f64(rad)

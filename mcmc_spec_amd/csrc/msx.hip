@@ -1618,6 +1618,47 @@ __global__ void composite_kernel(DevProblem P, const WalkerDesc *__restrict__ Dp
     spec[i] = total;
 }
 
+// ---- f2 on the device: the stretch move around the fused log-posterior (Goodman & Weare 2010 as emcee 3
+// applies it).  Randomness is drawn on the host (same Generator calls as the host-loop sampler) and shipped
+// per chunk of steps, so the device-resident chain is bit-identical to the host-driven one.
+// q = c - (c - s) * z  for the ns walkers of the active half (c = a walker of the complementary half)
+__global__ void stretch_propose_kernel(const double *__restrict__ coords, int ndim, const int32_t *__restrict__ sidx,
+                                       const int32_t *__restrict__ cidx, const int32_t *__restrict__ partner,
+                                       const double *__restrict__ zz, int ns, double *__restrict__ q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns * ndim) return;
+    const int w = i / ndim, d = i - w * ndim;
+    const double sv = coords[(int64_t)sidx[w] * ndim + d];
+    const double cv = coords[(int64_t)cidx[partner[w]] * ndim + d];
+    // no FMA contraction here: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that the
+    // device-resident and the host-driven sampler stay in lock-step
+    {
+#pragma clang fp contract(off)
+        const double diff = cv - sv;
+        const double prod = diff * zz[w];
+        q[i] = cv - prod;
+    }
+}
+
+// accept when log(u) < (ndim-1) ln z + ln p(q) - ln p(s); NaN differences compare false (-inf - -inf)
+__global__ void stretch_accept_kernel(double *__restrict__ coords, double *__restrict__ logp, const double *__restrict__ q,
+                                      const double *__restrict__ new_lp, const int32_t *__restrict__ wstatus,
+                                      const int32_t *__restrict__ sidx, const double *__restrict__ zfac,
+                                      const double *__restrict__ logu, int ns, int ndim, int64_t *__restrict__ naccept,
+                                      int32_t *__restrict__ worst_status) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ns) return;
+    const int st = wstatus[w];
+    if (st > MSX_W_REJECT) atomicMax(worst_status, st);
+    const int s = sidx[w];
+    const double lnpdiff = (zfac[w] + new_lp[w]) - logp[s];  // additions only: nothing to contract
+    if (logu[w] < lnpdiff) {
+        for (int d = 0; d < ndim; ++d) coords[(int64_t)s * ndim + d] = q[(int64_t)w * ndim + d];
+        logp[s] = new_lp[w];
+        naccept[s] += 1;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
     // 4 independent 16-B loads in flight per lane, then 4 stores; grid-stride over 1024-element tiles
@@ -2201,6 +2242,81 @@ int msx_opt_step(msx_ctx *c, const double *theta, const int32_t *chain, int64_t 
     HIP_TRY(c, hipMemcpyAsync(c->d_opt_chain, chain, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
     c->P.opt_chain = c->d_opt_chain;
     return msx_logprob_batch(c, MSX_MODE_OPT_STEP, theta, n, ndim, chi2_out, status_out);
+}
+
+int msx_sampler_run(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t nsteps, double *coords, double *logp,
+                    const int32_t *sidx, const int32_t *cidx, const int32_t *partner, const double *zz,
+                    const double *zfac, const double *logu, double *chain_out, double *logp_out, int64_t *naccept,
+                    int32_t *worst_status) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_sampler_run: no problem staged");
+    if (!coords || !logp || !sidx || !cidx || !partner || !zz || !zfac || !logu || !chain_out || !logp_out || !naccept ||
+        !worst_status || nw < 2 || (nw & 1) || nsteps < 1)
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_run: bad arguments (need an even number of walkers)");
+    if (ndim != 2 * c->P.nspec + 2) return fail(c, MSX_ERR_INVALID, "P0 doesn't match what I was expecting");
+    if (mode != MSX_MODE_LOGPOST && mode != MSX_MODE_LOGLIKE) return fail(c, MSX_ERR_INVALID, "msx_sampler_run: bad mode");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t ns = nw / 2, nh = nsteps * 2 * ns;
+    // one allocation for the whole chunk: state, per-half randomness, chain
+    const size_t bytes_d = sizeof(double) * (size_t)(nw * ndim + nw + 3 * nh + ns * ndim + ns + nsteps * nw * ndim + nsteps * nw);
+    const size_t bytes_i = sizeof(int32_t) * (size_t)(3 * nh + ns + 1) + sizeof(int64_t) * (size_t)nw;
+    char *base = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&base, bytes_d + bytes_i + 64));
+    double *d_coords = (double *)base, *d_logp = d_coords + nw * ndim, *d_zz = d_logp + nw, *d_zfac = d_zz + nh,
+           *d_logu = d_zfac + nh, *d_q = d_logu + nh, *d_newlp = d_q + ns * ndim, *d_chain = d_newlp + ns,
+           *d_lpchain = d_chain + nsteps * nw * ndim;
+    int64_t *d_nacc = (int64_t *)(d_lpchain + nsteps * nw);
+    int32_t *d_sidx = (int32_t *)(d_nacc + nw), *d_cidx = d_sidx + nh, *d_partner = d_cidx + nh, *d_wst = d_partner + nh,
+            *d_worst = d_wst + ns;
+    int rc = MSX_OK;
+    hipError_t e = hipSuccess;
+    auto up = [&](void *dst, const void *src, size_t n) {
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream);
+    };
+    up(d_coords, coords, sizeof(double) * nw * ndim);
+    up(d_logp, logp, sizeof(double) * nw);
+    up(d_zz, zz, sizeof(double) * nh);
+    up(d_zfac, zfac, sizeof(double) * nh);
+    up(d_logu, logu, sizeof(double) * nh);
+    up(d_sidx, sidx, sizeof(int32_t) * nh);
+    up(d_cidx, cidx, sizeof(int32_t) * nh);
+    up(d_partner, partner, sizeof(int32_t) * nh);
+    up(d_nacc, naccept, sizeof(int64_t) * nw);
+    if (e == hipSuccess) e = hipMemsetAsync(d_worst, 0, sizeof(int32_t), c->stream);
+    for (int64_t st = 0; st < nsteps && e == hipSuccess && rc == MSX_OK; ++st) {
+        for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
+            const int64_t off = (st * 2 + half) * ns;
+            hipLaunchKernelGGL(stretch_propose_kernel, dim3((unsigned)((ns * ndim + 255) / 256)), dim3(256), 0, c->stream,
+                               d_coords, ndim, d_sidx + off, d_cidx + off, d_partner + off, d_zz + off, (int)ns, d_q);
+            rc = msx_logprob_batch_dev(c, mode, d_q, ns, ndim, d_newlp, d_wst, c->stream, 0);
+            if (rc != MSX_OK) break;
+            hipLaunchKernelGGL(stretch_accept_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, d_coords,
+                               d_logp, d_q, d_newlp, d_wst, d_sidx + off, d_zfac + off, d_logu + off, (int)ns, ndim, d_nacc,
+                               d_worst);
+        }
+        if (rc != MSX_OK) break;
+        e = hipMemcpyAsync(d_chain + st * nw * ndim, d_coords, sizeof(double) * nw * ndim, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_lpchain + st * nw, d_logp, sizeof(double) * nw, hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    auto down = [&](void *dst, const void *src, size_t n) {
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream);
+    };
+    if (rc == MSX_OK) {
+        down(coords, d_coords, sizeof(double) * nw * ndim);
+        down(logp, d_logp, sizeof(double) * nw);
+        down(chain_out, d_chain, sizeof(double) * nsteps * nw * ndim);
+        down(logp_out, d_lpchain, sizeof(double) * nsteps * nw);
+        down(naccept, d_nacc, sizeof(int64_t) * nw);
+        down(worst_status, d_worst, sizeof(int32_t));
+    }
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = e2;
+    (void)hipFree(base);
+    if (rc != MSX_OK) return rc;
+    if (e != hipSuccess) return fail(c, MSX_ERR_HIP, std::string("msx_sampler_run: ") + hipGetErrorString(e));
+    return MSX_OK;
 }
 
 int msx_make_composite(msx_ctx *c, const double *teff, const double *logg, const double *rad, int32_t use_distance,
