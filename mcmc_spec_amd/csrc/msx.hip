@@ -87,6 +87,16 @@ struct DevProblem {
     double *opt_med;           // [nchains]
     const int32_t *opt_chain;  // [n] (OPT_STEP launches)
     double *model_scratch;     // [n][npix] only when the model vector does not fit LDS (GM kernel variants)
+    // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
+    // active half; the kernel builds its own proposal and applies the accept rule in its last lines
+    int32_t smp_on;
+    double *smp_coords, *smp_logp;          // [nw][ndim], [nw]   ensemble state (updated in place)
+    double *smp_q;                          // [ns][ndim]         proposals of this half-step
+    const int32_t *smp_sidx, *smp_cidx, *smp_partner;  // [ns]
+    const double *smp_zz, *smp_zfac, *smp_logu;        // [ns]
+    int64_t *smp_naccept;                   // [nw]
+    double *smp_chain_row, *smp_lp_row;     // chain[step] [nw][ndim], logp chain[step] [nw]
+    int32_t *smp_worst;
 #ifdef MSX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
 #endif
@@ -1145,6 +1155,33 @@ __device__ double block_median(const double *model, int npix, unsigned long long
     return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
 }
 
+// Last lines of a walker (one lane): publish the value and, for the device-resident sampler, apply the
+// stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
+// like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
+// own half-step, so its row after the step is written here.
+__device__ void walker_done(const DevProblem &P, int64_t wk, int ndim, double out, int st,
+                            double *__restrict__ logp, int32_t *__restrict__ status) {
+    logp[wk] = out;
+    status[wk] = st;
+    if (!P.smp_on) return;
+    if (st > MSX_W_REJECT) atomicMax(P.smp_worst, st);
+    const int64_t s = P.smp_sidx[wk];
+    const double lnpdiff = (P.smp_zfac[wk] + out) - P.smp_logp[s];
+    const bool acc = P.smp_logu[wk] < lnpdiff;
+    double lp_now = P.smp_logp[s];
+    if (acc) {
+        lp_now = out;
+        P.smp_logp[s] = out;
+        P.smp_naccept[s] += 1;
+    }
+    for (int d = 0; d < ndim; ++d) {
+        const double v = acc ? P.smp_q[wk * ndim + d] : P.smp_coords[s * ndim + d];
+        if (acc) P.smp_coords[s * ndim + d] = v;
+        P.smp_chain_row[s * ndim + d] = v;
+    }
+    P.smp_lp_row[s] = lp_now;
+}
+
 // ------------------------------------------------------------------------------------------------
 // THE HOT KERNEL: one workgroup per walker.
 //   phase 0  wave 0 builds the walker's recipe on 64 lanes (prior gate, A1, A2, A4, A5, A6)
@@ -1161,7 +1198,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
 template <int NS, int U, int MAXT, bool GM = false>
 __global__ void __launch_bounds__(MAXT, 1)
-logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t n, int ndim,
+logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
@@ -1174,6 +1211,20 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
 
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
+    if (P.smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
+        if (tid < ndim) {
+#pragma clang fp contract(off)
+            // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
+            // the device-resident and the host-driven sampler stay in lock-step
+            const double sv = P.smp_coords[(int64_t)P.smp_sidx[wk] * ndim + tid];
+            const double cv = P.smp_coords[(int64_t)P.smp_cidx[P.smp_partner[wk]] * ndim + tid];
+            const double diff = cv - sv;
+            const double prod = diff * P.smp_zz[wk];
+            P.smp_q[wk * ndim + tid] = cv - prod;
+        }
+        __syncthreads();  // same-workgroup global hand-off: stores drained + barrier, then plain loads
+        theta = P.smp_q;
+    }
     for (int i = tid; i < kBins; i += B) S.hist[i] = 0;
     // register-resident tables when they fit one wave (the usual case), else the generic walk
     const bool fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave &&
@@ -1193,8 +1244,7 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
     }
     if (wst != MSX_W_OK) {
         if (tid == 0) {
-            logp[wk] = (wst == MSX_W_REJECT) ? -INFINITY : NAN;
-            status[wk] = wst;
+            walker_done(P, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
         }
         return;
     }
@@ -1304,9 +1354,9 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
     // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
     if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
         if (tid == 0) {
-            logp[wk] = (mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT) ? NAN : -INFINITY;
+            const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
             if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
-            status[wk] = MSX_W_OK;
+            walker_done(P, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
         }
         return;
     }
@@ -1444,8 +1494,7 @@ logprob_kernel(DevProblem P, int mode, const double *__restrict__ theta, int64_t
         double out;
         if (mode == MSX_MODE_CHISQ || opt_step || opt_init) out = total;  // mft6.py:1198-1199
         else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
-        logp[wk] = out;
-        status[wk] = MSX_W_OK;
+        walker_done(P, wk, ndim, out, MSX_W_OK, logp, status);
     }
 }
 
@@ -1616,47 +1665,6 @@ __global__ void composite_kernel(DevProblem P, const WalkerDesc *__restrict__ Dp
         total += acc;
     }
     spec[i] = total;
-}
-
-// ---- f2 on the device: the stretch move around the fused log-posterior (Goodman & Weare 2010 as emcee 3
-// applies it).  Randomness is drawn on the host (same Generator calls as the host-loop sampler) and shipped
-// per chunk of steps, so the device-resident chain is bit-identical to the host-driven one.
-// q = c - (c - s) * z  for the ns walkers of the active half (c = a walker of the complementary half)
-__global__ void stretch_propose_kernel(const double *__restrict__ coords, int ndim, const int32_t *__restrict__ sidx,
-                                       const int32_t *__restrict__ cidx, const int32_t *__restrict__ partner,
-                                       const double *__restrict__ zz, int ns, double *__restrict__ q) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns * ndim) return;
-    const int w = i / ndim, d = i - w * ndim;
-    const double sv = coords[(int64_t)sidx[w] * ndim + d];
-    const double cv = coords[(int64_t)cidx[partner[w]] * ndim + d];
-    // no FMA contraction here: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that the
-    // device-resident and the host-driven sampler stay in lock-step
-    {
-#pragma clang fp contract(off)
-        const double diff = cv - sv;
-        const double prod = diff * zz[w];
-        q[i] = cv - prod;
-    }
-}
-
-// accept when log(u) < (ndim-1) ln z + ln p(q) - ln p(s); NaN differences compare false (-inf - -inf)
-__global__ void stretch_accept_kernel(double *__restrict__ coords, double *__restrict__ logp, const double *__restrict__ q,
-                                      const double *__restrict__ new_lp, const int32_t *__restrict__ wstatus,
-                                      const int32_t *__restrict__ sidx, const double *__restrict__ zfac,
-                                      const double *__restrict__ logu, int ns, int ndim, int64_t *__restrict__ naccept,
-                                      int32_t *__restrict__ worst_status) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= ns) return;
-    const int st = wstatus[w];
-    if (st > MSX_W_REJECT) atomicMax(worst_status, st);
-    const int s = sidx[w];
-    const double lnpdiff = (zfac[w] + new_lp[w]) - logp[s];  // additions only: nothing to contract
-    if (logu[w] < lnpdiff) {
-        for (int d = 0; d < ndim; ++d) coords[(int64_t)s * ndim + d] = q[(int64_t)w * ndim + d];
-        logp[s] = new_lp[w];
-        naccept[s] += 1;
-    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -2283,22 +2291,20 @@ int msx_sampler_run(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t 
     up(d_partner, partner, sizeof(int32_t) * nh);
     up(d_nacc, naccept, sizeof(int64_t) * nw);
     if (e == hipSuccess) e = hipMemsetAsync(d_worst, 0, sizeof(int32_t), c->stream);
+    // one fused launch per half-step: proposal in the kernel's first lines, accept rule + chain row in its last
+    DevProblem &P = c->P;
+    P.smp_on = 1;
+    P.smp_coords = d_coords; P.smp_logp = d_logp; P.smp_q = d_q; P.smp_naccept = d_nacc; P.smp_worst = d_worst;
     for (int64_t st = 0; st < nsteps && e == hipSuccess && rc == MSX_OK; ++st) {
         for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
             const int64_t off = (st * 2 + half) * ns;
-            hipLaunchKernelGGL(stretch_propose_kernel, dim3((unsigned)((ns * ndim + 255) / 256)), dim3(256), 0, c->stream,
-                               d_coords, ndim, d_sidx + off, d_cidx + off, d_partner + off, d_zz + off, (int)ns, d_q);
+            P.smp_sidx = d_sidx + off; P.smp_cidx = d_cidx + off; P.smp_partner = d_partner + off;
+            P.smp_zz = d_zz + off; P.smp_zfac = d_zfac + off; P.smp_logu = d_logu + off;
+            P.smp_chain_row = d_chain + st * nw * ndim; P.smp_lp_row = d_lpchain + st * nw;
             rc = msx_logprob_batch_dev(c, mode, d_q, ns, ndim, d_newlp, d_wst, c->stream, 0);
-            if (rc != MSX_OK) break;
-            hipLaunchKernelGGL(stretch_accept_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, d_coords,
-                               d_logp, d_q, d_newlp, d_wst, d_sidx + off, d_zfac + off, d_logu + off, (int)ns, ndim, d_nacc,
-                               d_worst);
         }
-        if (rc != MSX_OK) break;
-        e = hipMemcpyAsync(d_chain + st * nw * ndim, d_coords, sizeof(double) * nw * ndim, hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(d_lpchain + st * nw, d_logp, sizeof(double) * nw, hipMemcpyDeviceToDevice, c->stream);
     }
+    P.smp_on = 0;
     if (e == hipSuccess) e = hipGetLastError();
     auto down = [&](void *dst, const void *src, size_t n) {
         if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream);

@@ -207,9 +207,8 @@ class DeviceEnsembleSampler(EnsembleSampler):
         coords = np.ascontiguousarray(coords)
         logp = np.ascontiguousarray(logp)
         nd, ns = self.ndim, self.nwalkers // 2
-        left = int(iterations)
-        while left > 0:
-            m = min(left, self.chunk)
+
+        def draw_chunk(m):
             sidx = np.empty((m, 2, ns), dtype=np.int32)
             cidx = np.empty((m, 2, ns), dtype=np.int32)
             partner = np.empty((m, 2, ns), dtype=np.int32)
@@ -218,20 +217,34 @@ class DeviceEnsembleSampler(EnsembleSampler):
                 for k, (s_i, c_i, z, p_i, lu) in enumerate(self._draw_step()):
                     sidx[i, k], cidx[i, k], partner[i, k] = s_i, c_i, p_i
                     zz[i, k], zfac[i, k], logu[i, k] = z, (nd - 1.0) * np.log(z), lu
-            before = self._accepted.copy()
-            chain, lpc, nacc, worst = self.engine.ctx.sampler_run(self._mode, coords, logp, sidx, cidx, partner, zz, zfac,
-                                                                  logu)
-            if worst:
-                _raise_for_status(np.array([worst]), coords[:1])
-            self._accepted = before + nacc
-            for i in range(m):
-                self.iteration += 1
-                if store:
-                    self._chain.append(chain[i])
-                    self._logp.append(lpc[i])
-                self._last = State(chain[i], lpc[i])
-                yield self._last
-            left -= m
+            return sidx, cidx, partner, zz, zfac, logu
+
+        # the randomness of chunk i+1 is drawn (in stream order, by one worker thread) while the GPU runs
+        # chunk i: the ctypes call releases the GIL for the whole chunk
+        from concurrent.futures import ThreadPoolExecutor
+        left = int(iterations)
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            m = min(left, self.chunk)
+            fut = pool.submit(draw_chunk, m) if m > 0 else None
+            while left > 0:
+                sidx, cidx, partner, zz, zfac, logu = fut.result()
+                left -= m
+                m_next = min(left, self.chunk)
+                fut = pool.submit(draw_chunk, m_next) if m_next > 0 else None
+                before = self._accepted.copy()
+                chain, lpc, nacc, worst = self.engine.ctx.sampler_run(self._mode, coords, logp, sidx, cidx, partner, zz,
+                                                                      zfac, logu)
+                if worst:
+                    _raise_for_status(np.array([worst]), coords[:1])
+                self._accepted = before + nacc
+                for i in range(m):
+                    self.iteration += 1
+                    if store:
+                        self._chain.append(chain[i])
+                        self._logp.append(lpc[i])
+                    self._last = State(chain[i], lpc[i])
+                    yield self._last
+                m = m_next
 
     @property
     def acceptance_fraction(self):
