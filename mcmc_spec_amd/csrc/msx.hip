@@ -40,7 +40,6 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;            // 1024 threads
 constexpr int kMaxCorners = MSX_MAX_SPEC * 4;
-constexpr int kMaxBandsTotal = 2 * MSX_MAX_BANDS;
 constexpr int kSelectFinish = 256;       // radix select switches to all-pairs ranking at this many candidates
 constexpr double kRsunCm = 6.957e10;     // mft6.py:691
 constexpr double kPcCm = 3.086e18;       // mft6.py:691
@@ -223,23 +222,6 @@ __device__ __forceinline__ double val_of(unsigned long long k) {
     return __longlong_as_double((long long)b);
 }
 
-// np.interp semantics on a table sorted in x (what scipy's interp1d(kind='linear') evaluates for
-// 1-D float64 input); returns false when x is outside [x0, xn-1] (interp1d raises ValueError).
-__device__ bool table_interp(const double *xs, const double *ys, int n, double x, double *out) {
-    if (!(x >= xs[0]) || !(x <= xs[n - 1])) return false;
-    int lo = 0, hi = n;  // upper_bound: first index with xs[i] > x
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (xs[mid] <= x) lo = mid + 1; else hi = mid;
-    }
-    int j = lo - 1;
-    if (j >= n - 1) { *out = ys[n - 1]; return true; }
-    if (xs[j] == x) { *out = ys[j]; return true; }
-    double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
-    *out = slope * (x - xs[j]) + ys[j];
-    return true;
-}
-
 // mft6.py:439-453 / :467-477.  Nearest node first (first index on ties), then its neighbour on the
 // other side; Python index semantics: -1 wraps to the last node, == n is an IndexError.
 __device__ int bracket_nodes(const double *nodes, int n, double v, int *i1, int *i2) {
@@ -327,67 +309,6 @@ __device__ void build_desc(const DevProblem &P, const double *teff, const double
         chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
     }
     D->chi_extra = chi;
-}
-
-// logprior for one walker (mft6.py:1207-1272 ndim 6; :1329-1393 ndim 8).  Returns false -> -inf.
-__device__ bool log_prior(const DevProblem &P, const double *th, int ndim, double *lp_out, int *status) {
-    const int ns = P.nspec;
-    const double *T = th;
-    const double a_v = th[ns];
-    const double *rad = th + ns + 1;
-    const double plx = th[2 * ns + 1];
-    for (int s = 0; s < ns; ++s)
-        if (T[s] > P.tmax || T[s] < P.tmin) return false;
-    for (int s = 0; s < ns; ++s)
-        if (rad[s] < 0.05) return false;
-    if (ns == 2) {
-        if (rad[0] > 1.5 || plx < 1.0 / 3000 || plx > 1.0 / 4) return false;  // mft6.py:1227
-    } else {
-        if (plx < 1.0 / 1000 || plx > 1.0 / 4) return false;  // mft6.py:1347
-    }
-    double lp = 0.0;
-    if (P.use_av) {
-        if (a_v < 0.0) return false;  // mft6.py:1229
-        if (P.nav > 0) {
-            double d = 1.0 / plx;  // pc, mft6.py:1233
-            int lo = 0, hi = P.nav + 1;  // searchsorted(edges, d, 'right') - 1, clipped
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (P.av_edges[mid] <= d) lo = mid + 1; else hi = mid;
-            }
-            int b = lo - 1;
-            b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
-            double sig = P.av_sig[b];
-            if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
-            double z = (a_v - P.av_mu[b]) / sig;
-            lp += -0.5 * (z * z);
-        }
-    }
-    if (P.has_prior) {
-        for (int k = 0; k < ndim; ++k) {
-            if (P.pmean[k] != 0.0) {  // mft6.py:1258
-                double z = (th[k] - P.pmean[k]) / P.psig[k];
-                lp += -0.5 * (z * z);
-            }
-        }
-    }
-    if (P.rad_prior) {  // mft6.py:1262-1269
-        double mr[MSX_MAX_SPEC];
-        for (int s = 0; s < ns; ++s) {
-            double lum;
-            if (!table_interp(P.iso_t, P.iso_l, P.niso, T[s], &lum)) { *status = MSX_W_VALUEERROR; return false; }
-            const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
-            double t2 = T[s] * T[s];
-            mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
-        }
-        for (int s = 0; s < ns; ++s) {
-            double target = (s == 0) ? mr[0] : mr[s] / mr[0];
-            double z = (rad[s] - target) / (0.02 * target);
-            lp += -0.5 * (z * z);
-        }
-    }
-    *lp_out = lp;
-    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
