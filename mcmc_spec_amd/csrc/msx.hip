@@ -311,6 +311,35 @@ __device__ void build_desc(const DevProblem &P, const double *teff, const double
     D->chi_extra = chi;
 }
 
+// The hard gates of logprior (a value of -inf, not an error) for theta = [T.., A_V, R1, ratios.., plx]:
+//   dist_fit, binary   : T box, every radius entry >= 0.05, R1 <= 1.5, 1/3000 <= plx <= 1/4   mft6.py:1227
+//   dist_fit, triple   : T box, every radius entry >= 0.05, 1/1000 <= plx <= 1/4               mft6.py:1347
+//   no dist_fit, binary: T box, both radius entries >= 0.05                                    mft6.py:1286
+//   no dist_fit, triple: T box, the two RATIOS >= 0.05 (R1 is not tested), plx >= 0            mft6.py:1411
+//   and A_V >= 0 whenever extinction is fitted                                                 mft6.py:1229
+template <int NS>
+__device__ __forceinline__ bool prior_gates(const DevProblem &P, const double *t) {
+    const double a_v = t[NS], plx = t[2 * NS + 1];
+    const double *rad = t + NS + 1;
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ok = ok && !(t[s] > P.tmax) && !(t[s] < P.tmin);
+    if (P.dist_fit) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ok = ok && !(rad[s] < 0.05);
+        if (NS == 2) ok = ok && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);
+        else ok = ok && !(plx < 1.0 / 1000) && !(plx > 1.0 / 4);
+    } else if (NS == 2) {
+        ok = ok && !(rad[0] < 0.05) && !(rad[1] < 0.05);
+    } else {
+#pragma unroll
+        for (int s = 1; s < NS; ++s) ok = ok && !(rad[s] < 0.05);
+        ok = ok && !(plx < 0.0);
+    }
+    if (P.use_av) ok = ok && !(a_v < 0.0);
+    return ok;
+}
+
 // ------------------------------------------------------------------------------------------------
 // wave-parallel recipe helpers (phase 0 of the hot kernel runs on wave 0, all 64 lanes)
 // ------------------------------------------------------------------------------------------------
@@ -385,15 +414,9 @@ __device__ void build_recipe_wave(const DevProblem &P, const RecipeTabs &T, int 
     int st = MSX_W_OK;
     double lp = 0.0;
     if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) {
-        // box (mft6.py:1227 binary, :1347 triple)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) alive = alive && !(t[s] > P.tmax) && !(t[s] < P.tmin) && !(rad[s] < 0.05);
-        if (NS == 2) alive = alive && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);
-        else alive = alive && !(plx < 1.0 / 1000) && !(plx > 1.0 / 4);
+        alive = alive && prior_gates<NS>(P, t);
         if (alive && P.use_av) {
-            if (a_v < 0.0) {
-                alive = false;  // mft6.py:1229
-            } else if (P.nav > 0) {
+            if (P.nav > 0) {
                 const double d = 1.0 / plx;  // pc, mft6.py:1233
                 int b = wave_count_le(T.av_edges, P.nav + 1, d, lane) - 1;
                 b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
@@ -610,11 +633,7 @@ __device__ void recipe_part1_regs(const DevProblem &P, int mode, const double *_
     const double plx = t[2 * NS + 1];
     const double *rad = &t[NS + 1];
     if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) alive = alive && !(t[s] > P.tmax) && !(t[s] < P.tmin) && !(rad[s] < 0.05);
-        if (NS == 2) alive = alive && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);
-        else alive = alive && !(plx < 1.0 / 1000) && !(plx > 1.0 / 4);
-        if (P.use_av) alive = alive && !(a_v < 0.0);
+        alive = alive && prior_gates<NS>(P, t);
     }
     if (!alive) {
         if (lane == 0) D.stat[star] = MSX_W_REJECT;
@@ -1942,7 +1961,6 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     if (p->n_contrast < 0 || p->n_contrast > MSX_MAX_BANDS || p->n_phot < 0 || p->n_phot > MSX_MAX_BANDS)
         return fail(c, MSX_ERR_INVALID, "too many bands");
     if (p->niso < 2) return fail(c, MSX_ERR_INVALID, "isochrone table needs >= 2 rows");
-    if (!p->dist_fit) return fail(c, MSX_ERR_INVALID, "dist_fit=False (mft6.py:1275-1327) is not implemented");
     if (p->win_j0 < 0 || p->win_n < 1 || p->win_j0 + p->win_n > c->nwl)
         return fail(c, MSX_ERR_RANGE, "composite window is outside the staged grid");
     const int64_t need_lds = (int64_t)sizeof(double) * p->npix;

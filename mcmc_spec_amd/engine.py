@@ -59,8 +59,6 @@ class Engine:
                       tmin=-np.inf, tmax=np.inf, prior=0, use_av=True, dist_fit=True, rad_prior=False):
         if self.grid is None:
             raise RuntimeError('stage the model grid first')
-        if not dist_fit:
-            raise NotImplementedError('dist_fit=False (mft6.py:1275-1327) is not implemented yet')
         st = staging.build_problem(self.ctx, self.grid['wl'], data, err, fr, r, ctm, ptm, tmi, tma, matrix,
                                    nspec=nspec, bands=bands, av_table=av_table, tmin=tmin, tmax=tmax, prior=prior,
                                    use_av=use_av, dist_fit=dist_fit, rad_prior=rad_prior)

@@ -109,17 +109,24 @@ def sorted_isochrone(matrix):
     return x[order], np.asarray(matrix[sel, 5], dtype=float)[order], np.asarray(matrix[sel, 6], dtype=float)[order]
 
 
-def prior_vectors(prior, nspec):
-    """The reference's ``prior`` list re-ordered to parameter order (mft6.py:1243-1254)."""
+def prior_vectors(prior, nspec, dist_fit=True):
+    """The reference's ``prior`` list re-ordered to parameter order: mft6.py:1243-1254 with ``dist_fit``
+    (Teff.., A_V, radii.., parallax), :1303-1312 without (Teff.., A_V and ``nspec-1`` radius entries only --
+    the slices there are one element shorter and the parallax has no Gaussian term)."""
     ndim = 2 * nspec + 2
     mean, sig = np.zeros(_lib.MAX_DIM), np.ones(_lib.MAX_DIM)
     if isinstance(prior, (int, float)) and prior == 0:
         return mean, sig, 0
     prior = [float(p) for p in prior]
-    ps = prior[:nspec] + [prior[2 * nspec]] + prior[2 * nspec + 2:3 * nspec + 2] + [prior[-2]]
-    ss = prior[nspec:2 * nspec] + [prior[2 * nspec + 1]] + prior[3 * nspec + 2:4 * nspec + 2] + [prior[-1]]
-    mean[:ndim] = ps
-    sig[:ndim] = ss
+    if dist_fit:
+        ps = prior[:nspec] + [prior[2 * nspec]] + prior[2 * nspec + 2:3 * nspec + 2] + [prior[-2]]
+        ss = prior[nspec:2 * nspec] + [prior[2 * nspec + 1]] + prior[3 * nspec + 2:4 * nspec + 2] + [prior[-1]]
+    else:
+        ps = prior[:nspec] + [prior[2 * nspec]] + prior[2 * nspec + 2:3 * nspec + 1]
+        ss = prior[nspec:2 * nspec] + [prior[2 * nspec + 1]] + prior[3 * nspec + 2:4 * nspec + 1]
+    assert len(ps) <= ndim
+    mean[:len(ps)] = ps
+    sig[:len(ss)] = ss
     return mean, sig, 1
 
 
@@ -231,7 +238,7 @@ def build_problem(ctx, grid_wl, data, err, fr, r, ctm, ptm, tmi, tma, matrix, ns
         P.nav = 0
         P.av_edges_pc, P.av_mu, P.av_sig = st.f64([]), st.f64([]), st.f64([])
     P.tmin, P.tmax = float(tmin), float(tmax)
-    mean, sig, has = prior_vectors(prior, nspec)
+    mean, sig, has = prior_vectors(prior, nspec, dist_fit)
     for i in range(_lib.MAX_DIM):
         P.prior_mean[i] = mean[i]
         P.prior_sig[i] = sig[i]

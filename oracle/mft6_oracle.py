@@ -359,7 +359,7 @@ def logprior(p0, nspec, tmin, tmax, matrix, av_prior, prior=0, ext=True, dist_fi
     sigma == 0 is replaced by 0.05 as in the reference.
     """
     if not dist_fit:
-        raise NotImplementedError('dist_fit=False branch (mft6.py:1275-1327) is not restated yet')
+        return _logprior_no_dist(p0, nspec, tmin, tmax, matrix, av_prior, prior, ext, rad_prior)
     temps = p0[:nspec]
     a_v = p0[nspec]
     rad = list(p0[nspec + 1:2 * nspec + 1])
@@ -392,6 +392,46 @@ def logprior(p0, nspec, tmin, tmax, matrix, av_prior, prior=0, ext=True, dist_fi
         targets = [mr[0]] + [m / mr[0] for m in mr[1:]]
         for k, p in enumerate(targets):
             pp.append(-0.5 * ((rad[k] - p) / (0.02 * p)) ** 2)
+    return np.sum(pp)
+
+
+def _logprior_no_dist(p0, nspec, tmin, tmax, matrix, av_prior, prior, ext, rad_prior):
+    """``dist_fit=False``: mft6.py:1275-1327 (len 6) and :1397-1454 (len 8).  No parallax / absolute-radius
+    bounds, a shorter Gaussian-prior list, the A_V prior still evaluated at distance 1/p0[-1]."""
+    temps = p0[:nspec]
+    if len(p0) == 6:
+        rad, rad1 = p0[-2], p0[-3]
+        a_v = p0[-4]
+        if any(t > tmax for t in temps) or any(t < tmin for t in temps) or rad < 0.05 or rad1 < 0.05:  # :1286
+            return -np.inf
+        radii = [rad1, rad]
+    else:
+        rad1, rad2, rad, dist = p0[-3], p0[-2], p0[-4], p0[-1]
+        a_v = p0[-5]
+        if (any(t > tmax for t in temps) or any(t < tmin for t in temps) or rad1 < 0.05 or rad2 < 0.05
+                or dist < 0):  # :1411
+            return -np.inf
+        radii = [rad, rad1, rad2]
+    pp = []
+    if ext:
+        if a_v < 0:
+            return -np.inf
+        mu, sig = av_prior(1.0 / p0[-1])
+        if sig == 0:
+            sig = 0.05
+        pp.append(-0.5 * ((a_v - mu) / sig) ** 2)
+    if not (isinstance(prior, (int, float)) and prior == 0):  # mft6.py:1301-1318 / :1425-1442
+        prior = list(prior)
+        ps = prior[:nspec] + [prior[2 * nspec]] + prior[2 * nspec + 2:3 * nspec + 1]
+        ss = prior[nspec:2 * nspec] + [prior[2 * nspec + 1]] + prior[3 * nspec + 2:4 * nspec + 1]
+        for k, p in enumerate(ps):
+            if p != 0:
+                pp.append(-0.5 * ((p0[k] - p) / ss[k]) ** 2)
+    if rad_prior:
+        mr = [get_radius(t, matrix) for t in temps]
+        targets = [mr[0]] + [m / mr[0] for m in mr[1:]]
+        for k, p in enumerate(targets):
+            pp.append(-0.5 * ((radii[k] - p) / (0.02 * p)) ** 2)
     return np.sum(pp)
 
 

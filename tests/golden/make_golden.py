@@ -325,6 +325,30 @@ def main():
             out['A_logprior_' + tag] = np.array(lp_ref)
             out['A_logpost_' + tag] = np.array(po_ref)
 
+        # ------------------------------------------------------------ dist_fit=False branch (mft6.py:1275-1327)
+        prior_nd = [3800.0, 0.0, 60.0, 1.0, 0.12, 0.03, 0.5, 0.0, 0.05, 1.0, 2.0732e-3, 0.0277e-3]
+        th_nd = np.vstack([theta[:10], [[3850.0, 3025.0, 0.1, 1.7, 0.3, 2e-3], [3850.0, 3025.0, 0.1, 0.5, 0.3, 0.3],
+                                        [3850.0, 3025.0, 0.1, 0.5, 0.049, 2e-3], [3850.0, 3025.0, -0.1, 0.5, 0.3, 2e-3],
+                                        [2999.0, 3025.0, 0.1, 0.5, 0.3, 2e-3]]])
+        out['theta_nodist'] = th_nd
+        for rp in (False, True):
+            lp_ref, po_ref = [], []
+            for pq in th_nd:
+                lp = mft6.logprior(list(pq), 2, 0, 3000.0, 4200.0, matrix, 10.0, 20.0, prior=prior_nd, ext=True,
+                                   dist_fit=False, rad_prior=rp)
+                lo = orc.logprior(list(pq), 2, 3000.0, 4200.0, matrix, av_prior, prior=prior_nd, dist_fit=False,
+                                  rad_prior=rp)
+                assert (lp == lo) or abs(lp - lo) <= 1e-13 * abs(lp), (lp, lo)
+                po = mft6.logposterior(list(pq), frA, 2, 0, [dw, ds], de, 1700, rA, specs, ctm_real, ptm_empty, tmiA, tmaA,
+                                       None, 3000.0, 4200.0, matrix, 10.0, 20.0, prior=prior_nd, dist_fit=False,
+                                       rad_prior=rp)
+                lp_ref.append(lp)
+                po_ref.append(po)
+            tag = 'radprior' if rp else 'noradprior'
+            out['A_nodist_logprior_' + tag] = np.array(lp_ref)
+            out['A_nodist_logpost_' + tag] = np.array(po_ref)
+        out['prior_nodist'] = np.array(prior_nd)
+
         # ------------------------------------------------------------ triple system (ndim 8), dataset B
         # contrast list follows the reference's own triple example ['880','Kp','880','Kp'] (mft6.py:3632):
         # first half of the filters = secondary - primary, second half = tertiary - primary (mft6.py:747-749)

@@ -504,3 +504,25 @@ def test_end_to_end_fit_recovers_the_truth(tmp_path, monkeypatch):
     # radius is degenerate here (median-normalised spectrum, no photometry) and is not checked
     assert abs(med[0] - truth[0]) < 60 and abs(med[1] - truth[1]) < 350
     assert abs(med[5] - truth[5]) < 1e-4
+
+
+@pytest.mark.parametrize('rad_prior', [False, True])
+def test_dist_fit_false_branch_matches_reference_golden(rad_prior):
+    """logprior / logposterior with dist_fit=False (mft6.py:1275-1327): no parallax or R1 <= 1.5 bounds, a
+    shorter Gaussian-prior list (here with Teff_1, A_V and R1 priors switched on)."""
+    c = golden_case('A')
+    g = c.g
+    m = _dropin(c)
+    th = g['theta_nodist']
+    prior = list(g['prior_nodist'])
+    args = [c.fr, 2, 0, c.data, c.err, 1700, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, None, c.tmin, c.tmax, c.matrix, 10.0,
+            20.0]
+    tag = 'radprior' if rad_prior else 'noradprior'
+    got = m.logposterior(th, *args, prior=prior, a=True, dist_fit=False, rad_prior=rad_prior)
+    want = g['A_nodist_logpost_' + tag]
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and rel_err(got, want).max() < TIGHT
+    lp = m.logprior(th, 2, 0, c.tmin, c.tmax, c.matrix, 10.0, 20.0, prior=prior, ext=True, dist_fit=False,
+                    rad_prior=rad_prior)
+    wantp = g['A_nodist_logprior_' + tag]
+    assert np.array_equal(np.isinf(lp), np.isinf(wantp)) and rel_err(lp, wantp).max() < 1e-12
+    assert np.isfinite(want[10]) and np.isfinite(want[11])   # R1 = 1.7 and plx = 0.3 pass without dist_fit

@@ -141,3 +141,14 @@ def test_fit_spec_pieces_against_reference_trajectory():
     total = like + ((row[2] - mu) / sg) ** 2 + ((row[5] - 2.0732e-3) / 0.0277e-3) ** 2 \
         + ((row[3] - mr[0]) / si_rad[0]) ** 2 + ((row[4] - mr[1] / mr[0]) / si_rad[1]) ** 2
     assert abs(total - g['D_chisq'][2, 0]) < 1e-9 * total
+
+
+@pytest.mark.parametrize('rad_prior', [False, True])
+def test_dist_fit_false_prior(rad_prior):
+    c = golden_case('A')
+    g = c.g
+    tag = 'radprior' if rad_prior else 'noradprior'
+    lp = np.array([orc.logprior(list(t), 2, c.tmin, c.tmax, c.matrix, common.av_prior, prior=list(g['prior_nodist']),
+                                dist_fit=False, rad_prior=rad_prior) for t in g['theta_nodist']])
+    want = g['A_nodist_logprior_' + tag]
+    assert np.array_equal(np.isinf(lp), np.isinf(want)) and rel_err(lp, want).max() < 1e-13

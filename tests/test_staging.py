@@ -76,6 +76,8 @@ def test_prior_vectors_and_isochrone_order():
     full = [3850, 3025, 50, 60, 0.1, 0.02, 0.5, 0.3, 0.05, 0.06, 2e-3, 1e-5]
     mean, sig, _ = staging.prior_vectors(full, 2)
     assert list(mean[:6]) == [3850, 3025, 0.1, 0.5, 0.3, 2e-3] and list(sig[:6]) == [50, 60, 0.02, 0.05, 0.06, 1e-5]
+    mean, sig, _ = staging.prior_vectors(full, 2, dist_fit=False)   # mft6.py:1303-1312: one radius entry, no parallax
+    assert list(mean[:6]) == [3850, 3025, 0.1, 0.5, 0, 0] and list(sig[:4]) == [50, 60, 0.02, 0.05]
     m = synth.make_isochrone_matrix()
     x, g, l = staging.sorted_isochrone(m)
     assert len(x) == 220 and np.all(np.diff(x) > 0) and x[0] == 2900.0 and x[-1] == 6500.0
