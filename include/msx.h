@@ -89,6 +89,9 @@ typedef struct msx_problem {
     int32_t dist_fit;       /* only dist_fit = 1 is implemented                     mft6.py:1212    */
     int32_t rad_prior;      /*                                                      mft6.py:1262    */
     int32_t has_prior_list; /* `prior != 0`                                         mft6.py:1241    */
+    int32_t no_spectrum;    /* 1 = the mft6_nospec.py variant: total = contrast + photometry chi^2 only
+                             * (mft6_nospec.py:1163-1196); the spectral phases are skipped            */
+    int32_t reserved_;
 } msx_problem;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

@@ -81,6 +81,7 @@ struct DevProblem {
     double pmean[MSX_MAX_DIM], psig[MSX_MAX_DIM];
     int32_t use_av, dist_fit, rad_prior, has_prior;
     int32_t nspec;
+    int32_t no_spectrum;  // mft6_nospec.py: contrast + photometry chi^2 only
     // pre-optimiser (f4): per-chain normalised data vectors / their medians, walker -> chain map
     double *opt_flux;          // [nchains][npix]
     double *opt_med;           // [nchains]
@@ -1203,6 +1204,22 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         }
         return;
     }
+    if (P.no_spectrum) {
+        // the mft6_nospec.py variant (mft6_nospec.py:1163-1196): the spectrum term is commented out there and
+        // the total is contrast + photometry chi^2 only -- no spectral phases at all
+        if (fast) {
+            if (wave == 1) recipe_prior_terms<NS>(P, mode, theta + wk * ndim, D, lane);
+            else if (wave == 2) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double total = D.chi_extra;
+            const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
+            walker_done(P, wk, ndim, chi_valued ? total : (isnan(total) ? -INFINITY : D.lp + (-0.5 * total)), MSX_W_OK, logp,
+                        status);
+        }
+        return;
+    }
     MSX_STAMP(P, wk, 1);
 
     // ---- phase A ------------------------------------------------------------------------------------
@@ -1992,6 +2009,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     memcpy(P.pmean, p->prior_mean, sizeof(P.pmean));
     memcpy(P.psig, p->prior_sig, sizeof(P.psig));
     P.use_av = p->use_av; P.dist_fit = p->dist_fit; P.rad_prior = p->rad_prior; P.has_prior = p->has_prior_list;
+    P.no_spectrum = p->no_spectrum;
     int rc;
     double *d;
     if ((rc = dev_alloc_copy(c, &tr, p->pix_t, p->npix, &d))) return rc; P.pix_t = d;

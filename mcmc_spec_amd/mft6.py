@@ -26,6 +26,7 @@ from .engine import Engine
 _BANDS = None
 _AV_TABLE = None
 _AV_OPTIONAL = False
+_SPECTRUM = True
 _DEVICE = int(os.environ.get('LOCAL_RANK', '0'))
 _GRIDS = collections.OrderedDict()      # id(specs) -> (specs, Engine)
 _MAX_GRIDS = 2
@@ -64,6 +65,14 @@ def av_table_from_query(query, ra, dec, edges_pc):
         mu.append(np.mean(s))
         sig.append(np.std(s))
     return np.asarray(edges_pc, float), np.array(mu), np.array(sig)
+
+
+def set_spectrum_term(on=True):
+    """``False`` selects the ``mft6_nospec.py`` variant of the likelihood: contrast + photometry chi^2 only
+    (mft6_nospec.py:1163-1196)."""
+    global _SPECTRUM
+    _SPECTRUM = bool(on)
+    _invalidate_problems()
 
 
 def _invalidate_problems():
@@ -107,7 +116,8 @@ def _staged(specs, fr, nspec, data, err, r, ctm, ptm, tmi, tma, matrix, tmin=-np
             dist_fit=True, rad_prior=False, need_prior=False):
     eng = _engine_for(specs)
     key = (_ids(fr, data, err, ctm, ptm, matrix), tuple(float(x) for x in r), float(tmi), float(tma), int(nspec),
-           float(tmin), float(tmax), _prior_key(prior), bool(a), bool(dist_fit), bool(rad_prior), bool(need_prior))
+           float(tmin), float(tmax), _prior_key(prior), bool(a), bool(dist_fit), bool(rad_prior), bool(need_prior),
+           _SPECTRUM)
     if eng._problem_key != key:
         av = None
         if need_prior and a:
@@ -117,7 +127,8 @@ def _staged(specs, fr, nspec, data, err, r, ctm, ptm, tmi, tma, matrix, tmin=-np
                                    'queries dustmaps Bayestar here, mft6.py:1233-1239)')
             av = _AV_TABLE
         eng.stage_problem(data, err, fr, r, ctm, ptm, tmi, tma, matrix, nspec=int(nspec), bands=_BANDS, av_table=av,
-                          tmin=tmin, tmax=tmax, prior=prior, use_av=bool(a), dist_fit=dist_fit, rad_prior=rad_prior)
+                          tmin=tmin, tmax=tmax, prior=prior, use_av=bool(a), dist_fit=dist_fit, rad_prior=rad_prior,
+                          spectrum=_SPECTRUM)
         eng._problem_key = key
         eng._problem_refs = (fr, data, err, ctm, ptm, matrix)  # pin the ids in the key
     return eng

@@ -318,7 +318,7 @@ def norm_spec(wl, model, data):
 
 
 def loglikelihood(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, matrix, av=True, optimize=False,
-                  bandlib=None, temps=None, lgs=None, parts=None):
+                  bandlib=None, temps=None, lgs=None, parts=None, spectrum=True):
     """mft6.py:1139-1205 for len(p0) in (6, 8).  ``parts`` (a dict) receives intermediates for tests."""
     wl, spec = np.array(data)
     t_guess = p0[:nspec]
@@ -342,6 +342,8 @@ def loglikelihood(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, matrix
     chi_c = chisq(contrast, fr[0], fr[1])
     chi_p = chisq(init_phot, fr[3], fr[4])
     total = np.sum((iic * (len(chi_c) + len(chi_p)), np.sum(chi_c), np.sum(chi_p)))  # mft6.py:1191
+    if not spectrum:  # mft6_nospec.py:1192: the spectrum term is commented out there
+        total = np.sum((np.sum(chi_c), np.sum(chi_p)))
     if parts is not None:
         parts.update(logg=np.array(lg, dtype=float), contrast=np.array(contrast), phot=np.array(init_phot),
                      model=model, data_norm=spec_n, iic=iic, icontrast=np.sum(chi_c), iphot=np.sum(chi_p))

@@ -325,6 +325,22 @@ def main():
             out['A_logprior_' + tag] = np.array(lp_ref)
             out['A_logpost_' + tag] = np.array(po_ref)
 
+        # ------------------------------------------------------------ the mft6_nospec.py variant (dataset B)
+        import importlib.util
+        nsp = importlib.util.spec_from_file_location('mft6_nospec', os.path.join(REF, 'mft6_nospec.py'))
+        mns = importlib.util.module_from_spec(nsp)
+        nsp.loader.exec_module(mns)
+        patch_third_party(mns, bandlib)
+        ns_ref = []
+        for pq in theta[:12]:
+            v = mns.loglikelihood(list(pq), frB, 2, 0, [wb, sb], eb, 1700, [min(wb), max(wb)], specs, ctm_syn, ptm6, tmiB,
+                                  tmaB, None, matrix)
+            o = orc.loglikelihood(list(pq), frB, 2, [wb, sb], eb, [min(wb), max(wb)], specs, ctm_syn, ptm6, tmiB, tmaB,
+                                  matrix, bandlib=bandlib, spectrum=False)
+            assert v == o, (v, o)
+            ns_ref.append(v)
+        out['B_nospec_loglike'] = np.array(ns_ref)
+
         # ------------------------------------------------------------ dist_fit=False branch (mft6.py:1275-1327)
         prior_nd = [3800.0, 0.0, 60.0, 1.0, 0.12, 0.03, 0.5, 0.0, 0.05, 1.0, 2.0732e-3, 0.0277e-3]
         th_nd = np.vstack([theta[:10], [[3850.0, 3025.0, 0.1, 1.7, 0.3, 2e-3], [3850.0, 3025.0, 0.1, 0.5, 0.3, 0.3],

@@ -526,3 +526,19 @@ def test_dist_fit_false_branch_matches_reference_golden(rad_prior):
     wantp = g['A_nodist_logprior_' + tag]
     assert np.array_equal(np.isinf(lp), np.isinf(wantp)) and rel_err(lp, wantp).max() < 1e-12
     assert np.isfinite(want[10]) and np.isfinite(want[11])   # R1 = 1.7 and plx = 0.3 pass without dist_fit
+
+
+def test_nospec_variant_matches_mft6_nospec_golden():
+    """The mft6_nospec.py likelihood (spectrum term commented out, mft6_nospec.py:1163-1196) is a flag on the
+    same kernel; golden values come from the reference's mft6_nospec.py itself."""
+    c = golden_case('B')
+    m = _dropin(c)
+    m.set_spectrum_term(False)
+    try:
+        args = [c.fr, 2, 0, c.data, c.err, 1700, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, None, c.matrix]
+        got = m.loglikelihood(c.theta[:12], *args)
+        assert rel_err(got, c.g['B_nospec_loglike']).max() < 1e-12
+    finally:
+        m.set_spectrum_term(True)
+    again = m.loglikelihood(c.theta[:12], *args)
+    assert rel_err(again, c.g['B_loglike'][:12]).max() < TIGHT

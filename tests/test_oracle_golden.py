@@ -152,3 +152,10 @@ def test_dist_fit_false_prior(rad_prior):
                                 dist_fit=False, rad_prior=rad_prior) for t in g['theta_nodist']])
     want = g['A_nodist_logprior_' + tag]
     assert np.array_equal(np.isinf(lp), np.isinf(want)) and rel_err(lp, want).max() < 1e-13
+
+
+def test_nospec_variant():
+    c = golden_case('B')
+    got = [orc.loglikelihood(list(t), c.fr, 2, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, c.matrix,
+                             bandlib=c.bandlib, spectrum=False) for t in c.theta[:12]]
+    assert np.array_equal(got, c.g['B_nospec_loglike'])
