@@ -542,3 +542,28 @@ def test_nospec_variant_matches_mft6_nospec_golden():
         m.set_spectrum_term(True)
     again = m.loglikelihood(c.theta[:12], *args)
     assert rel_err(again, c.g['B_loglike'][:12]).max() < TIGHT
+
+
+def test_randomised_edge_walkers_against_oracle(engB):
+    """Seeded fuzz over the whole prior box plus deliberately awkward values: Teff exactly on nodes, exactly
+    half-way between nodes (find_nearest ties), logg landing near nodes, A_V = 0 and tiny, box edges."""
+    c = golden_case('B')
+    rng = np.random.default_rng(2024)
+    n = 160
+    th = np.column_stack([rng.uniform(3000, 4200, n), rng.uniform(3000, 4200, n), rng.uniform(0, 1.0, n),
+                          rng.uniform(0.05, 1.5, n), rng.uniform(0.05, 1.2, n), rng.uniform(1 / 3000, 1 / 4, n)])
+    nodes = np.arange(3000.0, 4300.0, 100.0)
+    th[:20, 0] = rng.choice(nodes, 20)                       # on-node primaries
+    th[20:40, 1] = rng.choice(nodes[:-1], 20) + 50.0         # exact ties between two nodes
+    th[40:50, 2] = 0.0                                       # no reddening branch
+    th[50:60, 2] = 1e-12
+    th[60:64, 0] = [3000.0, 4200.0, 3000.0, 4200.0]          # box edges are inside (strict comparisons)
+    th[64:68, 3] = [0.05, 1.5, 0.05, 1.5]
+    th[68:70, 5] = [1 / 3000, 1 / 4]
+    got = engB.logposterior(th)
+    want = np.array([oracle_logpost(c, t) for t in th])
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    assert rel_err(got, want).max() < TIGHT
+    ll = engB.loglikelihood(th)
+    wl = np.array([oracle_loglike(c, t) for t in th])
+    assert rel_err(ll, wl).max() < TIGHT
