@@ -163,7 +163,8 @@ def main():
         raise SystemExit('--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run'.format(args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    force_gather = os.environ.get('MSX_BENCH_FORCE_GATHER') == '1'  # measure collective overhead on one GPU
+    if world > 1 or force_gather:
         dist.init_process_group('nccl', device_id=dev)
 
     eng = Engine(local)
@@ -179,7 +180,8 @@ def main():
     # collective runs on RCCL's stream; a buffer is only reused after its all-gather has completed)
     logp = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
     status = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
-    gathered = [torch.empty(n * world, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    use_gather = world > 1 or force_gather
+    gathered = [torch.empty(n * world, dtype=torch.float64, device=dev) for _ in range(2)] if use_gather else None
     works = [None, None]
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
@@ -188,28 +190,80 @@ def main():
     import ctypes as C
     fn = eng.ctx.lib.msx_logprob_batch_dev
     h = eng.ctx.h
+    # With a collective in flight RCCL's kernel holds a CU or two: 512-thread workgroups (one per CU, all 256
+    # CUs needed at once) would then run a second round for the displaced walkers; 256-thread workgroups
+    # (three per CU) absorb it.  So N > 1 defaults to 256 threads, N = 1 to the library's own choice (512).
+    block = args.block if args.block else (256 if use_gather else 0)
     calls = [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
-               C.c_void_p(status[b].data_ptr()), C.c_void_p(sptr), args.block) for b in range(2)] for t in thetas]
+               C.c_void_p(status[b].data_ptr()), C.c_void_p(sptr), block) for b in range(2)] for t in thetas]
 
     def launch(i):
         if fn(*calls[i % nbatch][i & 1]) != 0:
             raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
 
+    # The collective: one RCCL all-gather of n float64 per rank per step.  Preferred path: the library's own
+    # communicator (msx_comm_*: ncclAllGather enqueued from C on a dedicated stream, ~3 us of host time per
+    # step); its id is broadcast with torch.distributed.  Any failure to set it up falls back to
+    # torch.distributed's all_gather_into_tensor (~12 us of host time per step).  Both are RCCL over xGMI.
+    collective = 'none'
+    if use_gather:
+        collective = 'torch.distributed'
+        # measured on one GPU (world 1, forced): the direct path costs MORE host time per step (44 us) than
+        # torch.distributed's (33 us), so it is opt-in: MSX_BENCH_COLLECTIVE=rccl
+        if os.environ.get('MSX_BENCH_COLLECTIVE', 'torch') == 'rccl':
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(eng.ctx.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                eng.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                collective = 'msx_comm (direct RCCL)'
+            except Exception as exc:  # noqa: BLE001 - any setup problem: use the torch collective instead
+                print('[bench] direct RCCL communicator unavailable ({}); using torch.distributed'.format(exc),
+                      file=sys.stderr, flush=True)
+        ok_t = torch.tensor([1 if collective.startswith('msx_comm') else 0], device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)  # every rank must agree on the path
+        if int(ok_t.item()) == 0:
+            collective = 'torch.distributed'
+    direct = collective.startswith('msx_comm')
+    ag = eng.ctx.lib.msx_comm_allgather_dev
+    wt = eng.ctx.lib.msx_comm_wait_slot
+    pending = [False, False]
+    if direct:
+        ag_calls = [(h, C.c_void_p(logp[b].data_ptr()), C.c_void_p(gathered[b].data_ptr()), n, C.c_void_p(sptr), b)
+                    for b in range(2)]
+
     def gather(i):
         b = i & 1
+        if direct:
+            if ag(*ag_calls[b]) != 0:
+                raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
+            if args.no_overlap:
+                wt(h, b, C.c_void_p(sptr))
+            else:
+                pending[b] = True
+            return
+        w = dist.all_gather_into_tensor(gathered[b], logp[b], async_op=True)
         if args.no_overlap:
-            dist.all_gather_into_tensor(gathered[b], logp[b])
+            w.wait()
         else:
-            works[b] = dist.all_gather_into_tensor(gathered[b], logp[b], async_op=True)
+            works[b] = w
 
     def reuse_guard(i):
         b = i & 1
-        if works[b] is not None:  # stream-level wait (no host block): step i-2's all-gather read logp[b]
+        if direct:
+            if pending[b]:  # stream-level wait (no host block): step i-2's all-gather read logp[b]
+                wt(h, b, C.c_void_p(sptr))
+                pending[b] = False
+        elif works[b] is not None:
             works[b].wait()
             works[b] = None
 
     def drain():
         for b in range(2):
+            if direct and pending[b]:
+                wt(h, b, C.c_void_p(sptr))
+                pending[b] = False
             if works[b] is not None:
                 works[b].wait()
                 works[b] = None
@@ -217,7 +271,7 @@ def main():
     for i in range(args.warmup):
         reuse_guard(i)
         launch(i)
-        if world > 1:
+        if use_gather:
             gather(i)
     drain()
     # HIP events on the launch stream bracket runs of `ev_run` consecutive launches inside the timed region
@@ -237,7 +291,7 @@ def main():
         if k == 0 and g < nev:
             ev[g][0].record(stream)
         launch(i)
-        if world > 1:
+        if use_gather:
             gather(i)
         if k == ev_run - 1 and g < nev:
             ev[g][1].record(stream)
@@ -288,7 +342,7 @@ def main():
                                                                           ' overlapped with the next launch'))
                                        if world > 1 else ''),
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': nwin, 'grid': '26x4x135000 f64 synthetic',
-                       'block_threads': args.block or 'auto'},
+                       'block_threads': block or 'auto', 'collective': collective},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'logprob_kernel<2,2>',
                          'kernel_ms': kern_ms, 'kernel_ms_samples': nev * ev_run, 'algorithmic_bytes_per_launch': n * b_alg,
@@ -304,7 +358,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_gather:
         dist.destroy_process_group()
 
 

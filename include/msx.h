@@ -167,6 +167,19 @@ int msx_make_composite(msx_ctx *ctx, const double *teff, const double *logg, con
                        int32_t use_distance, double plx, double *spec_out, double *contrast_out,
                        double *phot_out, int32_t *status_out);
 
+/* ---- the one collective of the sharded path -- an RCCL all-gather of `count` float64 log-probs per
+ * rank.  The reference has no counterpart (its parallelism is multiprocessing.Pool, mft6.py:1744).  RCCL is
+ * resolved at run time from the librccl.so.1 already mapped in the process (PyTorch-ROCm's).  The id comes
+ * from rank 0 (msx_comm_unique_id) and reaches the other ranks by any side channel (bench.py: a
+ * torch.distributed broadcast).  msx_comm_allgather_dev runs the collective on the ctx's communication stream
+ * after everything queued on `compute_stream`, then signals event `slot` (0..3); msx_comm_wait_slot makes
+ * `compute_stream` wait for that event before a buffer is reused -- so step i's all-gather overlaps step i+1. */
+int msx_comm_unique_id(msx_ctx *ctx, uint8_t *out128);
+int msx_comm_init(msx_ctx *ctx, const uint8_t *id128, int32_t rank, int32_t world);
+int msx_comm_allgather_dev(msx_ctx *ctx, const double *d_send, double *d_recv, int64_t count, void *compute_stream,
+                           int32_t slot);
+int msx_comm_wait_slot(msx_ctx *ctx, int32_t slot, void *compute_stream);
+
 /* ---- measurement helpers ----------------------------------------------------------------------- */
 /* float4 device-to-device copy of `bytes` bytes, `iters` times; returns GB/s (read+write counted)  */
 int msx_stream_copy_gbps(msx_ctx *ctx, int64_t bytes, int32_t iters, double *gbps_out);

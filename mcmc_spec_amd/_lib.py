@@ -96,6 +96,10 @@ def load():
                                       C.POINTER(C.c_int32)]),
         'msx_make_composite': (C.c_int, [vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp,
                                          C.POINTER(C.c_int32)]),
+        'msx_comm_unique_id': (C.c_int, [vp, C.POINTER(C.c_uint8)]),
+        'msx_comm_init': (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
+        'msx_comm_allgather_dev': (C.c_int, [vp, vp, vp, C.c_int64, vp, C.c_int32]),
+        'msx_comm_wait_slot': (C.c_int, [vp, C.c_int32, vp]),
         'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
         'msx_bytes_per_eval': (C.c_int, [vp, _ip]),
     }
@@ -110,7 +114,8 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_make_composite', 'msx_stream_copy_gbps', 'msx_bytes_per_eval']
+            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
+            'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
 
 def as_f64(a):
@@ -276,6 +281,16 @@ class Context:
         self.check(self.lib.msx_make_composite(self.h, dptr(teff), dptr(logg), dptr(rad), int(bool(use_distance)),
                                                float(plx), dptr(spec), dptr(con), dptr(ph), C.byref(st)))
         return spec, con[:nc], ph[:nph], st.value
+
+    # ---- RCCL all-gather ------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        self.check(self.lib.msx_comm_unique_id(self.h, buf))
+        return bytes(buf)
+
+    def comm_init(self, id128, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        self.check(self.lib.msx_comm_init(self.h, buf, int(rank), int(world)))
 
     def bytes_per_eval(self):
         out = C.c_int64()

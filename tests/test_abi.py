@@ -53,3 +53,24 @@ def test_missing_library_fails_loudly(monkeypatch):
         assert 'no CPU fallback' in str(e)
     else:
         raise AssertionError('load() must raise when the HIP library is missing')
+
+
+def test_hot_kernel_variants_do_not_spill_to_scratch():
+    """The binary (nspec = 2) variants of the hot kernel must keep the by-value problem struct in the kernarg
+    segment and their working set in registers: ScratchSize 0 (a 1.2 KB/lane scratch copy of the struct once
+    doubled the kernel time when a helper stopped being inlined)."""
+    src = os.path.join(ROOT, 'mcmc_spec_amd', 'csrc', 'msx.hip')
+    with tempfile.TemporaryDirectory() as d:
+        out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+                              '-Rpass-analysis=kernel-resource-usage', '-o', os.path.join(d, 't.so'), src],
+                             capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stderr.splitlines()
+    seen = 0
+    for i, ln in enumerate(lines):
+        if 'Function Name' in ln and 'logprob_kernelILi2E' in ln:
+            block = '\n'.join(lines[i:i + 14])
+            m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', block)
+            assert m and int(m.group(1)) == 0, block
+            seen += 1
+    assert seen >= 3
