@@ -35,7 +35,7 @@ extern "C" {
 #define MSX_W_INDEXERROR 3 /* logg/Teff bracket runs past the last node        (mft6.py:453,477)   */
 #define MSX_W_VALUEERROR 4 /* Teff outside the isochrone table                 (mft6.py:95)        */
 
-/* evaluation modes for msx_logprob_batch* */
+/* evaluation modes for msx_logprob_batch* (modes 4 and 5 are reached through msx_opt_step / msx_opt_init) */
 #define MSX_MODE_LOGLIKE 0      /* loglikelihood   (mft6.py:1139-1205)                              */
 #define MSX_MODE_LOGPOST 1      /* logposterior = logprior gate + loglikelihood (mft6.py:1459-1470) */
 #define MSX_MODE_CHISQ 2        /* loglikelihood(optimize=True): returns total chi^2 (mft6.py:1198) */
@@ -131,7 +131,8 @@ int msx_stage_problem(msx_ctx *ctx, const msx_problem *p);
 /* theta is [n][ndim] row-major (ndim = 2*nspec+2); logp_out [n]; status_out [n] (MSX_W_*).        */
 int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n, int32_t ndim,
                       double *logp_out, int32_t *status_out);
-/* same with device pointers on a caller stream; does not synchronise.  block_threads = 0 -> auto  */
+/* same with device pointers on a caller stream; does not synchronise.  block_threads: 0 = auto (512 when
+ * n <= #CUs, else 256; 1024 for >= 8192 pixels) or one of 256 / 512 / 1024.                          */
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
 
