@@ -91,7 +91,9 @@ typedef struct msx_problem {
     int32_t has_prior_list; /* `prior != 0`                                         mft6.py:1241    */
     int32_t no_spectrum;    /* 1 = the mft6_nospec.py variant: total = contrast + photometry chi^2 only
                              * (mft6_nospec.py:1163-1196); the spectral phases are skipped            */
-    int32_t reserved_;
+    int32_t compact_pairs;  /* 1 = also stage the 12-byte pair table {f64 flux[lo], f32 flux[lo+1]-flux[lo]} and use
+                             * it in the binary hot kernel: -25 % pair bytes, ~1e-9 relative perturbation of the
+                             * upper sample (NOT bit-faithful to float64; off by default)                      */
 } msx_problem;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

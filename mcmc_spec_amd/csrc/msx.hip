@@ -54,6 +54,16 @@ constexpr double kLog2Of10 = 3.3219280948873623478703194294893901758648313930245
 // compiler copy all ~1.2 KB of it into per-lane scratch and route every later access through scratch
 // (measured: 21.8 -> 44.8 us per 256-walker launch).  `-Rpass-analysis=kernel-resource-usage` must show
 // ScratchSize 0 for logprob_kernel; tests/test_abi.py checks it.
+// Optional compact pair storage (msx_problem.compact_pairs): {flux[lo] as float64, flux[lo+1]-flux[lo] as
+// float32}, 12 bytes instead of 16.  The difference of neighbouring 0.2 A samples is ~1e-2..1e-3 of the flux,
+// so rounding it to float32 perturbs the upper sample by ~1e-9..1e-10 relative -- NOT bit-faithful to the
+// float64 reference arithmetic; off by default, measured in DESIGN.md.
+struct __attribute__((packed, aligned(4))) PairC {
+    double lo;
+    float d;
+};
+static_assert(sizeof(PairC) == 12, "PairC must be 12 bytes");
+
 struct DevProblem {
     // grid (A0)
     const double *grid;   // [nt*ng][nwl]
@@ -65,6 +75,7 @@ struct DevProblem {
     const uint8_t *present;
     // pixel tables (A8)
     const double2 *pairs;  // [nt*ng][npix] {flux[lo], flux[lo+1]}
+    const PairC *pairs_c;  // [nt*ng][npix] compact form, or nullptr
     const double2 *pix_k;  // [npix] {k[lo], k[lo+1]}
     const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
     int64_t npix;
@@ -1143,7 +1154,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // VGPRs (the two-pixels-per-trip body wants ~146: no spills, 3 waves per SIMD); the 1024-thread variants
 // are capped at 128 VGPRs by the hardware and use one pixel per trip.
 // GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
-template <int NS, int U, int MAXT, bool GM = false>
+template <int NS, int U, int MAXT, bool GM = false, bool CP = false>
 __global__ void __launch_bounds__(MAXT, 1)
 logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
@@ -1230,10 +1241,13 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
 
     // ---- phase A ------------------------------------------------------------------------------------
     const double2 *rows[NS * 4];
+    const PairC *rows_c[NS * 4];
     double w[NS * 4];
 #pragma unroll
     for (int c = 0; c < NS * 4; ++c) {
-        rows[c] = P.pairs + (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
+        const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
+        rows[c] = P.pairs + off;
+        rows_c[c] = CP ? P.pairs_c + off : nullptr;
         w[c] = D.w[c];
     }
     const double redc = D.redc;
@@ -1250,7 +1264,14 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
             const int p = base + u * B + tid;
             pp[u] = p < npix ? p : npix - 1;
 #pragma unroll
-            for (int c = 0; c < NS * 4; ++c) v[u][c] = rows[c][pp[u]];
+            for (int c = 0; c < NS * 4; ++c) {
+                if (CP) {
+                    const PairC pc = rows_c[c][pp[u]];
+                    v[u][c] = make_double2(pc.lo, (double)pc.d);  // .y holds the DIFFERENCE in compact mode
+                } else {
+                    v[u][c] = rows[c][pp[u]];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1267,6 +1288,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                 ylo = fma(w[c], v[u][c].x, ylo);
                 yhi = fma(w[c], v[u][c].y, yhi);
             }
+            if (CP) yhi += ylo;  // blended difference -> blended upper sample
             if (redden) {
                 const double elo = exp2(redc * kk[u].x);  // 10^(-0.4 A_V k)     mft6.py:62-63
                 // neighbouring grid samples: y = ln2 * c * (k_hi - k_lo) is tiny, so e^y from four series
@@ -1503,6 +1525,18 @@ __global__ void gather_pairs_kernel(const double *__restrict__ grid, int64_t nwl
     const double *row = grid + (int64_t)blockIdx.y * nwl;
     const int64_t j = lo[p];
     pairs[(int64_t)blockIdx.y * npix + p] = make_double2(row[j], row[j + 1]);
+}
+
+__global__ void gather_pairs_compact_kernel(const double *__restrict__ grid, int64_t nwl, const int64_t *__restrict__ lo,
+                                            int64_t npix, PairC *__restrict__ pairs) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const double *row = grid + (int64_t)blockIdx.y * nwl;
+    const int64_t j = lo[p];
+    PairC out;
+    out.lo = row[j];
+    out.d = (float)(row[j + 1] - row[j]);
+    pairs[(int64_t)blockIdx.y * npix + p] = out;
 }
 
 // band_tab[node][b] = sum_i w_b[i] * grid[node][i0_b + i];  grid.x = band, grid.y = node
@@ -2090,6 +2124,14 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     hipLaunchKernelGGL(gather_pairs_kernel, dim3(gg.x, 1), dim3(256), 0, c->stream, c->d_kgrid, c->nwl, d_lo, p->npix, d_pk);
     HIP_TRY(c, hipGetLastError());
     P.pairs = d_pairs; P.pix_k = d_pk;
+    P.pairs_c = nullptr;
+    if (p->compact_pairs) {
+        PairC *d_pc = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&d_pc, sizeof(PairC) * nn * p->npix)); tr.push_back(d_pc);
+        hipLaunchKernelGGL(gather_pairs_compact_kernel, gg, dim3(256), 0, c->stream, c->d_grid, c->nwl, d_lo, p->npix, d_pc);
+        HIP_TRY(c, hipGetLastError());
+        P.pairs_c = d_pc;
+    }
     // band integrals
     double *d_tab = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_tab, sizeof(double) * std::max<int64_t>(1, nn * nb))); tr.push_back(d_tab);
@@ -2114,6 +2156,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     c->model_in_global = model_in_global;
     if (need_lds > 48 * 1024 && !model_in_global) {
         const void *variants[] = {(const void *)logprob_kernel<2, 2, 512>, (const void *)logprob_kernel<2, 1, 1024>,
+                                  (const void *)logprob_kernel<2, 2, 512, false, true>,
                                   (const void *)logprob_kernel<3, 1, 512>, (const void *)logprob_kernel<3, 1, 1024>};
         for (const void *k : variants)
             HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_lds));
@@ -2185,7 +2228,10 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     }
     const dim3 g((unsigned)n), b((unsigned)B);
     if (c->P.nspec == 2) {
-        if (B <= 512) hipLaunchKernelGGL((logprob_kernel<2, 2, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        if (B <= 512 && c->P.pairs_c)
+            hipLaunchKernelGGL((logprob_kernel<2, 2, 512, false, true>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        else if (B <= 512)
+            hipLaunchKernelGGL((logprob_kernel<2, 2, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
         else hipLaunchKernelGGL((logprob_kernel<2, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
     } else {
         if (B <= 512) hipLaunchKernelGGL((logprob_kernel<3, 1, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
@@ -2450,7 +2496,8 @@ int msx_bytes_per_eval(msx_ctx *c, int64_t *requested_bytes) {
     if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_bytes_per_eval: no problem staged");
     const int64_t npix = c->P.npix;
     // pair rows (16 B x corners) + per-pixel statics read in phases A and C
-    *requested_bytes = npix * (16 * (int64_t)c->P.nspec * 4 + 16 + 8 * 3 + 8 * 3) + 8 * (2 * c->P.nspec + 2) + 12;
+    const int64_t pair_bytes = (c->P.pairs_c && c->P.nspec == 2) ? 12 : 16;
+    *requested_bytes = npix * (pair_bytes * (int64_t)c->P.nspec * 4 + 16 + 8 * 3 + 8 * 3) + 8 * (2 * c->P.nspec + 2) + 12;
     return MSX_OK;
 }
 

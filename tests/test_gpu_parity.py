@@ -567,3 +567,19 @@ def test_randomised_edge_walkers_against_oracle(engB):
     ll = engB.loglikelihood(th)
     wl = np.array([oracle_loglike(c, t) for t in th])
     assert rel_err(ll, wl).max() < TIGHT
+
+
+def test_compact_pair_storage_is_opt_in_and_stays_inside_the_bar():
+    """msx_problem.compact_pairs: {f64 flux[lo], f32 difference} pair table (12 B).  Not bit-faithful to the
+    float64 arithmetic, so it is off by default; when switched on the log-probabilities must still agree with
+    the reference goldens far inside the 1e-6 bar (measured: 3e-13 at S/N 100, 3e-11 at S/N 1000)."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    c = golden_case('B')
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega), compact_pairs=True)
+    got = eng.loglikelihood(c.theta)
+    assert rel_err(got, c.g['B_loglike']).max() < TIGHT
+    assert eng.ctx.bytes_per_eval() < 700 * (16 * 8 + 64)   # 12-byte pairs are in use
