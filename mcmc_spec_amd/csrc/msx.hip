@@ -1701,7 +1701,8 @@ struct msx_ctx {
     std::vector<void *> prob_allocs;
     // scratch for host-pointer entry points
     double *d_theta = nullptr, *d_logp = nullptr;
-    int32_t *d_status = nullptr;
+    int32_t *d_status = nullptr;  // points into d_logp's allocation
+    void *h_pin = nullptr;        // pinned host staging for the host-pointer entry points
     int64_t cap_walkers = 0;
     double *d_misc = nullptr;  // composite args / desc / small outputs
     double *d_spec = nullptr;
@@ -1873,8 +1874,9 @@ void msx_destroy(msx_ctx *c) {
     (void)hipSetDevice(c->device);
     free_problem(c);
     free_grid(c);
-    void *ptrs[] = {c->d_theta, c->d_logp, c->d_status, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain,
+    void *ptrs[] = {c->d_theta, c->d_logp, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain,
                     c->d_model_scratch};
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->rccl_comm && rccl().ok) (void)rccl().CommDestroy(c->rccl_comm);
@@ -2250,20 +2252,30 @@ int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, 
     if (n > c->cap_walkers) {
         if (c->d_theta) (void)hipFree(c->d_theta);
         if (c->d_logp) (void)hipFree(c->d_logp);
-        if (c->d_status) (void)hipFree(c->d_status);
-        c->d_theta = c->d_logp = nullptr; c->d_status = nullptr; c->cap_walkers = 0;
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->d_theta = c->d_logp = nullptr; c->d_status = nullptr; c->h_pin = nullptr; c->cap_walkers = 0;
         const int64_t cap = std::max<int64_t>(n, 1024);
         HIP_TRY(c, hipMalloc((void **)&c->d_theta, sizeof(double) * cap * MSX_MAX_DIM));
-        HIP_TRY(c, hipMalloc((void **)&c->d_logp, sizeof(double) * cap));
-        HIP_TRY(c, hipMalloc((void **)&c->d_status, sizeof(int32_t) * cap));
+        // log-probs and statuses share one device allocation
+        HIP_TRY(c, hipMalloc((void **)&c->d_logp, (sizeof(double) + sizeof(int32_t)) * cap));
+        c->d_status = reinterpret_cast<int32_t *>(c->d_logp + cap);
+        // pinned staging: async copies from / to pageable memory are staged synchronously by the runtime and
+        // cost ~15 us each; through pinned memory the whole call is launch + ~12 us
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_pin, (sizeof(double) * (MSX_MAX_DIM + 1) + sizeof(int32_t)) * cap, hipHostMallocDefault));
         c->cap_walkers = cap;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * n * ndim, hipMemcpyHostToDevice, c->stream));
+    const int64_t cap = c->cap_walkers;
+    double *h_theta = reinterpret_cast<double *>(c->h_pin);
+    double *h_out = h_theta + cap * MSX_MAX_DIM;  // [cap] log-probs followed by [cap] int32 statuses
+    memcpy(h_theta, theta, sizeof(double) * n * ndim);
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, h_theta, sizeof(double) * n * ndim, hipMemcpyHostToDevice, c->stream));
     int rc = msx_logprob_batch_dev(c, mode, c->d_theta, n, ndim, c->d_logp, c->d_status, c->stream, 0);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(logp_out, c->d_logp, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(status_out, c->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_logp, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_out + cap, c->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(logp_out, h_out, sizeof(double) * n);
+    memcpy(status_out, reinterpret_cast<int32_t *>(h_out + cap), sizeof(int32_t) * n);
     return MSX_OK;
 }
 
