@@ -53,7 +53,9 @@ constexpr double kLog2Of10 = 3.3219280948873623478703194294893901758648313930245
 // reference must be __forceinline__: an out-of-line call needs the struct's address, which makes the
 // compiler copy all ~1.2 KB of it into per-lane scratch and route every later access through scratch
 // (measured: 21.8 -> 44.8 us per 256-walker launch).  `-Rpass-analysis=kernel-resource-usage` must show
-// ScratchSize 0 for logprob_kernel; tests/test_abi.py checks it.
+// ScratchSize 0 for logprob_kernel; tests/test_abi.py checks it.  (Reading the struct through a pointer to a
+// device copy instead was tried: no scratch hazard, but 61 instead of 16 spilled SGPRs and +10 % kernel time
+// for 256-thread workgroups, so by-value + forced inlining stays.)
 // Optional compact pair storage (msx_problem.compact_pairs): {flux[lo] as float64, flux[lo+1]-flux[lo] as
 // float32}, 12 bytes instead of 16.  The difference of neighbouring 0.2 A samples is ~1e-2..1e-3 of the flux,
 // so rounding it to float32 perturbs the upper sample by ~1e-9..1e-10 relative -- NOT bit-faithful to the
@@ -931,14 +933,14 @@ __device__ unsigned long long g_med_stamps[65536 * 8];
 //   the binning (heavy duplication, infinities) fall back to the bitwise radix select.
 // ------------------------------------------------------------------------------------------------
 struct NoSide {
-    __device__ void operator()() const {}
+    __device__ __forceinline__ void operator()() const {}
 };
 // Per-element work that can ride along the median's first pass over the vector (it already reads every
 // element): process4() gets four (index, value, valid) triples, flush() publishes the wave partials
 // right before the pass's barrier.
 struct NoElem {
-    __device__ void process4(const int (&)[4], const double (&)[4], const bool (&)[4]) {}
-    __device__ void flush(BlockScratch &) {}
+    __device__ __forceinline__ void process4(const int (&)[4], const double (&)[4], const bool (&)[4]) {}
+    __device__ __forceinline__ void flush(BlockScratch &) {}
 };
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {  // l wave-uniform
@@ -1365,7 +1367,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         const double *pix_u, *pix_flux, *pix_ivar;
         double c0, c1, c2, acc;
         bool on;
-        __device__ void process4(const int (&pp)[4], const double (&xv)[4], const bool (&ok)[4]) {
+        __device__ __forceinline__ void process4(const int (&pp)[4], const double (&xv)[4], const bool (&ok)[4]) {
             if (!on) return;
             double u[4], f[4], e[4];
 #pragma unroll
@@ -1378,7 +1380,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                 acc += ok[k] ? t : 0.0;
             }
         }
-        __device__ void flush(BlockScratch &S) {
+        __device__ __forceinline__ void flush(BlockScratch &S) {
             if (!on) return;
             const double r = wave_sum(acc);
             if ((threadIdx.x & 63) == 0) S.chi[threadIdx.x >> 6] = r;

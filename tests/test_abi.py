@@ -56,9 +56,9 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 
 def test_hot_kernel_variants_do_not_spill_to_scratch():
-    """The binary (nspec = 2) variants of the hot kernel must keep the by-value problem struct in the kernarg
-    segment and their working set in registers: ScratchSize 0 (a 1.2 KB/lane scratch copy of the struct once
-    doubled the kernel time when a helper stopped being inlined)."""
+    """Every variant of the hot kernel must keep its working set in registers: ScratchSize 0.  (When the
+    problem struct was still a by-value kernel argument, a helper that stopped being inlined made the compiler
+    copy all 1.2 KB of it into per-lane scratch and doubled the kernel time; it is read through a pointer now.)"""
     src = os.path.join(ROOT, 'mcmc_spec_amd', 'csrc', 'msx.hip')
     with tempfile.TemporaryDirectory() as d:
         out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
@@ -68,9 +68,9 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
     lines = out.stderr.splitlines()
     seen = 0
     for i, ln in enumerate(lines):
-        if 'Function Name' in ln and 'logprob_kernelILi2E' in ln:
+        if 'Function Name' in ln and 'logprob_kernel' in ln:
             block = '\n'.join(lines[i:i + 14])
             m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', block)
             assert m and int(m.group(1)) == 0, block
             seen += 1
-    assert seen >= 3
+    assert seen >= 7   # binary + triple, 512 / 1024 threads, global-model and compact-pair variants
