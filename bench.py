@@ -194,11 +194,14 @@ def main():
     # CUs needed at once) would then run a second round for the displaced walkers; 256-thread workgroups
     # (three per CU) absorb it.  So N > 1 defaults to 256 threads, N = 1 to the library's own choice (512).
     block = args.block if args.block else (256 if use_gather else 0)
-    calls = [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
-               C.c_void_p(status[b].data_ptr()), C.c_void_p(sptr), block) for b in range(2)] for t in thetas]
+    def calls_for(sp):
+        return [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
+                  C.c_void_p(status[b].data_ptr()), C.c_void_p(sp), block) for b in range(2)] for t in thetas]
 
-    def launch(i):
-        if fn(*calls[i % nbatch][i & 1]) != 0:
+    calls = calls_for(sptr)
+
+    def launch(i, table=None):
+        if fn(*(table or calls)[i % nbatch][i & 1]) != 0:
             raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
 
     # The collective: one RCCL all-gather of n float64 per rank per step.  Preferred path: the library's own
@@ -274,6 +277,34 @@ def main():
         if use_gather:
             gather(i)
     drain()
+
+    # N > 1: the step is launch-bound on the host (kernel launch + collective issue ~ 30 us against a ~25 us
+    # kernel), so a run of `chunk` steps (kernel -> all-gather, double-buffered exactly as above) is captured
+    # into one hipGraph and replayed; the timed region still executes exactly K steps (K // chunk replays, the
+    # remainder issued eagerly).  Any capture failure falls back to the eager loop on every rank.
+    graph, chunk = None, 0
+    if use_gather and not direct and os.environ.get('MSX_BENCH_GRAPH', '1') == '1' and args.steps >= 8:
+        chunk = min(int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '40')), args.steps) // (2 * nbatch) * (2 * nbatch)
+        try:
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev)):
+                tab = calls_for(torch.cuda.current_stream(dev).cuda_stream)
+                for i in range(chunk):
+                    reuse_guard(i)
+                    launch(i, tab)
+                    gather(i)
+                drain()
+            graph.replay()  # one untimed replay
+            torch.cuda.synchronize(dev)
+        except Exception as exc:  # noqa: BLE001
+            print('[bench] hipGraph capture of the step loop failed ({}); eager loop'.format(exc), file=sys.stderr, flush=True)
+            graph = None
+            works[0] = works[1] = None
+        ok_t = torch.tensor([1 if graph is not None else 0], device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if int(ok_t.item()) == 0:
+            graph = None
     # HIP events on the launch stream bracket runs of `ev_run` consecutive launches inside the timed region
     # (an event pair around every single launch would put two extra packets between back-to-back kernels
     # and inflate what it measures); kernel_ms = elapsed / ev_run, i.e. duration + the stream's launch gap
@@ -285,7 +316,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    first_eager = 0
+    if graph is not None:
+        for _ in range(args.steps // chunk):
+            graph.replay()
+        first_eager = args.steps // chunk * chunk
+        nev = 0  # kernel timed separately below
+    for i in range(first_eager, args.steps):
         reuse_guard(i)
         g, k = divmod(i, ev_run)
         if k == 0 and g < nev:
@@ -305,8 +342,9 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    if nev > 0 and world == 1:
+    if nev > 0 and world == 1 and graph is None:
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:nev]])) / ev_run
+        kern_samples = nev * ev_run
     else:  # N > 1: collectives share the stream timeline; time the kernel alone after the timed region
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -315,6 +353,7 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize(dev)
         kern_ms = e0.elapsed_time(e1) / ev_run
+        kern_samples = ev_run
     bad = int((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item())
 
     if rank == 0:
@@ -342,10 +381,13 @@ def main():
                                                                           ' overlapped with the next launch'))
                                        if world > 1 else ''),
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': nwin, 'grid': '26x4x135000 f64 synthetic',
-                       'block_threads': block or 'auto', 'collective': collective},
+                       'block_threads': block or 'auto', 'collective': collective,
+                       'step_loop': ('hipGraph of {} steps x {} replays + {} eager'.format(
+                           chunk, args.steps // chunk, args.steps - args.steps // chunk * chunk)
+                           if graph is not None else 'eager')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'logprob_kernel<2,2>',
-                         'kernel_ms': kern_ms, 'kernel_ms_samples': nev * ev_run, 'algorithmic_bytes_per_launch': n * b_alg,
+                         'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples, 'algorithmic_bytes_per_launch': n * b_alg,
                          'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
                          'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
                          'note': NWIN_DOC},
