@@ -163,6 +163,21 @@ int msx_sampler_run(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int64_
                     const double *zfac, const double *logu, double *chain_out, double *logp_out, int64_t *naccept,
                     int32_t *worst_status);
 
+/* The same loop, pipelined (what mcmc_spec_amd.sampler.DeviceEnsembleSampler drives): begin uploads the ensemble
+ * state and sets up two slots; enqueue(slot) stages one chunk of randomness (arrays of nsteps*2*(nw/2) entries, laid
+ * out as for msx_sampler_run; indices are range-checked on the host) and queues its 2*nsteps fused launches WITHOUT
+ * waiting -- uploads, launches and chain downloads run on three HIP streams; collect(slot) waits for that chunk only
+ * and returns its chain rows, the cumulative acceptance counts as of its last step and its worst status.  Enqueue
+ * chunk i+1 before collecting chunk i and the GPU never idles between chunks.  end() optionally returns the final
+ * state (coords/logp may be NULL) and frees everything; restaging the problem or destroying the ctx ends a run too. */
+int msx_sampler_begin(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int64_t max_chunk_steps, const double *coords,
+                      const double *logp, const int64_t *naccept /* NULL = zeros */);
+int msx_sampler_enqueue(msx_ctx *ctx, int32_t slot /* 0|1 */, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
+                        const int32_t *partner, const double *zz, const double *zfac, const double *logu);
+int msx_sampler_collect(msx_ctx *ctx, int32_t slot, double *chain_out, double *logp_out, int64_t *naccept,
+                        int32_t *worst_status);
+int msx_sampler_end(msx_ctx *ctx, double *coords, double *logp);
+
 /* ---- A4-A6: make_composite (mft6.py:651-831, plot=False) -------------------------------------- */
 /* teff/logg/rad are [nspec]; use_distance = 0 mirrors `distance=False` (mft6.py:701-703).         */
 /* spec_out [win_n], contrast_out [n_contrast], phot_out [n_phot] (unreddened magnitudes).         */

@@ -94,6 +94,11 @@ def load():
         'msx_sampler_run': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp, _ip,
                                       C.POINTER(C.c_int32)]),
+        'msx_sampler_begin': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, _ip]),
+        'msx_sampler_enqueue': (C.c_int, [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), _dp, _dp, _dp]),
+        'msx_sampler_collect': (C.c_int, [vp, C.c_int32, _dp, _dp, _ip, C.POINTER(C.c_int32)]),
+        'msx_sampler_end': (C.c_int, [vp, _dp, _dp]),
         'msx_make_composite': (C.c_int, [vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp,
                                          C.POINTER(C.c_int32)]),
         'msx_comm_unique_id': (C.c_int, [vp, C.POINTER(C.c_uint8)]),
@@ -114,7 +119,8 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
+            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
+            'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
 
@@ -271,6 +277,47 @@ class Context:
                                             arrs[2].ctypes.data_as(i32p), dptr(dbl[0]), dptr(dbl[1]), dptr(dbl[2]),
                                             dptr(chain), dptr(lpc), iptr(nacc), C.byref(worst)))
         return chain, lpc, nacc, worst.value
+
+    def sampler_begin(self, mode, coords, logp, max_chunk_steps, naccept=None):
+        """Start a pipelined device-resident run (msx_sampler_begin): uploads the ensemble state."""
+        coords, logp = as_f64(coords), as_f64(logp)
+        nw, ndim = coords.shape
+        nacc = None if naccept is None else np.ascontiguousarray(naccept, dtype=np.int64)
+        self.check(self.lib.msx_sampler_begin(self.h, int(mode), nw, ndim, int(max_chunk_steps), dptr(coords), dptr(logp),
+                                              None if nacc is None else iptr(nacc)))
+        self._smp_shape = (nw, ndim)
+
+    def sampler_enqueue(self, slot, sidx, cidx, partner, zz, zfac, logu):
+        """Queue one chunk (arrays of shape (nsteps, 2, nw/2)) without waiting for it."""
+        i32p = C.POINTER(C.c_int32)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (sidx, cidx, partner)]
+        dbl = [as_f64(a) for a in (zz, zfac, logu)]
+        nsteps = dbl[0].shape[0]
+        for a in arrs + dbl:
+            if a.shape != (nsteps, 2, self._smp_shape[0] // 2):
+                raise ValueError('sampler_enqueue: arrays must have shape (nsteps, 2, nwalkers/2)')
+        self.check(self.lib.msx_sampler_enqueue(self.h, int(slot), nsteps, arrs[0].ctypes.data_as(i32p),
+                                                arrs[1].ctypes.data_as(i32p), arrs[2].ctypes.data_as(i32p),
+                                                dptr(dbl[0]), dptr(dbl[1]), dptr(dbl[2])))
+        return nsteps
+
+    def sampler_collect(self, slot, nsteps):
+        """Wait for the chunk in `slot`: (chain [nsteps][nw][ndim], logp [nsteps][nw], naccept [nw], worst)."""
+        nw, ndim = self._smp_shape
+        chain, lpc = np.empty((nsteps, nw, ndim)), np.empty((nsteps, nw))
+        nacc = np.zeros(nw, dtype=np.int64)
+        worst = C.c_int32()
+        self.check(self.lib.msx_sampler_collect(self.h, int(slot), dptr(chain), dptr(lpc), iptr(nacc), C.byref(worst)))
+        return chain, lpc, nacc, worst.value
+
+    def sampler_end(self, want_state=False):
+        if not want_state:
+            self.check(self.lib.msx_sampler_end(self.h, None, None))
+            return None
+        nw, ndim = self._smp_shape
+        coords, logp = np.empty((nw, ndim)), np.empty(nw)
+        self.check(self.lib.msx_sampler_end(self.h, dptr(coords), dptr(logp)))
+        return coords, logp
 
     def make_composite(self, teff, logg, rad, use_distance, plx, win_n, nc, nph):
         teff, logg, rad = as_f64(teff), as_f64(logg), as_f64(rad)

@@ -1722,7 +1722,9 @@ struct msx_ctx {
     int comm_world = 0, comm_rank = 0;
     double *d_model_scratch = nullptr;
     int64_t cap_model_scratch = 0;  // doubles
+    struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
 };
+static void sampler_free(msx_ctx *c);
 
 namespace {
 
@@ -1786,6 +1788,7 @@ int dev_alloc_copy(msx_ctx *c, std::vector<void *> *track, const T *host, int64_
 }
 
 void free_problem(msx_ctx *c) {
+    sampler_free(c);  // a sampler in flight holds pointers into the problem's tables
     for (void *p : c->prob_allocs) (void)hipFree(p);
     c->prob_allocs.clear();
     c->problem_staged = false;
@@ -1874,6 +1877,7 @@ int msx_create(int device, msx_ctx **out) {
 void msx_destroy(msx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    sampler_free(c);
     free_problem(c);
     free_grid(c);
     void *ptrs[] = {c->d_theta, c->d_logp, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain,
@@ -2318,77 +2322,208 @@ int msx_opt_step(msx_ctx *c, const double *theta, const int32_t *chain, int64_t 
     return msx_logprob_batch(c, MSX_MODE_OPT_STEP, theta, n, ndim, chi2_out, status_out);
 }
 
-int msx_sampler_run(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t nsteps, double *coords, double *logp,
-                    const int32_t *sidx, const int32_t *cidx, const int32_t *partner, const double *zz,
-                    const double *zfac, const double *logu, double *chain_out, double *logp_out, int64_t *naccept,
-                    int32_t *worst_status) {
+// ---- device-resident sampler, pipelined -------------------------------------------------------------------
+// begin: ensemble state + two slots (device chunk buffers, pinned host staging, events).  enqueue(slot): the
+// chunk's randomness goes host -> pinned -> device on the copy stream while the previous chunk's kernels run,
+// its 2*nsteps fused launches go on the compute stream, its chain comes back on the copy stream.  collect(slot)
+// waits for that slot only.  With two slots the compute stream never drains between chunks.
+struct SamplerRun {
+    int32_t mode = 0, ndim = 0;
+    int64_t nw = 0, ns = 0, cap_steps = 0;
+    char *d_state = nullptr;
+    double *d_coords = nullptr, *d_logp = nullptr, *d_q = nullptr, *d_newlp = nullptr;
+    int64_t *d_nacc = nullptr;
+    int32_t *d_wst = nullptr;
+    hipStream_t copy = nullptr, up = nullptr;  // downloads / uploads: separate queues, or chunk i+1's upload
+                                               // would wait behind chunk i's download (which waits for its kernels)
+    struct Slot {
+        char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+        hipEvent_t in_ready = nullptr, kernels_done = nullptr, out_ready = nullptr;
+        int64_t nsteps = 0;
+        bool busy = false;
+    } slot[2];
+    size_t in_bytes(int64_t st) const { return (size_t)(st * 2 * ns) * (3 * sizeof(double) + 3 * sizeof(int32_t)); }
+    size_t out_bytes(int64_t st) const {
+        return sizeof(double) * (size_t)(st * nw * ndim + st * nw) + sizeof(int64_t) * (size_t)nw + 16;
+    }
+};
+
+static void sampler_free(msx_ctx *c) {
+    SamplerRun *r = c->smp;
+    if (!r) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (r->copy) (void)hipStreamSynchronize(r->copy);
+    if (r->up) (void)hipStreamSynchronize(r->up);
+    for (auto &sl : r->slot) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
+        if (sl.kernels_done) (void)hipEventDestroy(sl.kernels_done);
+        if (sl.out_ready) (void)hipEventDestroy(sl.out_ready);
+    }
+    if (r->d_state) (void)hipFree(r->d_state);
+    if (r->copy) (void)hipStreamDestroy(r->copy);
+    if (r->up) (void)hipStreamDestroy(r->up);
+    delete r;
+    c->smp = nullptr;
+    c->P.smp_on = 0;
+}
+
+int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t max_chunk_steps, const double *coords,
+                      const double *logp, const int64_t *naccept) {
     if (!c) return MSX_ERR_INVALID;
-    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_sampler_run: no problem staged");
-    if (!coords || !logp || !sidx || !cidx || !partner || !zz || !zfac || !logu || !chain_out || !logp_out || !naccept ||
-        !worst_status || nw < 2 || (nw & 1) || nsteps < 1)
-        return fail(c, MSX_ERR_INVALID, "msx_sampler_run: bad arguments (need an even number of walkers)");
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_sampler_begin: no problem staged");
+    if (!coords || !logp || nw < 2 || (nw & 1) || max_chunk_steps < 1)
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_begin: bad arguments (need an even number of walkers)");
     if (ndim != 2 * c->P.nspec + 2) return fail(c, MSX_ERR_INVALID, "P0 doesn't match what I was expecting");
-    if (mode != MSX_MODE_LOGPOST && mode != MSX_MODE_LOGLIKE) return fail(c, MSX_ERR_INVALID, "msx_sampler_run: bad mode");
+    if (mode != MSX_MODE_LOGPOST && mode != MSX_MODE_LOGLIKE) return fail(c, MSX_ERR_INVALID, "msx_sampler_begin: bad mode");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int64_t ns = nw / 2, nh = nsteps * 2 * ns;
-    // one allocation for the whole chunk: state, per-half randomness, chain
-    const size_t bytes_d = sizeof(double) * (size_t)(nw * ndim + nw + 3 * nh + ns * ndim + ns + nsteps * nw * ndim + nsteps * nw);
-    const size_t bytes_i = sizeof(int32_t) * (size_t)(3 * nh + ns + 1) + sizeof(int64_t) * (size_t)nw;
-    char *base = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&base, bytes_d + bytes_i + 64));
-    double *d_coords = (double *)base, *d_logp = d_coords + nw * ndim, *d_zz = d_logp + nw, *d_zfac = d_zz + nh,
-           *d_logu = d_zfac + nh, *d_q = d_logu + nh, *d_newlp = d_q + ns * ndim, *d_chain = d_newlp + ns,
-           *d_lpchain = d_chain + nsteps * nw * ndim;
-    int64_t *d_nacc = (int64_t *)(d_lpchain + nsteps * nw);
-    int32_t *d_sidx = (int32_t *)(d_nacc + nw), *d_cidx = d_sidx + nh, *d_partner = d_cidx + nh, *d_wst = d_partner + nh,
-            *d_worst = d_wst + ns;
-    int rc = MSX_OK;
-    hipError_t e = hipSuccess;
-    auto up = [&](void *dst, const void *src, size_t n) {
-        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream);
-    };
-    up(d_coords, coords, sizeof(double) * nw * ndim);
-    up(d_logp, logp, sizeof(double) * nw);
-    up(d_zz, zz, sizeof(double) * nh);
-    up(d_zfac, zfac, sizeof(double) * nh);
-    up(d_logu, logu, sizeof(double) * nh);
-    up(d_sidx, sidx, sizeof(int32_t) * nh);
-    up(d_cidx, cidx, sizeof(int32_t) * nh);
-    up(d_partner, partner, sizeof(int32_t) * nh);
-    up(d_nacc, naccept, sizeof(int64_t) * nw);
-    if (e == hipSuccess) e = hipMemsetAsync(d_worst, 0, sizeof(int32_t), c->stream);
-    // one fused launch per half-step: proposal in the kernel's first lines, accept rule + chain row in its last
+    sampler_free(c);
+    SamplerRun *r = new SamplerRun;
+    c->smp = r;
+    r->mode = mode; r->ndim = ndim; r->nw = nw; r->ns = nw / 2; r->cap_steps = max_chunk_steps;
+    const int64_t ns = r->ns;
+    const size_t state_bytes = sizeof(double) * (size_t)(nw * ndim + nw + ns * ndim + ns) + sizeof(int64_t) * (size_t)nw +
+                               sizeof(int32_t) * (size_t)ns + 64;
+    hipError_t e = hipMalloc((void **)&r->d_state, state_bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->up, hipStreamNonBlocking);
+    for (auto &sl : r->slot) {
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_in, r->in_bytes(max_chunk_steps));
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_out, r->out_bytes(max_chunk_steps));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_in, r->in_bytes(max_chunk_steps), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_out, r->out_bytes(max_chunk_steps), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.in_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.kernels_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.out_ready, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        r->d_coords = (double *)r->d_state; r->d_logp = r->d_coords + nw * ndim; r->d_q = r->d_logp + nw;
+        r->d_newlp = r->d_q + ns * ndim; r->d_nacc = (int64_t *)(r->d_newlp + ns); r->d_wst = (int32_t *)(r->d_nacc + nw);
+        e = hipMemcpyAsync(r->d_coords, coords, sizeof(double) * nw * ndim, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_logp, logp, sizeof(double) * nw, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = naccept ? hipMemcpyAsync(r->d_nacc, naccept, sizeof(int64_t) * nw, hipMemcpyHostToDevice, c->stream)
+                    : hipMemsetAsync(r->d_nacc, 0, sizeof(int64_t) * nw, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the caller's arrays are consumed on return
+    if (e != hipSuccess) {
+        sampler_free(c);
+        return fail(c, MSX_ERR_HIP, std::string("msx_sampler_begin: ") + hipGetErrorString(e));
+    }
+    return MSX_OK;
+}
+
+int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
+                        const int32_t *partner, const double *zz, const double *zfac, const double *logu) {
+    if (!c) return MSX_ERR_INVALID;
+    SamplerRun *r = c->smp;
+    if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: call msx_sampler_begin first");
+    if (slot < 0 || slot > 1 || nsteps < 1 || nsteps > r->cap_steps || !sidx || !cidx || !partner || !zz || !zfac || !logu)
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue: bad arguments");
+    SamplerRun::Slot &sl = r->slot[slot];
+    if (sl.busy) return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: slot not collected yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t ns = r->ns, nw = r->nw, nh = nsteps * 2 * ns;
+    const int ndim = r->ndim;
+    // pinned staging, doubles first: [zz | zfac | logu | sidx | cidx | partner]
+    double *hz = (double *)sl.h_in;
+    int32_t *hi = (int32_t *)(hz + 3 * nh);
+    memcpy(hz, zz, sizeof(double) * nh); memcpy(hz + nh, zfac, sizeof(double) * nh); memcpy(hz + 2 * nh, logu, sizeof(double) * nh);
+    memcpy(hi, sidx, sizeof(int32_t) * nh); memcpy(hi + nh, cidx, sizeof(int32_t) * nh);
+    memcpy(hi + 2 * nh, partner, sizeof(int32_t) * nh);
+    // every index is dereferenced on the device: check them here
+    for (int64_t i = 0; i < nh; ++i)
+        if ((uint32_t)hi[i] >= (uint32_t)nw || (uint32_t)hi[nh + i] >= (uint32_t)nw || (uint32_t)hi[2 * nh + i] >= (uint32_t)ns)
+            return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue: walker / partner index out of range");
+    HIP_TRY(c, hipMemcpyAsync(sl.d_in, sl.h_in, r->in_bytes(nsteps), hipMemcpyHostToDevice, r->up));
+    HIP_TRY(c, hipEventRecord(sl.in_ready, r->up));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.in_ready, 0));
+    double *d_zz = (double *)sl.d_in, *d_zfac = d_zz + nh, *d_logu = d_zfac + nh;
+    int32_t *d_sidx = (int32_t *)(d_logu + nh), *d_cidx = d_sidx + nh, *d_partner = d_cidx + nh;
+    double *d_chain = (double *)sl.d_out, *d_lpchain = d_chain + nsteps * nw * ndim;
+    int64_t *d_nacc_snap = (int64_t *)(d_lpchain + nsteps * nw);
+    int32_t *d_worst = (int32_t *)(d_nacc_snap + nw);
+    HIP_TRY(c, hipMemsetAsync(d_worst, 0, sizeof(int32_t), c->stream));
     DevProblem &P = c->P;
     P.smp_on = 1;
-    P.smp_coords = d_coords; P.smp_logp = d_logp; P.smp_q = d_q; P.smp_naccept = d_nacc; P.smp_worst = d_worst;
-    for (int64_t st = 0; st < nsteps && e == hipSuccess && rc == MSX_OK; ++st) {
+    P.smp_coords = r->d_coords; P.smp_logp = r->d_logp; P.smp_q = r->d_q; P.smp_naccept = r->d_nacc; P.smp_worst = d_worst;
+    int rc = MSX_OK;
+    for (int64_t st = 0; st < nsteps && rc == MSX_OK; ++st) {
         for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
             const int64_t off = (st * 2 + half) * ns;
             P.smp_sidx = d_sidx + off; P.smp_cidx = d_cidx + off; P.smp_partner = d_partner + off;
             P.smp_zz = d_zz + off; P.smp_zfac = d_zfac + off; P.smp_logu = d_logu + off;
             P.smp_chain_row = d_chain + st * nw * ndim; P.smp_lp_row = d_lpchain + st * nw;
-            rc = msx_logprob_batch_dev(c, mode, d_q, ns, ndim, d_newlp, d_wst, c->stream, 0);
+            rc = msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
         }
     }
     P.smp_on = 0;
-    if (e == hipSuccess) e = hipGetLastError();
-    auto down = [&](void *dst, const void *src, size_t n) {
-        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream);
-    };
-    if (rc == MSX_OK) {
-        down(coords, d_coords, sizeof(double) * nw * ndim);
-        down(logp, d_logp, sizeof(double) * nw);
-        down(chain_out, d_chain, sizeof(double) * nsteps * nw * ndim);
-        down(logp_out, d_lpchain, sizeof(double) * nsteps * nw);
-        down(naccept, d_nacc, sizeof(int64_t) * nw);
-        down(worst_status, d_worst, sizeof(int32_t));
-    }
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = e2;
-    (void)hipFree(base);
     if (rc != MSX_OK) return rc;
-    if (e != hipSuccess) return fail(c, MSX_ERR_HIP, std::string("msx_sampler_run: ") + hipGetErrorString(e));
+    // acceptance counters keep running while this chunk's results travel: snapshot them in stream order
+    HIP_TRY(c, hipMemcpyAsync(d_nacc_snap, r->d_nacc, sizeof(int64_t) * nw, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(sl.kernels_done, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(r->copy, sl.kernels_done, 0));
+    HIP_TRY(c, hipMemcpyAsync(sl.h_out, sl.d_out, r->out_bytes(nsteps), hipMemcpyDeviceToHost, r->copy));
+    HIP_TRY(c, hipEventRecord(sl.out_ready, r->copy));
+    sl.nsteps = nsteps;
+    sl.busy = true;
     return MSX_OK;
+}
+
+int msx_sampler_collect(msx_ctx *c, int32_t slot, double *chain_out, double *logp_out, int64_t *naccept,
+                        int32_t *worst_status) {
+    if (!c) return MSX_ERR_INVALID;
+    SamplerRun *r = c->smp;
+    if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_collect: call msx_sampler_begin first");
+    if (slot < 0 || slot > 1 || !chain_out || !logp_out || !naccept || !worst_status)
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_collect: bad arguments");
+    SamplerRun::Slot &sl = r->slot[slot];
+    if (!sl.busy) return fail(c, MSX_ERR_STATE, "msx_sampler_collect: nothing enqueued in this slot");
+    HIP_TRY(c, hipEventSynchronize(sl.out_ready));
+    const int64_t st = sl.nsteps, nw = r->nw;
+    const double *h_chain = (const double *)sl.h_out, *h_lp = h_chain + st * nw * r->ndim;
+    const int64_t *h_nacc = (const int64_t *)(h_lp + st * nw);
+    memcpy(chain_out, h_chain, sizeof(double) * st * nw * r->ndim);
+    memcpy(logp_out, h_lp, sizeof(double) * st * nw);
+    memcpy(naccept, h_nacc, sizeof(int64_t) * nw);
+    *worst_status = *(const int32_t *)(h_nacc + nw);
+    sl.busy = false;
+    return MSX_OK;
+}
+
+int msx_sampler_end(msx_ctx *c, double *coords, double *logp) {
+    if (!c) return MSX_ERR_INVALID;
+    SamplerRun *r = c->smp;
+    if (!r) return MSX_OK;
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && coords) e = hipMemcpy(coords, r->d_coords, sizeof(double) * r->nw * r->ndim, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && logp) e = hipMemcpy(logp, r->d_logp, sizeof(double) * r->nw, hipMemcpyDeviceToHost);
+    sampler_free(c);
+    if (e != hipSuccess) return fail(c, MSX_ERR_HIP, std::string("msx_sampler_end: ") + hipGetErrorString(e));
+    return MSX_OK;
+}
+
+// one synchronous chunk (the pipelined entry points above, used back to back)
+int msx_sampler_run(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t nsteps, double *coords, double *logp,
+                    const int32_t *sidx, const int32_t *cidx, const int32_t *partner, const double *zz,
+                    const double *zfac, const double *logu, double *chain_out, double *logp_out, int64_t *naccept,
+                    int32_t *worst_status) {
+    if (!c) return MSX_ERR_INVALID;
+    if (!coords || !logp || !chain_out || !logp_out || !naccept || !worst_status || nsteps < 1)
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_run: bad arguments (need an even number of walkers)");
+    int rc = msx_sampler_begin(c, mode, nw, ndim, nsteps, coords, logp, naccept);
+    if (rc == MSX_OK) rc = msx_sampler_enqueue(c, 0, nsteps, sidx, cidx, partner, zz, zfac, logu);
+    if (rc == MSX_OK) rc = msx_sampler_collect(c, 0, chain_out, logp_out, naccept, worst_status);
+    if (rc == MSX_OK) return msx_sampler_end(c, coords, logp);
+    const std::string keep = c->err;
+    sampler_free(c);
+    c->err = keep;
+    return rc;
 }
 
 int msx_make_composite(msx_ctx *c, const double *teff, const double *logg, const double *rad, int32_t use_distance,

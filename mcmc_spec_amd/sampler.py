@@ -43,7 +43,12 @@ class EnsembleSampler:
         self.a = float(a)
         self.vectorize = bool(vectorize)
         self.pool = pool
-        self.rng = np.random.default_rng(seed)
+        # two independent streams of one seed: uniforms (stretch factors, partners, accept draws) and the
+        # random split.  Each is consumed strictly row by row, so drawing m iterations in one call gives the
+        # same numbers as m calls of one iteration -- the host loop (m = 1) and the device-resident loop
+        # (m = chunk) walk the same chain
+        ss = seed if isinstance(seed, np.random.SeedSequence) else np.random.SeedSequence(seed)
+        self.rng, self._rng_split = (np.random.Generator(np.random.PCG64(c)) for c in ss.spawn(2))
         self.reset()
 
     # ---- bookkeeping ------------------------------------------------------------------------------
@@ -93,32 +98,48 @@ class EnsembleSampler:
         return lp
 
     # ---- the move -------------------------------------------------------------------------------------
-    def _draw_step(self):
-        """All randomness of one iteration, in a fixed order: the split, then per half the stretch factors,
-        the partner indices and the accept uniforms.  Shared by the host loop and the device-resident loop,
-        which therefore walk the same chain for the same seed."""
-        nw = self.nwalkers
-        perm = self.rng.permutation(nw)
-        halves = (perm[: nw // 2], perm[nw // 2:])
-        draws = []
-        for k in (0, 1):
-            ns = len(halves[k])
-            zz = ((self.a - 1.0) * self.rng.random(ns) + 1.0) ** 2 / self.a
-            partner = self.rng.integers(len(halves[1 - k]), size=ns)
-            logu = np.log(self.rng.random(ns))
-            draws.append((halves[k], halves[1 - k], zz, partner, logu))
-        return draws
+    def _draw_steps(self, m):
+        """All randomness of ``m`` iterations at once: per iteration the random split into two halves, then per
+        half the stretch factors ``z = ((a-1)u+1)^2/a``, the partner index ``floor(u*n_half)`` and ``ln u`` of
+        the accept draw.  Returns ``sidx, cidx, partner`` (int32) and ``zz, zfac, logu`` (float64), each of
+        shape (m, 2, nwalkers/2); ``zfac = (ndim-1) ln z``.  Shared by the host loop and the device-resident
+        loop; everything is vectorised over the m iterations (the host must stay ahead of a 23 us kernel)."""
+        return self._draw_split(m) + self._draw_moves(m)
+
+    def _draw_split(self, m):
+        """(sidx, cidx): the random split of each of m iterations (stream ``_rng_split``)."""
+        nw, ns = self.nwalkers, self.nwalkers // 2
+        # permuted() has its fast path for 8-byte items
+        perm = self._rng_split.permuted(np.broadcast_to(np.arange(nw, dtype=np.int64), (m, nw)).copy(), axis=1)
+        halves = perm.astype(np.int32).reshape(m, 2, ns)
+        return halves, halves[:, ::-1]
+
+    def _draw_moves(self, m):
+        """(partner, zz, zfac, logu) of m iterations (stream ``rng``)."""
+        ns = self.nwalkers // 2
+        u = self.rng.random((m, 3, 2, ns))
+        # contiguous operands: the elementwise loops (log in particular) then take the same code path for
+        # every m, which the bit-identity of host and device chains relies on
+        uz, up, ua = (np.ascontiguousarray(u[:, j]) for j in range(3))
+        zz = ((self.a - 1.0) * uz + 1.0) ** 2 / self.a
+        partner = np.minimum((up * ns).astype(np.int32), ns - 1)
+        with np.errstate(divide='ignore'):
+            logu = np.log(ua)
+        zfac = (self.ndim - 1.0) * np.log(zz)
+        return partner, zz, zfac, logu
 
     def _stretch_step(self, coords, logp):
         nw, nd = self.nwalkers, self.ndim
         accepted = np.zeros(nw, dtype=bool)
-        for s_idx, c_idx, zz, partner_idx, logu in self._draw_step():
+        sidx, cidx, part, zz_, zfac_, logu_ = self._draw_steps(1)
+        for k in (0, 1):
+            s_idx, c_idx, zz, partner_idx, logu, zfac = sidx[0, k], cidx[0, k], zz_[0, k], part[0, k], logu_[0, k], zfac_[0, k]
             s, c = coords[s_idx], coords[c_idx]
             partner = c[partner_idx]
             q = partner - (partner - s) * zz[:, None]
             new_lp = self.compute_log_prob(q)
             with np.errstate(invalid='ignore'):  # -inf - -inf = nan -> compares False -> rejected
-                lnpdiff = (nd - 1.0) * np.log(zz) + new_lp - logp[s_idx]
+                lnpdiff = zfac + new_lp - logp[s_idx]
             acc = logu < lnpdiff
             coords[s_idx[acc]] = q[acc]
             logp[s_idx[acc]] = new_lp[acc]
@@ -208,43 +229,57 @@ class DeviceEnsembleSampler(EnsembleSampler):
         logp = np.ascontiguousarray(logp)
         nd, ns = self.ndim, self.nwalkers // 2
 
-        def draw_chunk(m):
-            sidx = np.empty((m, 2, ns), dtype=np.int32)
-            cidx = np.empty((m, 2, ns), dtype=np.int32)
-            partner = np.empty((m, 2, ns), dtype=np.int32)
-            zz, zfac, logu = np.empty((m, 2, ns)), np.empty((m, 2, ns)), np.empty((m, 2, ns))
-            for i in range(m):
-                for k, (s_i, c_i, z, p_i, lu) in enumerate(self._draw_step()):
-                    sidx[i, k], cidx[i, k], partner[i, k] = s_i, c_i, p_i
-                    zz[i, k], zfac[i, k], logu[i, k] = z, (nd - 1.0) * np.log(z), lu
-            return sidx, cidx, partner, zz, zfac, logu
-
-        # the randomness of chunk i+1 is drawn (in stream order, by one worker thread) while the GPU runs
-        # chunk i: the ctypes call releases the GIL for the whole chunk
+        # Pipeline: the randomness of chunk i+1 is drawn (two streams, one thread each; NumPy's generators and
+        # the ctypes calls release the GIL) and QUEUED on the GPU while chunk i runs; chunk i is collected only
+        # after chunk i+1 has been queued, so the GPU never waits for the host between chunks.  Chunk sizes ramp
+        # up from 8 so the first launch does not wait for a whole chunk of randomness.
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+
+        def submit(pool, m):
+            return (pool.submit(self._draw_split, m), pool.submit(self._draw_moves, m)) if m > 0 else None
+
+        def next_size(prev, left):
+            return min(left, self.chunk, max(8, 2 * prev))
+
+        ctx = self.engine.ctx
         left = int(iterations)
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            m = min(left, self.chunk)
-            fut = pool.submit(draw_chunk, m) if m > 0 else None
-            while left > 0:
-                sidx, cidx, partner, zz, zfac, logu = fut.result()
-                left -= m
-                m_next = min(left, self.chunk)
-                fut = pool.submit(draw_chunk, m_next) if m_next > 0 else None
-                before = self._accepted.copy()
-                chain, lpc, nacc, worst = self.engine.ctx.sampler_run(self._mode, coords, logp, sidx, cidx, partner, zz,
-                                                                      zfac, logu)
-                if worst:
-                    _raise_for_status(np.array([worst]), coords[:1])
-                self._accepted = before + nacc
-                for i in range(m):
-                    self.iteration += 1
-                    if store:
-                        self._chain.append(chain[i])
-                        self._logp.append(lpc[i])
-                    self._last = State(chain[i], lpc[i])
-                    yield self._last
-                m = m_next
+        if left <= 0:
+            return
+        base_acc = self._accepted.copy()
+        ctx.sampler_begin(self._mode, coords, logp, self.chunk)
+        try:
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                queued = deque()
+                m = next_size(4, left)
+                fut = submit(pool, m)
+                slot = 0
+                while left > 0 or queued:
+                    if left > 0:
+                        arrays = [x for f in fut for x in f.result()]
+                        left -= m
+                        m_next = next_size(m, left) if left > 0 else 0
+                        fut = submit(pool, m_next)
+                        ctx.sampler_enqueue(slot, *arrays)
+                        queued.append((slot, m))
+                        slot ^= 1
+                        m = m_next
+                        if len(queued) < 2 and left > 0:
+                            continue  # keep two chunks in flight
+                    sl, mm = queued.popleft()
+                    chain, lpc, nacc, worst = ctx.sampler_collect(sl, mm)
+                    if worst:
+                        _raise_for_status(np.array([worst]), chain[-1][:1])
+                    self._accepted = base_acc + nacc
+                    for i in range(mm):
+                        self.iteration += 1
+                        if store:
+                            self._chain.append(chain[i])
+                            self._logp.append(lpc[i])
+                        self._last = State(chain[i], lpc[i])
+                        yield self._last
+        finally:
+            ctx.sampler_end()
 
     @property
     def acceptance_fraction(self):

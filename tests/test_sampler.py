@@ -70,3 +70,21 @@ def test_reference_driver_protocol_writes_the_reference_files(tmp_path):
     assert (tmp_path / 'samples.txt').exists() and (tmp_path / 't_0_burnin.txt').exists()
     assert (tmp_path / 't_20_burnin.txt').exists() and (tmp_path / 't_0_results.txt').exists()
     assert np.loadtxt(tmp_path / 'samples.txt').shape == samples.shape
+
+
+def test_randomness_is_independent_of_chunking():
+    """The device-resident loop draws a whole chunk of iterations per call, the host loop one: both must see the
+    same numbers (two streams, each consumed row by row), or the chains would differ."""
+    f = lambda x: -0.5 * np.sum(x * x, axis=1)  # noqa: E731
+    a = EnsembleSampler(64, 6, f, vectorize=True, seed=5)
+    b = EnsembleSampler(64, 6, f, vectorize=True, seed=5)
+    one = [a._draw_steps(1) for _ in range(10)]
+    many = [b._draw_steps(7), b._draw_steps(3)]
+    for j in range(6):
+        x = np.concatenate([t[j] for t in one])
+        y = np.concatenate([t[j] for t in many])
+        assert x.dtype == y.dtype and x.shape == (10, 2, 32) and np.array_equal(x, y)
+    sidx, cidx, partner, zz, zfac, logu = one[0]
+    assert sorted(np.concatenate([sidx[0, 0], sidx[0, 1]]).tolist()) == list(range(64))   # a true split
+    assert np.array_equal(cidx[0, 0], sidx[0, 1]) and np.array_equal(cidx[0, 1], sidx[0, 0])
+    assert partner.min() >= 0 and partner.max() < 32 and zz.min() >= 0.5 and zz.max() <= 2.0

@@ -28,12 +28,13 @@ def main():
         th = time.perf_counter() - t0
         dev = DeviceEnsembleSampler(nw, 6, eng, seed=1, chunk=100)
         dev.run_mcmc(p0, 5)
+        dsteps = 1000
         t0 = time.perf_counter()
-        dev.run_mcmc(p0, steps)
+        dev.run_mcmc(p0, dsteps, store=False)
         td = time.perf_counter() - t0
         print(json.dumps(dict(walkers=nw, steps=steps, host_loop_us_per_step=th / steps * 1e6,
-                              device_us_per_step=td / steps * 1e6, host_evals_per_s=nw * steps / th,
-                              device_evals_per_s=nw * steps / td,
+                              device_us_per_step=td / dsteps * 1e6, device_steps=dsteps, host_evals_per_s=nw * steps / th,
+                              device_evals_per_s=nw * dsteps / td,
                               acceptance=float(dev.acceptance_fraction.mean()))), flush=True)
 
 
