@@ -486,6 +486,56 @@ def test_device_resident_sampler_walks_the_same_chain_as_the_host_loop():
     assert np.all(np.isfinite(st.log_prob)) and flat[:, 1].min() >= 3000.0 and flat[:, 2].min() >= 0.0
 
 
+def test_pipelined_sampler_entry_points_guard_their_arguments():
+    """msx_sampler_begin/_enqueue/_collect/_end: indices that would be dereferenced on the device are range-checked
+    on the host, slots cannot be overwritten or collected twice, and a run continued from a State is the same
+    chain as an uninterrupted one."""
+    from mcmc_spec_amd import _lib
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    c = golden_case('B')
+    eng = make_engine(c, rad_prior=False)
+    rng = np.random.default_rng(4)
+    nw = 32
+    p0 = c.theta[0] + rng.normal(size=(nw, 6)) * np.array([30, 30, 0.02, 0.02, 0.02, 2e-5])
+    a = DeviceEnsembleSampler(nw, 6, eng, seed=2, chunk=16)
+    a.run_mcmc(p0, 30)
+    b = DeviceEnsembleSampler(nw, 6, eng, seed=2, chunk=16)
+    st = b.run_mcmc(p0, 12)
+    b.run_mcmc(st, 18)
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(a.acceptance_fraction, b.acceptance_fraction)
+
+    ctx = eng.ctx
+    lp = eng.logposterior(p0)
+    draws = list(a._draw_steps(3))
+    with pytest.raises(RuntimeError, match='msx_sampler_begin first'):
+        ctx._smp_shape = (nw, 6)
+        ctx.sampler_enqueue(0, *draws)
+    ctx.sampler_begin(_lib.MODE_LOGPOST, p0, lp, 4)
+    try:
+        bad = [x.copy() for x in draws]
+        bad[2][1, 0, 3] = nw // 2          # partner index one past the half
+        with pytest.raises(RuntimeError, match='out of range'):
+            ctx.sampler_enqueue(0, *bad)
+        bad = [x.copy() for x in draws]
+        bad[0][0, 1, 0] = -1               # active walker index
+        with pytest.raises(RuntimeError, match='out of range'):
+            ctx.sampler_enqueue(0, *bad)
+        with pytest.raises(RuntimeError, match='bad arguments'):
+            ctx.sampler_enqueue(0, *a._draw_steps(5))   # more steps than the slots were sized for
+        with pytest.raises(RuntimeError, match='nothing enqueued'):
+            ctx.sampler_collect(0, 3)
+        ctx.sampler_enqueue(0, *draws)
+        with pytest.raises(RuntimeError, match='not collected'):
+            ctx.sampler_enqueue(0, *draws)
+        chain, lpc, nacc, worst = ctx.sampler_collect(0, 3)
+        assert worst == 0 and chain.shape == (3, nw, 6) and np.all(nacc <= 3) and nacc.sum() > 0
+        coords, logp = ctx.sampler_end(want_state=True)
+        assert np.array_equal(coords, chain[-1]) and np.array_equal(logp, lpc[-1])
+        assert np.array_equal(eng.logposterior(coords), logp)   # the resident log-probs are those of the coords
+    finally:
+        ctx.sampler_end()                   # idempotent
+
+
 def test_end_to_end_fit_recovers_the_truth(tmp_path, monkeypatch):
     """examples/fit_synthetic.py: loader -> optimiser -> device-resident sampler -> samples.txt, like the
     reference's main() minus plotting.  The posterior median must land on the injected parameters."""
