@@ -1156,7 +1156,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // VGPRs (the two-pixels-per-trip body wants ~146: no spills, 3 waves per SIMD); the 1024-thread variants
 // are capped at 128 VGPRs by the hardware and use one pixel per trip.
 // GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
-template <int NS, int U, int MAXT, bool GM = false, bool CP = false>
+// PF = while the recipe waves work, the idle waves copy three walker-independent pixel vectors (u, data flux,
+//      resample weight t) into LDS; phase A and the chi^2 pass then read them from LDS, which takes 160 of the
+//      786 KB a walker pulls through its CU's L2 port off the critical path (one workgroup per CU only: 4 npix
+//      doubles of LDS).
+template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false>
 __global__ void __launch_bounds__(MAXT, 1)
 logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
@@ -1168,6 +1172,9 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     const int tid = threadIdx.x, B = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = B >> 6;
     const int npix = (int)P.npix;
+    double *const lds_u = PF ? reinterpret_cast<double *>(dyn_lds) + npix : nullptr;
+    double *const lds_f = PF ? lds_u + npix : nullptr;
+    double *const lds_t = PF ? lds_f + npix : nullptr;
 
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
@@ -1189,6 +1196,15 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     // register-resident tables when they fit one wave (the usual case), else the generic walk
     const bool fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave &&
                       P.nav + 1 <= 2 * kWave;
+    if (PF && wave >= NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
+        const int nthr = B - NS * kWave, id = tid - NS * kWave;
+#pragma unroll 4
+        for (int p = id; p < npix; p += nthr) {
+            lds_u[p] = P.pix_u[p];
+            lds_f[p] = P.pix_flux[p];
+            lds_t[p] = P.pix_t[p];
+        }
+    }
     if (fast) {
         if (wave < NS) recipe_part1_regs<NS>(P, mode, theta + wk * ndim, D, lane, wk, wave);
     } else if (wave == 0) {
@@ -1278,9 +1294,9 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             kk[u] = redden ? P.pix_k[pp[u]] : make_double2(0.0, 0.0);
-            tt[u] = P.pix_t[pp[u]];
-            ff[u] = P.pix_flux[pp[u]];
-            uu[u] = P.pix_u[pp[u]];
+            tt[u] = PF ? lds_t[pp[u]] : P.pix_t[pp[u]];
+            ff[u] = PF ? lds_f[pp[u]] : P.pix_flux[pp[u]];
+            uu[u] = PF ? lds_u[pp[u]] : P.pix_u[pp[u]];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1386,7 +1402,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
             if ((threadIdx.x & 63) == 0) S.chi[threadIdx.x >> 6] = r;
         }
     };
-    ChiElem chi_elem{P.pix_u, P.pix_flux, P.pix_ivar, P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
+    ChiElem chi_elem{PF ? lds_u : P.pix_u, PF ? lds_f : P.pix_flux, P.pix_ivar, P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
                      P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], 0.0, fused};
     bool chi_done = false;
@@ -1713,6 +1729,8 @@ struct msx_ctx {
     int32_t *d_opt_chain = nullptr;
     int64_t opt_chains = 0, cap_chain = 0;
     int max_dyn_lds = 0;
+    bool pf_ok = false;   // the LDS-staged-statics variants fit (msx_stage_problem)
+    bool use_pf = true;   // MSX_NO_PF=1 in the environment turns them off (A/B measurements)
     bool model_in_global = false;
     // RCCL all-gather of log-probabilities: communicator + its own stream + per-slot events
     void *rccl_comm = nullptr;
@@ -1866,6 +1884,7 @@ int msx_create(int device, msx_ctx **out) {
     msx_ctx *c = new msx_ctx();
     c->device = device;
     memset(&c->P, 0, sizeof(c->P));
+    if (const char *e = getenv("MSX_NO_PF")) c->use_pf = !(e[0] == '1');
     *out = c;  // returned even on failure so the caller can read msx_last_error
     HIP_TRY(c, hipSetDevice(device));
     HIP_TRY(c, hipGetDeviceProperties(&c->prop, device));
@@ -2169,6 +2188,13 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         for (const void *k : variants)
             HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_lds));
     }
+    c->pf_ok = !model_in_global && 4 * need_lds <= 148 * 1024;  // + ~9 KB static scratch <= 160 KB
+    if (c->pf_ok) {
+        const void *variants[] = {(const void *)logprob_kernel<2, 2, 512, false, false, true>,
+                                  (const void *)logprob_kernel<3, 1, 512, false, false, true>};
+        for (const void *k : variants)
+            HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * need_lds)));
+    }
 #ifdef MSX_STAMPS
     {   // diagnostic build only: per-walker shader-clock stamps
         unsigned long long *st = nullptr;
@@ -2235,14 +2261,20 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         return MSX_OK;
     }
     const dim3 g((unsigned)n), b((unsigned)B);
+    // pixel statics staged in LDS by the idle waves: 512-thread workgroups that own their CU (one per CU anyway)
+    // and whose 4 npix doubles fit beside the scratch
+    const bool pf = B == 512 && n <= c->prop.multiProcessorCount && !c->P.pairs_c && c->pf_ok && c->use_pf;
     if (c->P.nspec == 2) {
-        if (B <= 512 && c->P.pairs_c)
+        if (pf)
+            hipLaunchKernelGGL((logprob_kernel<2, 2, 512, false, false, true>), g, b, 4 * lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        else if (B <= 512 && c->P.pairs_c)
             hipLaunchKernelGGL((logprob_kernel<2, 2, 512, false, true>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
         else if (B <= 512)
             hipLaunchKernelGGL((logprob_kernel<2, 2, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
         else hipLaunchKernelGGL((logprob_kernel<2, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
     } else {
-        if (B <= 512) hipLaunchKernelGGL((logprob_kernel<3, 1, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        if (pf) hipLaunchKernelGGL((logprob_kernel<3, 1, 512, false, false, true>), g, b, 4 * lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        else if (B <= 512) hipLaunchKernelGGL((logprob_kernel<3, 1, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
         else hipLaunchKernelGGL((logprob_kernel<3, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
     }
     HIP_TRY(c, hipGetLastError());
