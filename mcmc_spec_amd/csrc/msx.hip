@@ -828,14 +828,15 @@ __device__ __forceinline__ void recipe_band_terms(const DevProblem &P, int mode,
 // block scratch.  Every reduction site has its own slots so that one barrier per reduction suffices
 // (fixed order everywhere: lanes via shuffles, then waves 0..nw-1 serially -> deterministic).
 // ------------------------------------------------------------------------------------------------
-constexpr int kBins = 1024;  // linear value bins of the median select
+constexpr int kBins = 1024;     // linear value bins of the median select
+constexpr int kLogBins = 2048;  // logarithmic bins of the early-histogram median (3 exponent + 8 mantissa bits)
 struct alignas(16) BlockScratch {
     double q[3][kMaxWaves];
     unsigned long long kmin[kMaxWaves], kmax[kMaxWaves];
     unsigned long long above[kMaxWaves];
     double chi[kMaxWaves];
     unsigned int wave_tot[kMaxWaves];
-    unsigned int hist[kBins];
+    unsigned int hist[kLogBins];  // block_median and radix_select use the first kBins / 256
     unsigned long long cand[kSelectFinish];
     unsigned long long sel_result[2];
     unsigned int sel_bin, sel_k, sel_cnt, cand_n, has_second;
@@ -1115,6 +1116,146 @@ __device__ __forceinline__ double block_median(const double *model, int npix, un
     return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same exact median when the histogram was filled DURING phase A.  That needs a bin map that does not
+// depend on the vector's min / max: for positive finite doubles the low 3 exponent bits and the top 8
+// mantissa bits (256 logarithmic sub-bins per binade, cyclic in the exponent).  The map is monotone along the
+// cycle starting at min's bin as long as the vector spans < 8 binades, which is checked here from min / max
+// (anything else -- zeros, negatives, infinities, huge ranges -- returns false and the caller takes
+// block_median).  On entry: S.hist complete (a barrier has passed), S.cand_n == 0, S.has_second == 0.
+//   every wave scans the 2048 counters itself (no publish, no barrier) -> ONE pass over the vector does the
+//   chi^2 terms (elem) and gathers the median bin's candidates -> barrier -> wave 0 ranks the candidates in
+//   registers.  The result is valid in wave 0 only (its lane 0 finishes the walker): no closing barrier.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int logbin(double x) {
+    return ((unsigned int)__double2hiint(x) >> 12) & (unsigned int)(kLogBins - 1);
+}
+
+template <class Elem>
+__device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
+                                              BlockScratch &S, Elem &elem, double *med_out) {
+    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
+    const bool need_two = (npix & 1) == 0;
+    if (!(kmin > key_of(0.0)) || kmin == kmax) return false;
+    const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
+    const unsigned int hmax = (unsigned int)__double2hiint(val_of(kmax)) >> 12;
+    constexpr int per = kLogBins / kWave;  // counters per lane in the scan
+    // scan origin: min's bin rounded down to a lane's group, so no group straddles the end of the array
+    const unsigned int a = (hmin & (unsigned int)(kLogBins - 1)) & ~(unsigned int)(per - 1);
+    if ((hmax - hmin) + (hmin & (unsigned int)(per - 1)) >= (unsigned int)kLogBins) return false;  // the cycle would lap itself
+    MED_STAMP(0);
+    MED_STAMP(1);
+    // ---- per-wave scan: lane l owns the `per` counters from physical bin (a + per*l) mod kLogBins ----------
+    const unsigned int phys = (a + (unsigned int)(per * lane)) & (unsigned int)(kLogBins - 1);
+    unsigned int own = 0;
+    {
+        const uint4 *h4 = reinterpret_cast<const uint4 *>(&S.hist[phys]);
+#pragma unroll
+        for (int i = 0; i < per / 4; ++i) {
+            const uint4 h = h4[i];
+            own += h.x + h.y + h.z + h.w;
+        }
+    }
+    const unsigned int inc = wave_scan_u32(own);
+    const unsigned int excl = inc - own;
+    const bool mine_it = own > 0 && excl <= k1 && k1 < excl + own;      // exactly one lane (total = npix > k1)
+    const int L = uni(__ffsll((long long)__ballot(mine_it)) - 1);
+    // second level, again on the whole wave: lane j < per takes counter j of lane L's group
+    const unsigned int phys_l = (unsigned int)__builtin_amdgcn_readlane((int)phys, L);
+    const unsigned int t = k1 - (unsigned int)__builtin_amdgcn_readlane((int)excl, L);
+    const unsigned int c = lane < per ? S.hist[phys_l + lane] : 0u;
+    const unsigned int inc2 = wave_scan_u32(c);
+    const int J = uni(__ffsll((long long)__ballot(c > 0 && inc2 - c <= t && t < inc2)) - 1);
+    const unsigned int kk = t - (unsigned int)__builtin_amdgcn_readlane((int)(inc2 - c), J);
+    const unsigned int cnt = (unsigned int)__builtin_amdgcn_readlane((int)c, J);
+    const unsigned int lsel = (phys_l + (unsigned int)J - a) & (unsigned int)(kLogBins - 1);
+    if (cnt > (unsigned int)kSelectFinish) return false;  // heavy duplication: the general path sorts it out
+    MED_STAMP(2);
+    // ---- one pass: chi^2 terms + candidates of the median's bin + smallest key of the later bins -----------
+    unsigned long long above = ~0ull;
+    for (int base = 0; base < npix; base += 4 * B) {
+        int pp[4];
+        double xv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + u * B + tid;
+            ok[u] = p < npix;
+            pp[u] = ok[u] ? p : npix - 1;
+            xv[u] = model[pp[u]];
+        }
+        elem.process4(pp, xv, ok);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int lx = (logbin(xv[u]) - a) & (unsigned int)(kLogBins - 1);
+            const unsigned long long key = key_of(xv[u]);
+            if (ok[u] && lx == lsel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+            else if (ok[u] && lx > lsel && key < above) above = key;
+        }
+    }
+    elem.flush(S);
+    above = wave_min_u64(above);
+    if (lane == 0) S.above[wave] = above;
+    __syncthreads();
+    MED_STAMP(3);
+    // ---- rank.  Up to 64 candidates (the usual case): wave 0 alone, in registers, and only wave 0 (whose lane 0
+    // finishes the walker) learns the median -- no further barrier.  More: the first waves through LDS.
+    unsigned long long v1 = 0, v2 = 0;
+    bool second = false;
+    if (cnt <= (unsigned int)kWave) {
+        if (wave == 0) {
+            // one candidate per lane; the others arrive as LDS broadcast reads, eight per trip.  Counting the keys
+            // below and not above a candidate pins its VALUE's rank interval [lt, le), which is all the median needs
+            // (duplicates share a value), so no tie-break by slot.  Pad slots hold ~0 and rank last.
+            if (lane < 8) S.cand[cnt + lane] = ~0ull;   // same wave: LDS operations execute in order
+            const unsigned long long mine = S.cand[lane < (int)cnt ? lane : (int)cnt];
+            unsigned int lt = 0, le = 0;
+            const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(S.cand);
+            for (int j = 0; j < (int)cnt; j += 8) {
+                ulonglong2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = c2[(j >> 1) + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lt += (x[u].x < mine) + (x[u].y < mine);
+                    le += (x[u].x <= mine) + (x[u].y <= mine);
+                }
+            }
+            const unsigned long long b1 = __ballot(lane < (int)cnt && lt <= kk && kk < le);
+            const unsigned long long b2 = __ballot(lane < (int)cnt && lt <= kk + 1 && kk + 1 < le);
+            v1 = readlane_u64(mine, uni(__ffsll((long long)b1) - 1));
+            second = b2 != 0ull;
+            if (second) v2 = readlane_u64(mine, uni(__ffsll((long long)b2) - 1));
+        }
+    } else {
+        if (tid < (int)cnt) {
+            const unsigned long long mine = S.cand[tid];
+            unsigned int r = 0;
+            for (unsigned int j = 0; j < cnt; ++j) {
+                const unsigned long long o = S.cand[j];
+                r += (o < mine) || (o == mine && j < (unsigned int)tid);
+            }
+            if (r == kk) S.sel_result[0] = mine;
+            if (r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
+        }
+        __syncthreads();
+        v1 = S.sel_result[0];
+        second = S.has_second != 0;
+        if (second) v2 = S.sel_result[1];
+    }
+    MED_STAMP(4);
+#ifdef MSX_STAMPS
+    if (tid == 0) g_med_stamps[blockIdx.x * 8 + 6] = cnt;
+#endif
+    if (!second) {
+        v2 = S.above[0];
+        for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+    }
+    *med_out = need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+    return true;
+}
+
 // Last lines of a walker (one lane): publish the value and, for the device-resident sampler, apply the
 // stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
 // like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
@@ -1192,12 +1333,21 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         __syncthreads();  // same-workgroup global hand-off: stores drained + barrier, then plain loads
         theta = P.smp_q;
     }
-    for (int i = tid; i < kBins; i += B) S.hist[i] = 0;
+    for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
+    if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
     // register-resident tables when they fit one wave (the usual case), else the generic walk
     const bool fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave &&
                       P.nav + 1 <= 2 * kWave;
-    if (PF && wave >= NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
-        const int nthr = B - NS * kWave, id = tid - NS * kWave;
+    // Early-histogram path (logbin_median): the median's histogram is filled while phase A computes the model,
+    // and the walker's prior terms move to an idle wave of phase 0.  Likelihood / posterior / chi^2 modes with
+    // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
+    const bool early = !GM && fast && !P.no_spectrum &&
+                       (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
+    // mode (rejected walkers never read them)
+    if (fast && wave == NS) recipe_prior_terms<NS>(P, mode, theta + wk * ndim, D, lane);
+    if (PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
+        const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
 #pragma unroll 4
         for (int p = id; p < npix; p += nthr) {
             lds_u[p] = P.pix_u[p];
@@ -1225,13 +1375,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         return;
     }
     if (mode == MSX_MODE_LOGPRIOR) {  // logprior alone (mft6.py:1207-1272): no spectrum pass
-        if (wave == 0) {
-            if (fast) {
-                if (lane == 0) D.status = MSX_W_OK;
-                recipe_prior_terms<NS>(P, mode, theta + wk * ndim, D, lane);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+        if (wave == 0) {  // (fast recipe: wave NS left D.lp / D.status before the barrier above)
             if (lane == 0) {
                 logp[wk] = (D.status == MSX_W_OK) ? D.lp : NAN;
                 status[wk] = D.status;
@@ -1242,10 +1386,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     if (P.no_spectrum) {
         // the mft6_nospec.py variant (mft6_nospec.py:1163-1196): the spectrum term is commented out there and
         // the total is contrast + photometry chi^2 only -- no spectral phases at all
-        if (fast) {
-            if (wave == 1) recipe_prior_terms<NS>(P, mode, theta + wk * ndim, D, lane);
-            else if (wave == 2) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
-        }
+        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
         __syncthreads();
         if (tid == 0) {
             const double total = D.chi_extra;
@@ -1328,10 +1469,15 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                 const unsigned long long key = key_of(m);
                 kmin = key < kmin ? key : kmin;
                 kmax = key > kmax ? key : kmax;
+                if (early) atomicAdd(&S.hist[logbin(m)], 1u);
             }
         }
     }
     MSX_STAMP(P, wk, 2);
+    // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
+    // bound by the CU's L2 port and wave 0's loads are served first, so wave 0 leaves the pixel loop thousands of
+    // cycles before the last wave: it computes the terms in that wait.  (Other modes: inside block_median.)
+    if (early && wave == 0) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
     {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -1365,13 +1511,10 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     }
 
     // ---- phase B: exact median (np.median, mft6.py:1173) -----------------------------------------------
-    // waves 1 and 2 compute the prior / band terms inside the median's scan stage (fast recipe only)
+    // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
     const double *th_w = theta + wk * ndim;
-    auto side = [&]() {
-        if (fast) {
-            if (wave == 1) recipe_prior_terms<NS>(P, mode, th_w, D, lane);
-            else if (wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
-        }
+    auto side = [&]() __attribute__((always_inline)) {
+        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
     };
     // The spectrum chi^2 factorises: with P(u) = c0 + c1 u + c2 u^2 the raw fit of data/model (from the q
     // sums), the fit of data/(scale*model) is P/scale, data' = scale*data/P and
@@ -1406,7 +1549,18 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
                      P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], 0.0, fused};
     bool chi_done = false;
-    const double med_model = block_median(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
+    double med_model = 0.0;
+    bool solved = false;
+    if (early) {
+        solved = logbin_median(model, npix, kmin, kmax, S, chi_elem, &med_model);
+        chi_done = solved;
+        if (!solved) {  // not a positive vector spanning < 8 binades, or > 256 equal-bin candidates: start over
+            __syncthreads();  // every wave decided from the counters by itself: none may still be reading them
+            for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
+            __syncthreads();
+        }
+    }
+    if (!solved) med_model = block_median(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
     if (fused && !chi_done) {  // degenerate vectors (all equal): the median took no pass, do it here
         for (int base = 0; base < npix; base += 4 * B) {
             int pp[4];

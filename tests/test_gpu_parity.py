@@ -205,6 +205,63 @@ def test_median_radix_fallback_on_heavily_duplicated_values():
         assert rel_err(got, want).max() < TIGHT, npix
 
 
+@pytest.mark.parametrize('shape', ['two_clusters', 'wide_range', 'plateau_at_median', 'flat'])
+def test_early_histogram_median_branches(shape):
+    """The median whose histogram is filled during phase A (logbin_median) and its exits: the upper middle value
+    in a LATER bin than the lower one (two clusters, even count), a vector spanning more than 8 binades (falls
+    back to the min/max-binned select), 65..256 equal candidates in the median's bin (ranked through LDS), and a
+    constant vector (min == max).  All against the oracle, even and odd pixel counts."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import synth
+    from oracle import mft6_oracle as orc
+    teffs = np.arange(3000, 3500, 100)
+    loggs = np.array([4.5, 5.0, 5.5])
+    wl = np.arange(5400, 9100, 0.2)
+    x = (wl - 5600.0) / (8800.0 - 5600.0)          # 0..1 across the data window
+    if shape == 'two_clusters':
+        base = np.where(x < 0.5, 1.0e5 * (1 + 1e-3 * x), 2.0e5 * (1 + 1e-3 * x))
+    elif shape == 'wide_range':
+        base = 1.0e5 * 10.0 ** (4.0 * np.clip(x, 0, 1))
+    elif shape == 'plateau_at_median':
+        base = 1.0e5 * (1 + 0.5 * np.where(np.abs(x - 0.5) < 0.035, 0.5, x))   # ~7 % of the pixels share one value
+    else:
+        base = np.full_like(wl, 1.0e5)
+    flux = np.empty((len(teffs), len(loggs), len(wl)))
+    for i in range(len(teffs)):
+        for j in range(len(loggs)):
+            flux[i, j] = base * (1 + 0.01 * i + 0.02 * j)
+    specs = synth.grid_to_specs(teffs, loggs, wl, flux)
+    matrix = synth.make_isochrone_matrix()
+    ctm = [[list(np.linspace(6000, 8800, 40))], [list(np.ones(40))], [0], [7400.0]]
+    ptm = [[], [], [], []]
+    fr = [[1.0], [0.1], ['x'], [], [], []]
+    for npix in (2048, 2047, 300):
+        wl_um = np.linspace(0.56, 0.88, npix)
+        rng = np.random.default_rng(4)
+        data = [wl_um, 1 + 0.05 * rng.normal(size=npix)]
+        err = np.full(npix, 0.05)
+        r = [wl_um.min(), wl_um.max()]
+        eng = Engine(0)
+        eng.stage_specs(specs)
+        eng.stage_problem(data, err, fr, r, ctm, ptm, 6000.0, 8800.0, matrix, nspec=2)
+        th = np.array([[3250.0, 3120.0, 0.0, 0.5, 0.4, 2e-3], [3300.0, 3049.0, 0.0, 0.7, 0.9, 3e-3],
+                       [3250.0, 3120.0, 0.3, 0.5, 0.4, 2e-3]])
+        want = np.array([orc.loglikelihood(list(t), fr, 2, data, err, r, specs, ctm, ptm, 6000.0, 8800.0, matrix)
+                         for t in th])
+        import torch
+        from mcmc_spec_amd import _lib
+        dev = torch.device('cuda', 0)
+        tht = torch.from_numpy(np.ascontiguousarray(th)).to(dev)
+        for block in (0, 256, 1024):   # auto = 512 threads with LDS-staged statics; 256 and 1024 without
+            lp = torch.empty(len(th), dtype=torch.float64, device=dev)
+            st = torch.empty(len(th), dtype=torch.int32, device=dev)
+            eng.ctx.logprob_batch_dev(tht.data_ptr(), len(th), 6, lp.data_ptr(), st.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream, _lib.MODE_LOGLIKE, block)
+            torch.cuda.synchronize()
+            assert int(st.abs().sum()) == 0
+            assert rel_err(lp.cpu().numpy(), want).max() < TIGHT, (shape, npix, block)
+
+
 @pytest.mark.parametrize('block', [256, 512, 1024])
 def test_every_workgroup_size_gives_identical_bits(block, engB):
     import torch
