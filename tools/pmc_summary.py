@@ -40,9 +40,13 @@ def main():
     ap.add_argument('--kernel', default='logprob_kernel')
     ap.add_argument('--out', required=True)
     ap.add_argument('--note', default='')
+    ap.add_argument('--walkers', type=int, default=256)
+    ap.add_argument('--npix', type=int, default=4096)
+    ap.add_argument('--phot', type=int, default=0)
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
-    summary = {'kernel': a.kernel, 'note': a.note}
+    summary = {'kernel': a.kernel, 'note': a.note,
+               'config': {'walkers': a.walkers, 'npix': a.npix, 'phot': bool(a.phot)}}  # bench.py matches on this
     if a.kt:
         ks = find(a.kt, '_kernel_stats.csv')
         shutil.copy(ks, a.out + '_kernel_stats.csv')
