@@ -386,7 +386,8 @@ def main():
                            chunk, args.steps // chunk, args.steps - args.steps // chunk * chunk)
                            if graph is not None else 'eager')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'logprob_kernel<2,2>',
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'logprob_kernel<NS=2,U=2,512 threads,PF>' if not block else 'logprob_kernel<NS=2>, %d threads' % block,
                          'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples, 'algorithmic_bytes_per_launch': n * b_alg,
                          'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
                          'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
