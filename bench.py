@@ -288,7 +288,8 @@ def main():
         try:
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev)):
+            # thread_local: calls made by other threads (c10d's watchdog) must not invalidate the capture
+            with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev), capture_error_mode='thread_local'):
                 tab = calls_for(torch.cuda.current_stream(dev).cuda_stream)
                 for i in range(chunk):
                     reuse_guard(i)
