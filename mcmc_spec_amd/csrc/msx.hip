@@ -1302,7 +1302,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //      786 KB a walker pulls through its CU's L2 port off the critical path (one workgroup per CU only: 4 npix
 //      doubles of LDS).
 template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false>
-__global__ void __launch_bounds__(MAXT, 1)
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && U == 1) ? 2 : 1)
 logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                double *__restrict__ logp, int32_t *__restrict__ status) {
     __shared__ WalkerDesc D;
@@ -1310,8 +1310,10 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     const int64_t wk = blockIdx.x;
     if (wk >= n) return;
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
-    const int tid = threadIdx.x, B = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    const int tid = threadIdx.x;
+    constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int nw = B >> 6;
     const int npix = (int)P.npix;
     double *const lds_u = PF ? reinterpret_cast<double *>(dyn_lds) + npix : nullptr;
     double *const lds_f = PF ? lds_u + npix : nullptr;
@@ -1411,9 +1413,26 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     }
     const double redc = D.redc;
     const bool redden = redc != 0.0;
-    double q[3] = {0.0, 0.0, 0.0};
+    // Sums are taken in an order that does not depend on the workgroup size: pixel p belongs to row p / B of the
+    // launch, i.e. to 64-pixel chunk c = p / 64, and chunk c is owned by VIRTUAL wave c mod 16.  A real wave of a
+    // 4- or 8-wave workgroup plays 4 or 2 virtual waves (its rows alternate between them), each with its own
+    // accumulator; every virtual wave sees its chunks in ascending order, lanes are reduced by the same DPP tree
+    // and the 16 partials are added serially -- the same association for 256, 512 and 1024 threads, so a
+    // walker's log-probability has the same bits whatever launch (batch size, shard, rank) evaluates it.
+    // (every variant is launched with exactly MAXT threads, so the count is a compile-time constant)
+    constexpr int vk = kMaxWaves / (MAXT / kWave);  // virtual waves per real wave: 4, 2 or 1
+    double qa[vk][3];
+#pragma unroll
+    for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
+    double q[3];
     unsigned long long kmin = ~0ull, kmax = 0ull;
-    for (int base = 0; base < npix; base += B * U) {
+    // rows are taken vk at a time (SUB sub-trips of U rows) so that every row's virtual-wave slot is static
+    constexpr int SUB = (vk > U) ? vk / U : 1;
+    for (int base0 = 0; base0 < npix; base0 += B * U * SUB) {
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int base = base0 + sub * B * U;
+        if (base >= npix) break;
         double2 v[U][NS * 4];
         double2 kk[U];
         double tt[U], ff[U], uu[U];
@@ -1463,15 +1482,18 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
             if (base + u * B + tid < npix) {
                 model[pp[u]] = m;
                 const double f = ff[u] / m;  // frac before the median scale, mft6.py:194
-                q[0] += f;
-                q[1] += f * uu[u];
-                q[2] += f * (uu[u] * uu[u]);
+                const double f1 = f * uu[u], f2 = f * (uu[u] * uu[u]);
+                const int slot = (sub * U + u) & (vk - 1);  // static: sub and u are unrolled
+#pragma unroll
+                for (int k = 0; k < vk; ++k)
+                    if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2; }
                 const unsigned long long key = key_of(m);
                 kmin = key < kmin ? key : kmin;
                 kmax = key > kmax ? key : kmax;
                 if (early) atomicAdd(&S.hist[logbin(m)], 1u);
             }
         }
+      }
     }
     MSX_STAMP(P, wk, 2);
     // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
@@ -1480,9 +1502,12 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     if (early && wave == 0) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
     {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double r = wave_sum(q[i]);
-            if (lane == 0) S.q[i][wave] = r;
+        for (int k = 0; k < vk; ++k) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r = wave_sum(qa[k][i]);
+                if (lane == 0) S.q[i][k * nw + wave] = r;  // virtual wave = row class * nw + wave
+            }
         }
         const unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
         if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
@@ -1490,7 +1515,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             double r = 0.0;
-            for (int x = 0; x < nw; ++x) r += S.q[i][x];
+            for (int x = 0; x < kMaxWaves; ++x) r += S.q[i][x];
             q[i] = r;
         }
         kmin = S.kmin[0]; kmax = S.kmax[0];
@@ -1523,9 +1548,12 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     // median's first pass over the model vector (fused modes only; the optimiser modes keep phase C).
     const bool fused = !(mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT);
     struct ChiElem {  // holds plain pointers, never a reference to the by-value kernel argument (see DevProblem)
+        enum { VK = kMaxWaves / (MAXT / kWave) };  // (a local class cannot have static data members)
         const double *pix_u, *pix_flux, *pix_ivar;
-        double c0, c1, c2, acc;
+        double c0, c1, c2;
+        double acc[VK];  // one per virtual wave this wave plays (see phase A): rows k, k + VK, ... of the pass
         bool on;
+        // four consecutive rows of the pass (row = p / blockDim.x; a trip starts at a multiple of four rows)
         __device__ __forceinline__ void process4(const int (&pp)[4], const double (&xv)[4], const bool (&ok)[4]) {
             if (!on) return;
             double u[4], f[4], e[4];
@@ -1535,19 +1563,22 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
             for (int k = 0; k < 4; ++k) {
                 const double poly = fma(fma(c2, u[k], c1), u[k], c0);
                 const double r = xv[k] - f[k] / poly;  // (model - data/P); mft6.py:196,120 up to scale^2
-                const double t = (r * r) * e[k];
-                acc += ok[k] ? t : 0.0;
+                acc[k & (VK - 1)] += ok[k] ? (r * r) * e[k] : 0.0;
             }
         }
         __device__ __forceinline__ void flush(BlockScratch &S) {
             if (!on) return;
-            const double r = wave_sum(acc);
-            if ((threadIdx.x & 63) == 0) S.chi[threadIdx.x >> 6] = r;
+#pragma unroll
+            for (int k = 0; k < VK; ++k) {
+                const double r = wave_sum(acc[k]);
+                if ((threadIdx.x & 63) == 0) S.chi[k * (MAXT / kWave) + (threadIdx.x >> 6)] = r;
+            }
         }
     };
-    ChiElem chi_elem{PF ? lds_u : P.pix_u, PF ? lds_f : P.pix_flux, P.pix_ivar, P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
+    ChiElem chi_elem{PF ? lds_u : P.pix_u, PF ? lds_f : P.pix_flux, P.pix_ivar,
+                     P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
-                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], 0.0, fused};
+                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused};
     bool chi_done = false;
     double med_model = 0.0;
     bool solved = false;
@@ -1595,9 +1626,11 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
-    double chi = 0.0;
+    double chia[vk];  // per virtual wave, like phase A
+#pragma unroll
+    for (int k = 0; k < vk; ++k) chia[k] = 0.0;
     unsigned long long dmin = ~0ull, dmax = 0ull;
-    for (int p = tid; p < npix && !fused; p += B) {
+    for (int p = tid, row = 0; p < npix && !fused; p += B, ++row) {
         const double ms = model[p] * scale;
         double dn;
         if (opt_step) {
@@ -1608,7 +1641,11 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
             dn = dflux[p] / poly;  // mft6.py:196
         }
         const double r = ms - dn;
-        chi += (r * r) * P.pix_ivar[p];  // mft6.py:120
+        const double t = (r * r) * P.pix_ivar[p];  // mft6.py:120
+        const int slot = row & (vk - 1);
+#pragma unroll
+        for (int k = 0; k < vk; ++k)
+            if (slot == k) chia[k] += t;
         if (opt_init) {
             P.opt_flux[wk * npix + p] = dn;
             model[p] = dn;  // the model value is dead now; reuse the LDS vector for median(data')
@@ -1619,8 +1656,11 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     }
     MSX_STAMP(P, wk, 6);
     if (!fused) {
-        chi = wave_sum(chi);
-        if (lane == 0) S.chi[wave] = chi;
+#pragma unroll
+        for (int k = 0; k < vk; ++k) {
+            const double r = wave_sum(chia[k]);
+            if (lane == 0) S.chi[k * nw + wave] = r;
+        }
     }
     if (opt_init) {
         const unsigned long long a = wave_min_u64(dmin), b = wave_max_u64(dmax);
@@ -1630,7 +1670,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     if (!fused) __syncthreads();  // (fused: S.chi was published before the median's first barrier)
     MSX_STAMP(P, wk, 7);
     double tot = 0.0;
-    for (int x = 0; x < nw; ++x) tot += S.chi[x];
+    for (int x = 0; x < kMaxWaves; ++x) tot += S.chi[x];
     if (fused) tot = tot * (scale * scale);
     if (opt_init) {
         dmin = S.kmin[0]; dmax = S.kmax[0];
@@ -2018,13 +2058,15 @@ int launch_conv(msx_ctx *c, const double *d_in, int64_t in_stride, double *d_tmp
 }
 
 int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
-    // few walkers or long spectra: spread one walker over 16 waves; many walkers: 4 waves each so
-    // several workgroups share a CU (LDS permitting).
+    // Long spectra: one walker over 16 waves.  Otherwise, measured at 4096 px (us, 256 / 512 / 1024 / 4096 /
+    // 16384 walkers):  512 threads, one workgroup per CU, two pixels per trip + LDS-staged statics   20 / -- ...
+    //                  512 threads, two workgroups per CU, one pixel per trip (<= 128 VGPRs)         -- / 31 / 55 / 179 / 668
+    //                  256 threads, three workgroups per CU                                          25 / 34 / 55 / 165 / 590
+    // The choice only affects speed: every variant sums in the same order (see phase A), so a walker's value
+    // has the same bits whichever one evaluates it.
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     if (npix >= 8192) return 1024;
-    // 512 threads when one workgroup per CU is all there is (22.1 us vs 24.4 at 256 walkers x 4096 px);
-    // beyond that 256-thread workgroups pack 3 per CU (146 VGPRs) and win (32 vs 40 us at 512 walkers)
-    if (n <= cus) return 512;
+    if (n <= 4 * cus) return 512;
     return 256;
 }
 
@@ -2336,9 +2378,13 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     c->max_dyn_lds = (int)need_lds;
     c->model_in_global = model_in_global;
     if (need_lds > 48 * 1024 && !model_in_global) {
-        const void *variants[] = {(const void *)logprob_kernel<2, 2, 512>, (const void *)logprob_kernel<2, 1, 1024>,
+        const void *variants[] = {(const void *)logprob_kernel<2, 2, 256>, (const void *)logprob_kernel<2, 2, 512>,
+                                  (const void *)logprob_kernel<2, 1, 512>,
+                                  (const void *)logprob_kernel<2, 1, 1024>,
+                                  (const void *)logprob_kernel<2, 2, 256, false, true>,
                                   (const void *)logprob_kernel<2, 2, 512, false, true>,
-                                  (const void *)logprob_kernel<3, 1, 512>, (const void *)logprob_kernel<3, 1, 1024>};
+                                  (const void *)logprob_kernel<3, 1, 256>, (const void *)logprob_kernel<3, 1, 512>,
+                                  (const void *)logprob_kernel<3, 1, 1024>};
         for (const void *k : variants)
             HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_lds));
     }
@@ -2418,19 +2464,26 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // pixel statics staged in LDS by the idle waves: 512-thread workgroups that own their CU (one per CU anyway)
     // and whose 4 npix doubles fit beside the scratch
     const bool pf = B == 512 && n <= c->prop.multiProcessorCount && !c->P.pairs_c && c->pf_ok && c->use_pf;
+    // every variant is compiled for, and launched with, exactly its thread count (the canonical summation order
+    // relies on it)
+#define MSX_GO(NS_, U_, T_, CP_, PF_, LDS_)                                                                           \
+    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, false, CP_, PF_>), g, b, (LDS_), s, c->P, mode, d_theta, n, ndim, \
+                       d_logp, d_status)
+    const bool cp = c->P.pairs_c != nullptr;
     if (c->P.nspec == 2) {
-        if (pf)
-            hipLaunchKernelGGL((logprob_kernel<2, 2, 512, false, false, true>), g, b, 4 * lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
-        else if (B <= 512 && c->P.pairs_c)
-            hipLaunchKernelGGL((logprob_kernel<2, 2, 512, false, true>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
-        else if (B <= 512)
-            hipLaunchKernelGGL((logprob_kernel<2, 2, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
-        else hipLaunchKernelGGL((logprob_kernel<2, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        if (B == 256) { if (cp) MSX_GO(2, 2, 256, true, false, lds); else MSX_GO(2, 2, 256, false, false, lds); }
+        else if (B == 512) {
+            if (pf) MSX_GO(2, 2, 512, false, true, 4 * lds);
+            else if (cp) MSX_GO(2, 2, 512, true, false, lds);
+            else if (n > c->prop.multiProcessorCount) MSX_GO(2, 1, 512, false, false, lds);  // two workgroups per CU
+            else MSX_GO(2, 2, 512, false, false, lds);
+        } else MSX_GO(2, 1, 1024, false, false, lds);
     } else {
-        if (pf) hipLaunchKernelGGL((logprob_kernel<3, 1, 512, false, false, true>), g, b, 4 * lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
-        else if (B <= 512) hipLaunchKernelGGL((logprob_kernel<3, 1, 512>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
-        else hipLaunchKernelGGL((logprob_kernel<3, 1, 1024>), g, b, lds, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+        if (B == 256) MSX_GO(3, 1, 256, false, false, lds);
+        else if (B == 512) { if (pf) MSX_GO(3, 1, 512, false, true, 4 * lds); else MSX_GO(3, 1, 512, false, false, lds); }
+        else MSX_GO(3, 1, 1024, false, false, lds);
     }
+#undef MSX_GO
     HIP_TRY(c, hipGetLastError());
     return MSX_OK;
 }

@@ -280,6 +280,48 @@ def test_every_workgroup_size_gives_identical_bits(block, engB):
     del ref
 
 
+def test_bits_do_not_depend_on_workgroup_size_or_batch():
+    """the gathered vector of a sharded run must be bit-identical to the one-GPU vector.  Shards are
+    launched with other batch sizes, hence other workgroup sizes, so every sum of the kernel is taken in an order
+    that is independent of both (16 virtual waves).  Weak contrast terms here, so that the spectral chi^2 -- the
+    part that is summed over pixels -- carries the value's low bits."""
+    import torch
+    from mcmc_spec_amd import _lib
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    c = golden_case('B')
+    bl = bands.make_bands(c.tables, *c.vega)
+    fr = [list(c.fr[0]), [10.0 for _ in c.fr[1]], c.fr[2], list(c.fr[3]), [10.0 for _ in c.fr[4]], c.fr[5]]
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(c.data, c.err, fr, [min(c.data[0]), max(c.data[0])], c.ctm, c.ptm, c.tmi, c.tma, c.matrix,
+                      nspec=2, bands=bl)
+    rng = np.random.default_rng(8)
+    th = np.repeat(c.theta[:8], 40, axis=0) * (1 + 1e-3 * rng.normal(size=(320, 6)))
+    dev = torch.device('cuda', 0)
+    tht = torch.from_numpy(np.ascontiguousarray(th)).to(dev)
+    out = {}
+    for mode in (_lib.MODE_LOGLIKE, _lib.MODE_CHISQ):
+        for block in (256, 512, 1024, 0):
+            lp = torch.empty(len(th), dtype=torch.float64, device=dev)
+            st = torch.empty(len(th), dtype=torch.int32, device=dev)
+            eng.ctx.logprob_batch_dev(tht.data_ptr(), len(th), 6, lp.data_ptr(), st.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream, mode, block)
+            torch.cuda.synchronize()
+            out[mode, block] = lp.cpu().numpy()
+        ref = out[mode, 256]
+        assert np.isfinite(ref).sum() > 100
+        for block in (512, 1024, 0):
+            assert np.array_equal(out[mode, block], ref, equal_nan=True), (mode, block)
+        # a shard of the batch (other n -> other automatic workgroup size, 512 threads with LDS-staged statics)
+        lp = torch.empty(100, dtype=torch.float64, device=dev)
+        st = torch.empty(100, dtype=torch.int32, device=dev)
+        eng.ctx.logprob_batch_dev(tht[57:157].contiguous().data_ptr(), 100, 6, lp.data_ptr(), st.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream, mode, 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(lp.cpu().numpy(), ref[57:157], equal_nan=True)
+
+
 def test_generic_recipe_path_for_large_tables():
     """Tables too large for the register-resident recipe (here a 300-bin A_V table) take the generic
     memory-walking path; results must not change."""
