@@ -445,6 +445,18 @@ def test_triple_system_ndim8_matches_reference_golden():
     assert rel_err(ll, g['C_loglike'][ok]).max() < TIGHT
     lp = eng.logprior(c.theta)
     assert np.array_equal(np.isinf(lp), np.isinf(g['C_logprior'])) and rel_err(lp, g['C_logprior']).max() < 1e-12
+    # the triple-system kernel variants (256 / 512 / 1024 threads) agree to the bit
+    import torch
+    from mcmc_spec_amd import _lib
+    dev = torch.device('cuda', 0)
+    tht = torch.from_numpy(np.ascontiguousarray(c.theta)).to(dev)
+    for block in (256, 512, 1024):
+        out = torch.empty(len(c.theta), dtype=torch.float64, device=dev)
+        st = torch.empty(len(c.theta), dtype=torch.int32, device=dev)
+        eng.ctx.logprob_batch_dev(tht.data_ptr(), len(c.theta), 8, out.data_ptr(), st.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream, _lib.MODE_LOGPOST, block)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), got, equal_nan=True), block
 
 
 def test_loader_spec_interpolator_matches_reference_golden(tmp_path):
@@ -732,3 +744,14 @@ def test_compact_pair_storage_is_opt_in_and_stays_inside_the_bar():
     got = eng.loglikelihood(c.theta)
     assert rel_err(got, c.g['B_loglike']).max() < TIGHT
     assert eng.ctx.bytes_per_eval() < 700 * (16 * 8 + 64)   # 12-byte pairs are in use
+    import torch
+    from mcmc_spec_amd import _lib
+    dev = torch.device('cuda', 0)
+    tht = torch.from_numpy(np.ascontiguousarray(c.theta)).to(dev)
+    for block in (256, 512):   # both compact-pair variants, same bits
+        lp = torch.empty(len(c.theta), dtype=torch.float64, device=dev)
+        st = torch.empty(len(c.theta), dtype=torch.int32, device=dev)
+        eng.ctx.logprob_batch_dev(tht.data_ptr(), len(c.theta), 6, lp.data_ptr(), st.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream, _lib.MODE_LOGLIKE, block)
+        torch.cuda.synchronize()
+        assert np.array_equal(lp.cpu().numpy(), got, equal_nan=True), block
