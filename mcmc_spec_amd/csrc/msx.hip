@@ -111,7 +111,8 @@ struct DevProblem {
     int32_t smp_on;
     double *smp_coords, *smp_logp;          // [nw][ndim], [nw]   ensemble state (updated in place)
     double *smp_q;                          // [ns][ndim]         proposals of this half-step
-    const int32_t *smp_sidx, *smp_cidx, *smp_partner;  // [ns]
+    const int32_t *smp_sidx, *smp_cidx, *smp_partner;  // [ns]; smp_partner holds cidx[partner]: the ensemble
+                                                       // index of the complementary walker (resolved on the host)
     const double *smp_zz, *smp_zfac, *smp_logu;        // [ns]
     int64_t *smp_naccept;                   // [nw]
     double *smp_chain_row, *smp_lp_row;     // chain[step] [nw][ndim], logp chain[step] [nw]
@@ -140,6 +141,13 @@ struct WalkerDesc {
     int32_t status;
     int32_t ncorner;
     int32_t stat[MSX_MAX_SPEC];  // fast recipe: per-star status of part 1 (one wave per star)
+    // device-resident sampler: everything the accept step needs is fetched in the kernel's first lines (in
+    // parallel with the proposal's own loads) so that its last lines touch no memory they have to wait for
+    double theta[2 * MSX_MAX_SPEC + 2];   // the proposal q (this walker's coordinates for the launch)
+    double smp_sv[2 * MSX_MAX_SPEC + 2];  // the walker's current coordinates
+    double smp_old, smp_zfac, smp_logu;   // its current log-probability, (ndim-1) ln z, ln u
+    int64_t smp_s;                        // its index in the ensemble
+    int64_t smp_nacc;                     // its acceptance count so far
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1260,27 +1268,25 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
 // stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
 // like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
 // own half-step, so its row after the step is written here.
-__device__ __forceinline__ void walker_done(const DevProblem &P, int64_t wk, int ndim, double out, int st,
+__device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
                             double *__restrict__ logp, int32_t *__restrict__ status) {
     logp[wk] = out;
     status[wk] = st;
     if (!P.smp_on) return;
     if (st > MSX_W_REJECT) atomicMax(P.smp_worst, st);
-    const int64_t s = P.smp_sidx[wk];
-    const double lnpdiff = (P.smp_zfac[wk] + out) - P.smp_logp[s];
-    const bool acc = P.smp_logu[wk] < lnpdiff;
-    double lp_now = P.smp_logp[s];
+    const int64_t s = D.smp_s;
+    const double lnpdiff = (D.smp_zfac + out) - D.smp_old;
+    const bool acc = D.smp_logu < lnpdiff;
     if (acc) {
-        lp_now = out;
         P.smp_logp[s] = out;
-        P.smp_naccept[s] += 1;
+        P.smp_naccept[s] = D.smp_nacc + 1;
     }
     for (int d = 0; d < ndim; ++d) {
-        const double v = acc ? P.smp_q[wk * ndim + d] : P.smp_coords[s * ndim + d];
+        const double v = acc ? D.theta[d] : D.smp_sv[d];
         if (acc) P.smp_coords[s * ndim + d] = v;
         P.smp_chain_row[s * ndim + d] = v;
     }
-    P.smp_lp_row[s] = lp_now;
+    P.smp_lp_row[s] = acc ? out : D.smp_old;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,19 +1327,35 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
 
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
+    const double *th_row = theta + wk * ndim;
     if (P.smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
+        // two dependent levels only: {own index, complement index, z} -> the two coordinate rows.  The proposal
+        // goes to LDS (the recipe waves read it there, no round trip through memory); wave 1 meanwhile fetches
+        // what the accept step will need at the very end.
         if (tid < ndim) {
 #pragma clang fp contract(off)
             // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
             // the device-resident and the host-driven sampler stay in lock-step
-            const double sv = P.smp_coords[(int64_t)P.smp_sidx[wk] * ndim + tid];
-            const double cv = P.smp_coords[(int64_t)P.smp_cidx[P.smp_partner[wk]] * ndim + tid];
+            const int64_t si = P.smp_sidx[wk], ci = P.smp_partner[wk];
+            const double zz = P.smp_zz[wk];
+            const double sv = P.smp_coords[si * ndim + tid];
+            const double cv = P.smp_coords[ci * ndim + tid];
             const double diff = cv - sv;
-            const double prod = diff * P.smp_zz[wk];
-            P.smp_q[wk * ndim + tid] = cv - prod;
+            const double prod = diff * zz;
+            const double qv = cv - prod;
+            D.theta[tid] = qv;
+            D.smp_sv[tid] = sv;
+            P.smp_q[wk * ndim + tid] = qv;  // (kept for inspection; nothing reads it back)
+        } else if (tid == kWave) {
+            const int64_t si = P.smp_sidx[wk];
+            D.smp_s = si;
+            D.smp_old = P.smp_logp[si];
+            D.smp_nacc = P.smp_naccept[si];
+            D.smp_zfac = P.smp_zfac[wk];
+            D.smp_logu = P.smp_logu[wk];
         }
-        __syncthreads();  // same-workgroup global hand-off: stores drained + barrier, then plain loads
-        theta = P.smp_q;
+        __syncthreads();
+        th_row = D.theta;
     }
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
@@ -1347,7 +1369,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
                        (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
     // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
     // mode (rejected walkers never read them)
-    if (fast && wave == NS) recipe_prior_terms<NS>(P, mode, theta + wk * ndim, D, lane);
+    if (fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
     if (PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
         const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
 #pragma unroll 4
@@ -1358,10 +1380,10 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         }
     }
     if (fast) {
-        if (wave < NS) recipe_part1_regs<NS>(P, mode, theta + wk * ndim, D, lane, wk, wave);
+        if (wave < NS) recipe_part1_regs<NS>(P, mode, th_row, D, lane, wk, wave);
     } else if (wave == 0) {
         const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
-        build_recipe_wave<NS>(P, T, mode, theta + wk * ndim, ndim, D, lane, wk);
+        build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
     }
     __syncthreads();
     int wst = D.status;
@@ -1372,7 +1394,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     }
     if (wst != MSX_W_OK) {
         if (tid == 0) {
-            walker_done(P, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
+            walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
         }
         return;
     }
@@ -1388,12 +1410,12 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     if (P.no_spectrum) {
         // the mft6_nospec.py variant (mft6_nospec.py:1163-1196): the spectrum term is commented out there and
         // the total is contrast + photometry chi^2 only -- no spectral phases at all
-        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
+        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_row, D, lane);
         __syncthreads();
         if (tid == 0) {
             const double total = D.chi_extra;
             const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
-            walker_done(P, wk, ndim, chi_valued ? total : (isnan(total) ? -INFINITY : D.lp + (-0.5 * total)), MSX_W_OK, logp,
+            walker_done(P, D, wk, ndim, chi_valued ? total : (isnan(total) ? -INFINITY : D.lp + (-0.5 * total)), MSX_W_OK, logp,
                         status);
         }
         return;
@@ -1499,7 +1521,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
     // bound by the CU's L2 port and wave 0's loads are served first, so wave 0 leaves the pixel loop thousands of
     // cycles before the last wave: it computes the terms in that wait.  (Other modes: inside block_median.)
-    if (early && wave == 0) recipe_band_terms<NS>(P, mode, theta + wk * ndim, D, lane);
+    if (early && wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
     {
 #pragma unroll
         for (int k = 0; k < vk; ++k) {
@@ -1530,14 +1552,14 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         if (tid == 0) {
             const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
             if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
-            walker_done(P, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
+            walker_done(P, D, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
         }
         return;
     }
 
     // ---- phase B: exact median (np.median, mft6.py:1173) -----------------------------------------------
     // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
-    const double *th_w = theta + wk * ndim;
+    const double *th_w = th_row;
     auto side = [&]() __attribute__((always_inline)) {
         if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
     };
@@ -1691,7 +1713,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         double out;
         if (mode == MSX_MODE_CHISQ || opt_step || opt_init) out = total;  // mft6.py:1198-1199
         else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
-        walker_done(P, wk, ndim, out, MSX_W_OK, logp, status);
+        walker_done(P, D, wk, ndim, out, MSX_W_OK, logp, status);
     }
 }
 
@@ -2678,6 +2700,9 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
     for (int64_t i = 0; i < nh; ++i)
         if ((uint32_t)hi[i] >= (uint32_t)nw || (uint32_t)hi[nh + i] >= (uint32_t)nw || (uint32_t)hi[2 * nh + i] >= (uint32_t)ns)
             return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue: walker / partner index out of range");
+    // resolve partner -> ensemble index of the complementary walker here, so that the kernel's proposal needs
+    // two dependent loads (index, coordinates) instead of three
+    for (int64_t i = 0; i < nh; ++i) hi[2 * nh + i] = hi[nh + (i / ns) * ns + hi[2 * nh + i]];
     HIP_TRY(c, hipMemcpyAsync(sl.d_in, sl.h_in, r->in_bytes(nsteps), hipMemcpyHostToDevice, r->up));
     HIP_TRY(c, hipEventRecord(sl.in_ready, r->up));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.in_ready, 0));
