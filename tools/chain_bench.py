@@ -28,7 +28,7 @@ def main():
         th = time.perf_counter() - t0
         dev = DeviceEnsembleSampler(nw, 6, eng, seed=1, chunk=100)
         dev.run_mcmc(p0, 5)
-        dsteps = 1000
+        dsteps = 4000
         t0 = time.perf_counter()
         dev.run_mcmc(p0, dsteps, store=False)
         td = time.perf_counter() - t0
