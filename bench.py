@@ -392,6 +392,9 @@ def main():
                          'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples, 'algorithmic_bytes_per_launch': n * b_alg,
                          'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
                          'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
+                         # what actually bounds the kernel: bytes a workgroup pulls through its
+                         # CU's L2 port, averaged over the kernel (the guide's per-CU L2 rate is 66-73 GB/s)
+                         'requested_GBps_per_workgroup': eng.ctx.bytes_per_eval() / (kern_ms * 1e-3) / 1e9,
                          'note': NWIN_DOC},
             'walker_error_statuses': bad,
         }
