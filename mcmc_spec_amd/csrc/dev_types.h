@@ -1,0 +1,122 @@
+// dev_types.h -- part of the single translation unit msx.hip (included there, in this order).
+// constants and the device-side structs: DevProblem (the staged problem, a by-value kernel argument), WalkerDesc (a walker's recipe, in LDS).
+#ifndef MSX_DEV_TYPES_H
+#define MSX_DEV_TYPES_H
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxWaves = 16;            // 1024 threads
+constexpr int kMaxCorners = MSX_MAX_SPEC * 4;
+constexpr int kSelectFinish = 256;       // radix select switches to all-pairs ranking at this many candidates
+constexpr double kRsunCm = 6.957e10;     // mft6.py:691
+constexpr double kPcCm = 3.086e18;       // mft6.py:691
+constexpr double kLog2Of10 = 3.321928094887362347870319429489390175864831393024580612054;
+
+// ------------------------------------------------------------------------------------------------
+// Device-side view of everything staged.  Passed to kernels by value (well under the 4 KiB limit).
+// ------------------------------------------------------------------------------------------------
+// NOTE: kernels take this struct BY VALUE (kernarg segment).  Every device helper that receives it by
+// reference must be __forceinline__: an out-of-line call needs the struct's address, which makes the
+// compiler copy all ~1.2 KB of it into per-lane scratch and route every later access through scratch
+// (measured: 21.8 -> 44.8 us per 256-walker launch).  `-Rpass-analysis=kernel-resource-usage` must show
+// ScratchSize 0 for logprob_kernel; tests/test_abi.py checks it.  (Reading the struct through a pointer to a
+// device copy instead was tried: no scratch hazard, but 61 instead of 16 spilled SGPRs and +10 % kernel time
+// for 256-thread workgroups, so by-value + forced inlining stays.)
+// Optional compact pair storage (msx_problem.compact_pairs): {flux[lo] as float64, flux[lo+1]-flux[lo] as
+// float32}, 12 bytes instead of 16.  The difference of neighbouring 0.2 A samples is ~1e-2..1e-3 of the flux,
+// so rounding it to float32 perturbs the upper sample by ~1e-9..1e-10 relative -- NOT bit-faithful to the
+// float64 reference arithmetic; off by default, measured in DESIGN.md.
+struct __attribute__((packed, aligned(4))) PairC {
+    double lo;
+    float d;
+};
+static_assert(sizeof(PairC) == 12, "PairC must be 12 bytes");
+
+struct DevProblem {
+    // grid (A0)
+    const double *grid;   // [nt*ng][nwl]
+    const double *kgrid;  // [nwl]  CCM89 a + b/3.1 per grid sample (A7)
+    int64_t nwl;
+    int32_t nt, ng;
+    const double *teff_nodes;
+    const double *logg_nodes;
+    const uint8_t *present;
+    // pixel tables (A8)
+    const double2 *pairs;  // [nt*ng][npix] {flux[lo], flux[lo+1]}
+    const PairC *pairs_c;  // [nt*ng][npix] compact form, or nullptr
+    const double2 *pix_k;  // [npix] {k[lo], k[lo+1]}
+    const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
+    int64_t npix;
+    double median_flux;
+    double minv[9];
+    // bands (A5/A6)
+    int32_t nc, np;
+    const double *band_tab;  // [nt*ng][nc+np]
+    double cmag[MSX_MAX_BANDS], cerr[MSX_MAX_BANDS];
+    double pmag[MSX_MAX_BANDS], perr[MSX_MAX_BANDS], pzero[MSX_MAX_BANDS], pk[MSX_MAX_BANDS];
+    double civar[MSX_MAX_BANDS], pivar[MSX_MAX_BANDS];  // 1/cerr^2, 1/perr^2
+    int64_t win_j0, win_n;
+    // isochrone (A1)
+    int32_t niso;
+    const double *iso_t, *iso_g, *iso_l;
+    // prior (f1)
+    int32_t nav;
+    const double *av_edges, *av_mu, *av_sig;
+    double tmin, tmax;
+    double pmean[MSX_MAX_DIM], psig[MSX_MAX_DIM];
+    int32_t use_av, dist_fit, rad_prior, has_prior;
+    int32_t nspec;
+    int32_t no_spectrum;  // mft6_nospec.py: contrast + photometry chi^2 only
+    // pre-optimiser (f4): per-chain normalised data vectors / their medians, walker -> chain map
+    double *opt_flux;          // [nchains][npix]
+    double *opt_med;           // [nchains]
+    const int32_t *opt_chain;  // [n] (OPT_STEP launches)
+    double *model_scratch;     // [n][npix] only when the model vector does not fit LDS (GM kernel variants)
+    // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
+    // active half; the kernel builds its own proposal and applies the accept rule in its last lines
+    int32_t smp_on;
+    double *smp_coords, *smp_logp;          // [nw][ndim], [nw]   ensemble state (updated in place)
+    double *smp_q;                          // [ns][ndim]         proposals of this half-step
+    const int32_t *smp_sidx, *smp_cidx, *smp_partner;  // [ns]; smp_partner holds cidx[partner]: the ensemble
+                                                       // index of the complementary walker (resolved on the host)
+    const double *smp_zz, *smp_zfac, *smp_logu;        // [ns]
+    int64_t *smp_naccept;                   // [nw]
+    double *smp_chain_row, *smp_lp_row;     // chain[step] [nw][ndim], logp chain[step] [nw]
+    int32_t *smp_worst;
+#ifdef MSX_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
+#endif
+};
+
+#ifdef MSX_STAMPS
+#define MSX_STAMP(P, wk, i) do { if (threadIdx.x == 0) (P).stamps[(wk) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MSX_STAMP(P, wk, i) do { } while (0)
+#endif
+
+// Per-walker recipe computed once by one lane and broadcast through LDS.
+struct WalkerDesc {
+    int32_t node[kMaxCorners];   // flat node index it*ng+ig of each corner
+    double w[kMaxCorners];       // bilinear weight * (R/d)^2 scale
+    double redc;                 // exp2 coefficient -0.4*log2(10)*A_V; 0 -> no reddening (A_V <= 0)
+    double lp;                   // log prior (0 in LOGLIKE mode)
+    double chi_extra;            // icontrast + iphot                        mft6.py:1183,1189
+    double contrast[MSX_MAX_BANDS];
+    double phot[MSX_MAX_BANDS];
+    double mag[MSX_MAX_BANDS * MSX_MAX_SPEC + MSX_MAX_BANDS];  // per-lane magnitudes of the wave recipe
+    int32_t status;
+    int32_t ncorner;
+    int32_t stat[MSX_MAX_SPEC];  // fast recipe: per-star status of part 1 (one wave per star)
+    // device-resident sampler: everything the accept step needs is fetched in the kernel's first lines (in
+    // parallel with the proposal's own loads) so that its last lines touch no memory they have to wait for
+    double theta[2 * MSX_MAX_SPEC + 2];   // the proposal q (this walker's coordinates for the launch)
+    double smp_sv[2 * MSX_MAX_SPEC + 2];  // the walker's current coordinates
+    double smp_old, smp_zfac, smp_logu;   // its current log-probability, (ndim-1) ln z, ln u
+    int64_t smp_s;                        // its index in the ensemble
+    int64_t smp_nacc;                     // its acceptance count so far
+};
+
+}  // namespace
+
+#endif  // MSX_DEV_TYPES_H

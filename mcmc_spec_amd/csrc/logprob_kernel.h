@@ -1,0 +1,463 @@
+// logprob_kernel.h -- part of the single translation unit msx.hip (included there, in this order).
+// THE HOT KERNEL logprob_kernel<NS,U,MAXT,GM,CP,PF> and the walker's last lines (walker_done).
+#ifndef MSX_LOGPROB_KERNEL_H
+#define MSX_LOGPROB_KERNEL_H
+
+namespace {
+
+// Last lines of a walker (one lane): publish the value and, for the device-resident sampler, apply the
+// stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
+// like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
+// own half-step, so its row after the step is written here.
+__device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
+                            double *__restrict__ logp, int32_t *__restrict__ status) {
+    logp[wk] = out;
+    status[wk] = st;
+    if (!P.smp_on) return;
+    if (st > MSX_W_REJECT) atomicMax(P.smp_worst, st);
+    const int64_t s = D.smp_s;
+    const double lnpdiff = (D.smp_zfac + out) - D.smp_old;
+    const bool acc = D.smp_logu < lnpdiff;
+    if (acc) {
+        P.smp_logp[s] = out;
+        P.smp_naccept[s] = D.smp_nacc + 1;
+    }
+    for (int d = 0; d < ndim; ++d) {
+        const double v = acc ? D.theta[d] : D.smp_sv[d];
+        if (acc) P.smp_coords[s * ndim + d] = v;
+        P.smp_chain_row[s * ndim + d] = v;
+    }
+    P.smp_lp_row[s] = acc ? out : D.smp_old;
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE HOT KERNEL: one workgroup per walker.
+//   phase 0  wave 0 builds the walker's recipe on 64 lanes (prior gate, A1, A2, A4, A5, A6)
+//   phase A  blend + redden + resample into LDS; fit sums; value range           (A2, A4, A7, A8.1)
+//   phase B  exact median: 1024 linear value bins -> <=256 candidates -> all-pairs rank
+//            (falls back to the bitwise radix select for adversarial distributions)     (A8.2)
+//   phase C  continuum fit coefficients, chi^2                                          (A8.3, A9)
+// ------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+
+// MAXT = largest workgroup the variant is launched with.  The 512-thread variants may use up to 256
+// VGPRs (the two-pixels-per-trip body wants ~146: no spills, 3 waves per SIMD); the 1024-thread variants
+// are capped at 128 VGPRs by the hardware and use one pixel per trip.
+// GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
+// PF = while the recipe waves work, the idle waves copy three walker-independent pixel vectors (u, data flux,
+//      resample weight t) into LDS; phase A and the chi^2 pass then read them from LDS, which takes 160 of the
+//      786 KB a walker pulls through its CU's L2 port off the critical path (one workgroup per CU only: 4 npix
+//      doubles of LDS).
+template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false>
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && U == 1) ? 2 : 1)
+logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
+               double *__restrict__ logp, int32_t *__restrict__ status) {
+    __shared__ WalkerDesc D;
+    __shared__ BlockScratch S;
+    const int64_t wk = blockIdx.x;
+    if (wk >= n) return;
+    double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
+    const int tid = threadIdx.x;
+    constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int nw = B >> 6;
+    const int npix = (int)P.npix;
+    double *const lds_u = PF ? reinterpret_cast<double *>(dyn_lds) + npix : nullptr;
+    double *const lds_f = PF ? lds_u + npix : nullptr;
+    double *const lds_t = PF ? lds_f + npix : nullptr;
+
+    MSX_STAMP(P, wk, 0);
+    MSX_STAMP(P, wk, 8);
+    const double *th_row = theta + wk * ndim;
+    if (P.smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
+        // two dependent levels only: {own index, complement index, z} -> the two coordinate rows.  The proposal
+        // goes to LDS (the recipe waves read it there, no round trip through memory); wave 1 meanwhile fetches
+        // what the accept step will need at the very end.
+        if (tid < ndim) {
+#pragma clang fp contract(off)
+            // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
+            // the device-resident and the host-driven sampler stay in lock-step
+            const int64_t si = P.smp_sidx[wk], ci = P.smp_partner[wk];
+            const double zz = P.smp_zz[wk];
+            const double sv = P.smp_coords[si * ndim + tid];
+            const double cv = P.smp_coords[ci * ndim + tid];
+            const double diff = cv - sv;
+            const double prod = diff * zz;
+            const double qv = cv - prod;
+            D.theta[tid] = qv;
+            D.smp_sv[tid] = sv;
+            P.smp_q[wk * ndim + tid] = qv;  // (kept for inspection; nothing reads it back)
+        } else if (tid == kWave) {
+            const int64_t si = P.smp_sidx[wk];
+            D.smp_s = si;
+            D.smp_old = P.smp_logp[si];
+            D.smp_nacc = P.smp_naccept[si];
+            D.smp_zfac = P.smp_zfac[wk];
+            D.smp_logu = P.smp_logu[wk];
+        }
+        __syncthreads();
+        th_row = D.theta;
+    }
+    for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
+    if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
+    // register-resident tables when they fit one wave (the usual case), else the generic walk
+    const bool fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave &&
+                      P.nav + 1 <= 2 * kWave;
+    // Early-histogram path (logbin_median): the median's histogram is filled while phase A computes the model,
+    // and the walker's prior terms move to an idle wave of phase 0.  Likelihood / posterior / chi^2 modes with
+    // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
+    const bool early = !GM && fast && !P.no_spectrum &&
+                       (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
+    // mode (rejected walkers never read them)
+    if (fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    if (PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
+        const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
+#pragma unroll 4
+        for (int p = id; p < npix; p += nthr) {
+            lds_u[p] = P.pix_u[p];
+            lds_f[p] = P.pix_flux[p];
+            lds_t[p] = P.pix_t[p];
+        }
+    }
+    if (fast) {
+        if (wave < NS) recipe_part1_regs<NS>(P, mode, th_row, D, lane, wk, wave);
+    } else if (wave == 0) {
+        const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
+        build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
+    }
+    __syncthreads();
+    int wst = D.status;
+    if (fast) {  // first star that failed decides, like the reference's star-by-star loop
+        wst = D.stat[0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) wst = (wst == MSX_W_OK) ? D.stat[k] : wst;
+    }
+    if (wst != MSX_W_OK) {
+        if (tid == 0) {
+            walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
+        }
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {  // logprior alone (mft6.py:1207-1272): no spectrum pass
+        if (wave == 0) {  // (fast recipe: wave NS left D.lp / D.status before the barrier above)
+            if (lane == 0) {
+                logp[wk] = (D.status == MSX_W_OK) ? D.lp : NAN;
+                status[wk] = D.status;
+            }
+        }
+        return;
+    }
+    if (P.no_spectrum) {
+        // the mft6_nospec.py variant (mft6_nospec.py:1163-1196): the spectrum term is commented out there and
+        // the total is contrast + photometry chi^2 only -- no spectral phases at all
+        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+        __syncthreads();
+        if (tid == 0) {
+            const double total = D.chi_extra;
+            const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
+            walker_done(P, D, wk, ndim, chi_valued ? total : (isnan(total) ? -INFINITY : D.lp + (-0.5 * total)), MSX_W_OK, logp,
+                        status);
+        }
+        return;
+    }
+    MSX_STAMP(P, wk, 1);
+
+    // ---- phase A ------------------------------------------------------------------------------------
+    const double2 *rows[NS * 4];
+    const PairC *rows_c[NS * 4];
+    double w[NS * 4];
+#pragma unroll
+    for (int c = 0; c < NS * 4; ++c) {
+        const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
+        rows[c] = P.pairs + off;
+        rows_c[c] = CP ? P.pairs_c + off : nullptr;
+        w[c] = D.w[c];
+    }
+    const double redc = D.redc;
+    const bool redden = redc != 0.0;
+    // Sums are taken in an order that does not depend on the workgroup size: pixel p belongs to row p / B of the
+    // launch, i.e. to 64-pixel chunk c = p / 64, and chunk c is owned by VIRTUAL wave c mod 16.  A real wave of a
+    // 4- or 8-wave workgroup plays 4 or 2 virtual waves (its rows alternate between them), each with its own
+    // accumulator; every virtual wave sees its chunks in ascending order, lanes are reduced by the same DPP tree
+    // and the 16 partials are added serially -- the same association for 256, 512 and 1024 threads, so a
+    // walker's log-probability has the same bits whatever launch (batch size, shard, rank) evaluates it.
+    // (every variant is launched with exactly MAXT threads, so the count is a compile-time constant)
+    constexpr int vk = kMaxWaves / (MAXT / kWave);  // virtual waves per real wave: 4, 2 or 1
+    double qa[vk][3];
+#pragma unroll
+    for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
+    double q[3];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    // rows are taken vk at a time (SUB sub-trips of U rows) so that every row's virtual-wave slot is static
+    constexpr int SUB = (vk > U) ? vk / U : 1;
+    for (int base0 = 0; base0 < npix; base0 += B * U * SUB) {
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int base = base0 + sub * B * U;
+        if (base >= npix) break;
+        double2 v[U][NS * 4];
+        double2 kk[U];
+        double tt[U], ff[U], uu[U];
+        int pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = base + u * B + tid;
+            pp[u] = p < npix ? p : npix - 1;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) {
+                if (CP) {
+                    const PairC pc = rows_c[c][pp[u]];
+                    v[u][c] = make_double2(pc.lo, (double)pc.d);  // .y holds the DIFFERENCE in compact mode
+                } else {
+                    v[u][c] = rows[c][pp[u]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kk[u] = redden ? P.pix_k[pp[u]] : make_double2(0.0, 0.0);
+            tt[u] = PF ? lds_t[pp[u]] : P.pix_t[pp[u]];
+            ff[u] = PF ? lds_f[pp[u]] : P.pix_flux[pp[u]];
+            uu[u] = PF ? lds_u[pp[u]] : P.pix_u[pp[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double ylo = 0.0, yhi = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) {
+                ylo = fma(w[c], v[u][c].x, ylo);
+                yhi = fma(w[c], v[u][c].y, yhi);
+            }
+            if (CP) yhi += ylo;  // blended difference -> blended upper sample
+            if (redden) {
+                const double elo = exp2(redc * kk[u].x);  // 10^(-0.4 A_V k)     mft6.py:62-63
+                // neighbouring grid samples: y = ln2 * c * (k_hi - k_lo) is tiny, so e^y from four series
+                // terms is exact to < 1e-17 for |y| < 1e-3; anything larger takes the full exp2
+                const double y = 0.6931471805599453 * (redc * (kk[u].y - kk[u].x));
+                const double ehi = (fabs(y) < 1e-3)
+                                       ? elo * fma(y, fma(y, fma(y, fma(y, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0)
+                                       : exp2(redc * kk[u].y);
+                ylo *= elo;
+                yhi *= ehi;
+            }
+            const double m = fma(yhi - ylo, tt[u], ylo);  // mft6.py:1169-1170
+            if (base + u * B + tid < npix) {
+                model[pp[u]] = m;
+                const double f = ff[u] / m;  // frac before the median scale, mft6.py:194
+                const double f1 = f * uu[u], f2 = f * (uu[u] * uu[u]);
+                const int slot = (sub * U + u) & (vk - 1);  // static: sub and u are unrolled
+#pragma unroll
+                for (int k = 0; k < vk; ++k)
+                    if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2; }
+                const unsigned long long key = key_of(m);
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+                if (early) atomicAdd(&S.hist[logbin(m)], 1u);
+            }
+        }
+      }
+    }
+    MSX_STAMP(P, wk, 2);
+    // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
+    // bound by the CU's L2 port and wave 0's loads are served first, so wave 0 leaves the pixel loop thousands of
+    // cycles before the last wave: it computes the terms in that wait.  (Other modes: inside block_median.)
+    if (early && wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+    {
+#pragma unroll
+        for (int k = 0; k < vk; ++k) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r = wave_sum(qa[k][i]);
+                if (lane == 0) S.q[i][k * nw + wave] = r;  // virtual wave = row class * nw + wave
+            }
+        }
+        const unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
+        if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double r = 0.0;
+            for (int x = 0; x < kMaxWaves; ++x) r += S.q[i][x];
+            q[i] = r;
+        }
+        kmin = S.kmin[0]; kmax = S.kmax[0];
+        for (int x = 1; x < nw; ++x) {
+            kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
+            kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
+        }
+    }
+    MSX_STAMP(P, wk, 3);
+    // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
+    if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
+        if (tid == 0) {
+            const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
+            if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
+            walker_done(P, D, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
+        }
+        return;
+    }
+
+    // ---- phase B: exact median (np.median, mft6.py:1173) -----------------------------------------------
+    // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
+    const double *th_w = th_row;
+    auto side = [&]() __attribute__((always_inline)) {
+        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
+    };
+    // The spectrum chi^2 factorises: with P(u) = c0 + c1 u + c2 u^2 the raw fit of data/model (from the q
+    // sums), the fit of data/(scale*model) is P/scale, data' = scale*data/P and
+    //   sum (scale*m - data')^2/err^2 = scale^2 * sum (m - data/P)^2/err^2,
+    // so everything but the final scalar multiply is independent of the median and rides along the
+    // median's first pass over the model vector (fused modes only; the optimiser modes keep phase C).
+    const bool fused = !(mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT);
+    struct ChiElem {  // holds plain pointers, never a reference to the by-value kernel argument (see DevProblem)
+        enum { VK = kMaxWaves / (MAXT / kWave) };  // (a local class cannot have static data members)
+        const double *pix_u, *pix_flux, *pix_ivar;
+        double c0, c1, c2;
+        double acc[VK];  // one per virtual wave this wave plays (see phase A): rows k, k + VK, ... of the pass
+        bool on;
+        // four consecutive rows of the pass (row = p / blockDim.x; a trip starts at a multiple of four rows)
+        __device__ __forceinline__ void process4(const int (&pp)[4], const double (&xv)[4], const bool (&ok)[4]) {
+            if (!on) return;
+            double u[4], f[4], e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { u[k] = pix_u[pp[k]]; f[k] = pix_flux[pp[k]]; e[k] = pix_ivar[pp[k]]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double poly = fma(fma(c2, u[k], c1), u[k], c0);
+                const double r = xv[k] - f[k] / poly;  // (model - data/P); mft6.py:196,120 up to scale^2
+                acc[k & (VK - 1)] += ok[k] ? (r * r) * e[k] : 0.0;
+            }
+        }
+        __device__ __forceinline__ void flush(BlockScratch &S) {
+            if (!on) return;
+#pragma unroll
+            for (int k = 0; k < VK; ++k) {
+                const double r = wave_sum(acc[k]);
+                if ((threadIdx.x & 63) == 0) S.chi[k * (MAXT / kWave) + (threadIdx.x >> 6)] = r;
+            }
+        }
+    };
+    ChiElem chi_elem{PF ? lds_u : P.pix_u, PF ? lds_f : P.pix_flux, P.pix_ivar,
+                     P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
+                     P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
+                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused};
+    bool chi_done = false;
+    double med_model = 0.0;
+    bool solved = false;
+    if (early) {
+        solved = logbin_median(model, npix, kmin, kmax, S, chi_elem, &med_model);
+        chi_done = solved;
+        if (!solved) {  // not a positive vector spanning < 8 binades, or > 256 equal-bin candidates: start over
+            __syncthreads();  // every wave decided from the counters by itself: none may still be reading them
+            for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
+            __syncthreads();
+        }
+    }
+    if (!solved) med_model = block_median(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
+    if (fused && !chi_done) {  // degenerate vectors (all equal): the median took no pass, do it here
+        for (int base = 0; base < npix; base += 4 * B) {
+            int pp[4];
+            double xv[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = base + u * B + tid;
+                ok[u] = p < npix;
+                pp[u] = ok[u] ? p : npix - 1;
+                xv[u] = model[pp[u]];
+            }
+            chi_elem.process4(pp, xv, ok);
+        }
+        chi_elem.flush(S);
+        __syncthreads();
+    }
+    MSX_STAMP(P, wk, 4);
+    MSX_STAMP(P, wk, 5);
+
+    // ---- phase C: median scale, quadratic continuum fit, chi^2 (A8.2, A8.3, A9) ------------------
+    // Pre-optimiser variants (fit_spec, mft6.py:856-1137): OPT_INIT normalises the data against the
+    // chain's initial model like the hot path does and KEEPS the normalised vector + its median
+    // (:888-889); OPT_STEP compares every proposal with that stored vector, with no per-proposal
+    // continuum fit (:1011-1015).  Both weight the spectrum term by 3 (:893,:1015).
+    const bool opt_step = mode == MSX_MODE_OPT_STEP, opt_init = mode == MSX_MODE_OPT_INIT;
+    const int64_t chain = opt_step ? (int64_t)P.opt_chain[wk] : wk;
+    const double *__restrict__ dflux = opt_step ? P.opt_flux + chain * npix : P.pix_flux;
+    const double med_data = opt_step ? P.opt_med[chain] : P.median_flux;
+    const double scale = med_data / med_model;  // mft6.py:1173 / :1011
+    double coef[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
+    double chia[vk];  // per virtual wave, like phase A
+#pragma unroll
+    for (int k = 0; k < vk; ++k) chia[k] = 0.0;
+    unsigned long long dmin = ~0ull, dmax = 0ull;
+    for (int p = tid, row = 0; p < npix && !fused; p += B, ++row) {
+        const double ms = model[p] * scale;
+        double dn;
+        if (opt_step) {
+            dn = dflux[p];
+        } else {
+            const double u = P.pix_u[p];
+            const double poly = fma(fma(coef[2], u, coef[1]), u, coef[0]);
+            dn = dflux[p] / poly;  // mft6.py:196
+        }
+        const double r = ms - dn;
+        const double t = (r * r) * P.pix_ivar[p];  // mft6.py:120
+        const int slot = row & (vk - 1);
+#pragma unroll
+        for (int k = 0; k < vk; ++k)
+            if (slot == k) chia[k] += t;
+        if (opt_init) {
+            P.opt_flux[wk * npix + p] = dn;
+            model[p] = dn;  // the model value is dead now; reuse the LDS vector for median(data')
+            const unsigned long long key = key_of(dn);
+            dmin = key < dmin ? key : dmin;
+            dmax = key > dmax ? key : dmax;
+        }
+    }
+    MSX_STAMP(P, wk, 6);
+    if (!fused) {
+#pragma unroll
+        for (int k = 0; k < vk; ++k) {
+            const double r = wave_sum(chia[k]);
+            if (lane == 0) S.chi[k * nw + wave] = r;
+        }
+    }
+    if (opt_init) {
+        const unsigned long long a = wave_min_u64(dmin), b = wave_max_u64(dmax);
+        if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
+        for (int i = tid; i < kBins; i += B) S.hist[i] = 0;
+    }
+    if (!fused) __syncthreads();  // (fused: S.chi was published before the median's first barrier)
+    MSX_STAMP(P, wk, 7);
+    double tot = 0.0;
+    for (int x = 0; x < kMaxWaves; ++x) tot += S.chi[x];
+    if (fused) tot = tot * (scale * scale);
+    if (opt_init) {
+        dmin = S.kmin[0]; dmax = S.kmax[0];
+        for (int x = 1; x < nw; ++x) {
+            dmin = S.kmin[x] < dmin ? S.kmin[x] : dmin;
+            dmax = S.kmax[x] > dmax ? S.kmax[x] : dmax;
+        }
+        const bool bad = dmax > key_of(INFINITY) || dmin < key_of(-INFINITY);
+        NoElem no_elem;
+        bool unused = false;
+        const double md = bad ? NAN : block_median(model, npix, dmin, dmax, S, NoSide(), no_elem, &unused);  // np.median(flux), :1011
+        if (tid == 0) P.opt_med[wk] = md;
+    }
+    if (tid == 0) {
+        double iic = tot / (double)npix;  // mft6.py:1179
+        if (opt_step || opt_init) iic = iic * 3;  // mft6.py:893,1015
+        const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191 / :904 / :1028
+        double out;
+        if (mode == MSX_MODE_CHISQ || opt_step || opt_init) out = total;  // mft6.py:1198-1199
+        else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
+        walker_done(P, D, wk, ndim, out, MSX_W_OK, logp, status);
+    }
+}
+
+}  // namespace
+
+#endif  // MSX_LOGPROB_KERNEL_H

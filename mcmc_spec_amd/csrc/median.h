@@ -1,0 +1,442 @@
+// median.h -- part of the single translation unit msx.hip (included there, in this order).
+// exact np.median of the model vector in LDS: block scratch, radix select, block_median (min/max bins) and logbin_median (histogram filled during phase A).
+#ifndef MSX_MEDIAN_H
+#define MSX_MEDIAN_H
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// block scratch.  Every reduction site has its own slots so that one barrier per reduction suffices
+// (fixed order everywhere: lanes via shuffles, then waves 0..nw-1 serially -> deterministic).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBins = 1024;     // linear value bins of the median select
+constexpr int kLogBins = 2048;  // logarithmic bins of the early-histogram median (3 exponent + 8 mantissa bits)
+struct alignas(16) BlockScratch {
+    double q[3][kMaxWaves];
+    unsigned long long kmin[kMaxWaves], kmax[kMaxWaves];
+    unsigned long long above[kMaxWaves];
+    double chi[kMaxWaves];
+    unsigned int wave_tot[kMaxWaves];
+    unsigned int hist[kLogBins];  // block_median and radix_select use the first kBins / 256
+    unsigned long long cand[kSelectFinish];
+    unsigned long long sel_result[2];
+    unsigned int sel_bin, sel_k, sel_cnt, cand_n, has_second;
+    unsigned int cnt_le;
+};
+
+// Exact k-th smallest (0-based) of the keys of model[0..npix) by MSB radix passes; the general,
+// always-terminating fallback of the median.  Uses hist[0..256).  All threads must call it.
+__device__ __forceinline__ unsigned long long radix_select(const double *model, int npix, unsigned int k, unsigned long long kmin,
+                                           unsigned long long kmax, BlockScratch &S) {
+    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    if (kmin == kmax) return kmin;
+    const int hb = 63 - __clzll((long long)(kmin ^ kmax));  // highest differing bit
+    int shift = hb + 1;
+    unsigned long long pmask = (shift >= 64) ? 0ull : ~((1ull << shift) - 1ull);
+    unsigned long long pval = kmin & pmask;
+    unsigned long long v1 = kmin;
+    bool done = false;
+    while (shift > 0 && !done) {
+        const int bits = shift < 8 ? shift : 8;
+        shift -= bits;
+        const unsigned int dmask = (1u << bits) - 1u;
+        if (tid < 256) S.hist[tid] = 0;
+        __syncthreads();
+        for (int p = tid; p < npix; p += B) {
+            const unsigned long long key = key_of(model[p]);
+            if ((key & pmask) == pval) atomicAdd(&S.hist[(unsigned int)(key >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {  // locate the bin holding rank k: 4 bins per lane + wave inclusive scan
+            const unsigned int c0 = S.hist[4 * lane], c1 = S.hist[4 * lane + 1], c2 = S.hist[4 * lane + 2],
+                               c3 = S.hist[4 * lane + 3];
+            const unsigned int tot = c0 + c1 + c2 + c3;
+            const unsigned int inc = wave_scan_u32(tot);
+            const unsigned long long ball = __ballot(inc > k);
+            const int L = __ffsll((long long)ball) - 1;
+            if (lane == L) {
+                unsigned int kk = k - (inc - tot);
+                unsigned int bin, cnt;
+                if (kk < c0) { bin = 0; cnt = c0; }
+                else if ((kk -= c0) < c1) { bin = 1; cnt = c1; }
+                else if ((kk -= c1) < c2) { bin = 2; cnt = c2; }
+                else { kk -= c2; bin = 3; cnt = c3; }
+                S.sel_bin = 4 * L + bin;
+                S.sel_k = kk;
+                S.sel_cnt = cnt;
+                S.cand_n = 0;
+            }
+        }
+        __syncthreads();
+        k = S.sel_k;
+        const unsigned int cnt = S.sel_cnt;
+        pval |= ((unsigned long long)S.sel_bin) << shift;
+        pmask |= ((unsigned long long)dmask) << shift;
+        if (shift == 0) {
+            v1 = pval;  // every remaining candidate equals the prefix
+            done = true;
+        } else if (cnt <= (unsigned int)kSelectFinish) {
+            for (int p = tid; p < npix; p += B) {
+                const unsigned long long key = key_of(model[p]);
+                if ((key & pmask) == pval) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+            }
+            __syncthreads();
+            if (tid < (int)cnt) {
+                const unsigned long long mine = S.cand[tid];
+                unsigned int r = 0;
+                for (unsigned int j = 0; j < cnt; ++j) {
+                    const unsigned long long o = S.cand[j];
+                    r += (o < mine) || (o == mine && j < (unsigned int)tid);
+                }
+                if (r == k) S.sel_result[0] = mine;
+            }
+            __syncthreads();
+            v1 = S.sel_result[0];
+            done = true;
+        }
+        __syncthreads();
+    }
+    return v1;
+}
+
+#ifdef MSX_STAMPS
+__device__ unsigned long long g_med_stamps[65536 * 8];
+#define MED_STAMP(i) do { if (threadIdx.x == 0) g_med_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MED_STAMP(i) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// Exact np.median of v[0..npix) held in LDS, given the min / max keys of the vector.  All threads of
+// the block call it; S.hist[0..kBins) must be zero on entry (it is left dirty).
+//   1024 linear value bins between min and max (a monotone map, so ranks resolve bin by bin) -> block
+//   scan -> the <= 256 candidates of the median's bin are ranked all-pairs; the upper middle value
+//   comes from the same ranking or from the minimum of the higher bins.  Distributions that defeat
+//   the binning (heavy duplication, infinities) fall back to the bitwise radix select.
+// ------------------------------------------------------------------------------------------------
+struct NoSide {
+    __device__ __forceinline__ void operator()() const {}
+};
+// Per-element work that can ride along the median's first pass over the vector (it already reads every
+// element): process4() gets four (index, value, valid) triples, flush() publishes the wave partials
+// right before the pass's barrier.
+struct NoElem {
+    __device__ __forceinline__ void process4(const int (&)[4], const double (&)[4], const bool (&)[4]) {}
+    __device__ __forceinline__ void flush(BlockScratch &) {}
+};
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {  // l wave-uniform
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <class Side, class Elem>
+__device__ __forceinline__ double block_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
+                               BlockScratch &S, Side side, Elem &elem, bool *elem_done) {
+    bool side_done = false;  // `side` runs exactly once, preferably in the stage that keeps only wave 0 busy
+    *elem_done = false;
+    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    // k1 = lower middle rank (0-based); for even npix the median averages ranks k1 and k1+1.
+    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
+    const bool need_two = (npix & 1) == 0;
+    unsigned long long v1 = kmin, v2 = kmin;
+    if (kmin != kmax) {
+        const double vmin = val_of(kmin), vmax = val_of(kmax);
+        // monotone map value -> bin: (x - vmin) * scale is non-decreasing in x, so every key in a lower
+        // bin is <= every key in a higher bin and ranks can be resolved bin by bin.
+        const double scale = (double)kBins / (vmax - vmin);
+        const bool lin_ok = isfinite(scale) && scale > 0.0;
+        bool solved = false;
+        MED_STAMP(0);
+        if (lin_ok) {
+            for (int base = 0; base < npix; base += 4 * B) {  // 4 elements per trip: loads first, then use
+                int pp[4];
+                double xv[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = base + u * B + tid;
+                    ok[u] = p < npix;
+                    pp[u] = ok[u] ? p : npix - 1;
+                    xv[u] = model[pp[u]];
+                }
+                elem.process4(pp, xv, ok);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int bin = (int)((xv[u] - vmin) * scale);
+                    bin = bin > kBins - 1 ? kBins - 1 : bin;
+                    if (ok[u]) atomicAdd(&S.hist[bin], 1u);
+                }
+            }
+            elem.flush(S);
+            *elem_done = true;
+            __syncthreads();
+            MED_STAMP(1);
+            // bin scan by wave 0 alone (16 bins per lane + one wave scan); the other waves are idle here,
+            // so two of them do the walker's off-critical-path side work meanwhile
+            side();
+            side_done = true;
+            if (wave == 0) {
+                constexpr int per = kBins / kWave;
+                unsigned int own = 0;
+                const uint4 *h4 = reinterpret_cast<const uint4 *>(&S.hist[lane * per]);
+#pragma unroll
+                for (int i = 0; i < per / 4; ++i) {
+                    const uint4 h = h4[i];
+                    own += h.x + h.y + h.z + h.w;
+                }
+                const unsigned int inc = wave_scan_u32(own);
+                const unsigned int excl = inc - own;
+                if (own > 0 && excl <= k1 && k1 < excl + own) {  // exactly one lane
+                    unsigned int kk = k1 - excl;
+                    int bin = lane * per;
+                    unsigned int cnt = S.hist[bin];
+                    while (kk >= cnt) { kk -= cnt; ++bin; cnt = S.hist[bin]; }
+                    S.sel_bin = (unsigned int)bin;
+                    S.sel_k = kk;
+                    S.sel_cnt = cnt;
+                    S.cand_n = 0;
+                    S.has_second = 0;
+                }
+            }
+            __syncthreads();
+            MED_STAMP(2);
+            const unsigned int cnt = S.sel_cnt, kk = S.sel_k;
+            const int sel = (int)S.sel_bin;
+            if (cnt <= (unsigned int)kSelectFinish) {
+                // gather the candidates of the selected bin; keep the smallest key of the higher bins
+                unsigned long long above = ~0ull;
+                for (int base = 0; base < npix; base += 4 * B) {
+                    double xv[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = base + u * B + tid;
+                        ok[u] = p < npix;
+                        xv[u] = model[ok[u] ? p : npix - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int bin = (int)((xv[u] - vmin) * scale);
+                        bin = bin > kBins - 1 ? kBins - 1 : bin;
+                        const unsigned long long key = key_of(xv[u]);
+                        if (ok[u] && bin == sel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+                        else if (ok[u] && bin > sel && key < above) above = key;
+                    }
+                }
+                above = wave_min_u64(above);
+                if (lane == 0) S.above[wave] = above;
+                __syncthreads();
+                MED_STAMP(3);
+                if (cnt <= (unsigned int)kWave) {
+                    // all-pairs rank inside wave 0: one candidate per lane, the others arrive by readlane
+                    if (wave == 0) {
+                        const unsigned long long mine = lane < (int)cnt ? S.cand[lane] : ~0ull;
+                        unsigned int r = 0;
+                        for (int j = 0; j < (int)cnt; ++j) {
+                            const unsigned long long o = readlane_u64(mine, j);
+                            r += (o < mine) || (o == mine && j < lane);
+                        }
+                        if (lane < (int)cnt && r == kk) S.sel_result[0] = mine;
+                        if (lane < (int)cnt && r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
+                    }
+                } else if (tid < (int)cnt) {  // all-pairs rank through LDS, ties broken by slot
+                    const unsigned long long mine = S.cand[tid];
+                    unsigned int r = 0;
+                    for (unsigned int j = 0; j < cnt; ++j) {
+                        const unsigned long long o = S.cand[j];
+                        r += (o < mine) || (o == mine && j < (unsigned int)tid);
+                    }
+                    if (r == kk) S.sel_result[0] = mine;
+                    if (r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
+                }
+                __syncthreads();
+                MED_STAMP(4);
+#ifdef MSX_STAMPS
+                if (tid == 0) g_med_stamps[blockIdx.x * 8 + 6] = cnt;
+#endif
+                v1 = S.sel_result[0];
+                if (S.has_second) {
+                    v2 = S.sel_result[1];
+                } else {
+                    v2 = S.above[0];
+                    for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+                }
+                solved = true;
+            }
+        }
+        if (!solved) {  // adversarial value distribution: bitwise radix select (always terminates)
+            __syncthreads();
+            v1 = radix_select(model, npix, k1, kmin, kmax, S);
+            v2 = v1;
+            if (need_two) {
+                // rank k1+1: equals v1 when v1 is duplicated past rank k1, else the smallest key above v1
+                unsigned int cle = 0;
+                unsigned long long nxt = ~0ull;
+                for (int p = tid; p < npix; p += B) {
+                    const unsigned long long key = key_of(model[p]);
+                    cle += key <= v1;
+                    if (key > v1 && key < nxt) nxt = key;
+                }
+                if (tid == 0) S.cnt_le = 0;
+                __syncthreads();
+                const unsigned int wc0 = wave_scan_u32(cle);
+                const unsigned int wc = (unsigned int)__builtin_amdgcn_readlane((int)wc0, 63);
+                nxt = wave_min_u64(nxt);
+                if (lane == 0) { atomicAdd(&S.cnt_le, wc); S.above[wave] = nxt; }
+                __syncthreads();
+                v2 = S.above[0];
+                for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+                if (S.cnt_le >= k1 + 2) v2 = v1;
+            }
+        }
+    }
+    // np.median: mean of the two middle values for even npix
+    if (!side_done) side();
+    return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same exact median when the histogram was filled DURING phase A.  That needs a bin map that does not
+// depend on the vector's min / max: for positive finite doubles the low 3 exponent bits and the top 8
+// mantissa bits (256 logarithmic sub-bins per binade, cyclic in the exponent).  The map is monotone along the
+// cycle starting at min's bin as long as the vector spans < 8 binades, which is checked here from min / max
+// (anything else -- zeros, negatives, infinities, huge ranges -- returns false and the caller takes
+// block_median).  On entry: S.hist complete (a barrier has passed), S.cand_n == 0, S.has_second == 0.
+//   every wave scans the 2048 counters itself (no publish, no barrier) -> ONE pass over the vector does the
+//   chi^2 terms (elem) and gathers the median bin's candidates -> barrier -> wave 0 ranks the candidates in
+//   registers.  The result is valid in wave 0 only (its lane 0 finishes the walker): no closing barrier.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int logbin(double x) {
+    return ((unsigned int)__double2hiint(x) >> 12) & (unsigned int)(kLogBins - 1);
+}
+
+template <class Elem>
+__device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
+                                              BlockScratch &S, Elem &elem, double *med_out) {
+    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
+    const bool need_two = (npix & 1) == 0;
+    if (!(kmin > key_of(0.0)) || kmin == kmax) return false;
+    const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
+    const unsigned int hmax = (unsigned int)__double2hiint(val_of(kmax)) >> 12;
+    constexpr int per = kLogBins / kWave;  // counters per lane in the scan
+    // scan origin: min's bin rounded down to a lane's group, so no group straddles the end of the array
+    const unsigned int a = (hmin & (unsigned int)(kLogBins - 1)) & ~(unsigned int)(per - 1);
+    if ((hmax - hmin) + (hmin & (unsigned int)(per - 1)) >= (unsigned int)kLogBins) return false;  // the cycle would lap itself
+    MED_STAMP(0);
+    MED_STAMP(1);
+    // ---- per-wave scan: lane l owns the `per` counters from physical bin (a + per*l) mod kLogBins ----------
+    const unsigned int phys = (a + (unsigned int)(per * lane)) & (unsigned int)(kLogBins - 1);
+    unsigned int own = 0;
+    {
+        const uint4 *h4 = reinterpret_cast<const uint4 *>(&S.hist[phys]);
+#pragma unroll
+        for (int i = 0; i < per / 4; ++i) {
+            const uint4 h = h4[i];
+            own += h.x + h.y + h.z + h.w;
+        }
+    }
+    const unsigned int inc = wave_scan_u32(own);
+    const unsigned int excl = inc - own;
+    const bool mine_it = own > 0 && excl <= k1 && k1 < excl + own;      // exactly one lane (total = npix > k1)
+    const int L = uni(__ffsll((long long)__ballot(mine_it)) - 1);
+    // second level, again on the whole wave: lane j < per takes counter j of lane L's group
+    const unsigned int phys_l = (unsigned int)__builtin_amdgcn_readlane((int)phys, L);
+    const unsigned int t = k1 - (unsigned int)__builtin_amdgcn_readlane((int)excl, L);
+    const unsigned int c = lane < per ? S.hist[phys_l + lane] : 0u;
+    const unsigned int inc2 = wave_scan_u32(c);
+    const int J = uni(__ffsll((long long)__ballot(c > 0 && inc2 - c <= t && t < inc2)) - 1);
+    const unsigned int kk = t - (unsigned int)__builtin_amdgcn_readlane((int)(inc2 - c), J);
+    const unsigned int cnt = (unsigned int)__builtin_amdgcn_readlane((int)c, J);
+    const unsigned int lsel = (phys_l + (unsigned int)J - a) & (unsigned int)(kLogBins - 1);
+    if (cnt > (unsigned int)kSelectFinish) return false;  // heavy duplication: the general path sorts it out
+    MED_STAMP(2);
+    // ---- one pass: chi^2 terms + candidates of the median's bin + smallest key of the later bins -----------
+    unsigned long long above = ~0ull;
+    for (int base = 0; base < npix; base += 4 * B) {
+        int pp[4];
+        double xv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + u * B + tid;
+            ok[u] = p < npix;
+            pp[u] = ok[u] ? p : npix - 1;
+            xv[u] = model[pp[u]];
+        }
+        elem.process4(pp, xv, ok);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int lx = (logbin(xv[u]) - a) & (unsigned int)(kLogBins - 1);
+            const unsigned long long key = key_of(xv[u]);
+            if (ok[u] && lx == lsel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
+            else if (ok[u] && lx > lsel && key < above) above = key;
+        }
+    }
+    elem.flush(S);
+    above = wave_min_u64(above);
+    if (lane == 0) S.above[wave] = above;
+    __syncthreads();
+    MED_STAMP(3);
+    // ---- rank.  Up to 64 candidates (the usual case): wave 0 alone, in registers, and only wave 0 (whose lane 0
+    // finishes the walker) learns the median -- no further barrier.  More: the first waves through LDS.
+    unsigned long long v1 = 0, v2 = 0;
+    bool second = false;
+    if (cnt <= (unsigned int)kWave) {
+        if (wave == 0) {
+            // one candidate per lane; the others arrive as LDS broadcast reads, eight per trip.  Counting the keys
+            // below and not above a candidate pins its VALUE's rank interval [lt, le), which is all the median needs
+            // (duplicates share a value), so no tie-break by slot.  Pad slots hold ~0 and rank last.
+            if (lane < 8) S.cand[cnt + lane] = ~0ull;   // same wave: LDS operations execute in order
+            const unsigned long long mine = S.cand[lane < (int)cnt ? lane : (int)cnt];
+            unsigned int lt = 0, le = 0;
+            const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(S.cand);
+            for (int j = 0; j < (int)cnt; j += 8) {
+                ulonglong2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = c2[(j >> 1) + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lt += (x[u].x < mine) + (x[u].y < mine);
+                    le += (x[u].x <= mine) + (x[u].y <= mine);
+                }
+            }
+            const unsigned long long b1 = __ballot(lane < (int)cnt && lt <= kk && kk < le);
+            const unsigned long long b2 = __ballot(lane < (int)cnt && lt <= kk + 1 && kk + 1 < le);
+            v1 = readlane_u64(mine, uni(__ffsll((long long)b1) - 1));
+            second = b2 != 0ull;
+            if (second) v2 = readlane_u64(mine, uni(__ffsll((long long)b2) - 1));
+        }
+    } else {
+        if (tid < (int)cnt) {
+            const unsigned long long mine = S.cand[tid];
+            unsigned int r = 0;
+            for (unsigned int j = 0; j < cnt; ++j) {
+                const unsigned long long o = S.cand[j];
+                r += (o < mine) || (o == mine && j < (unsigned int)tid);
+            }
+            if (r == kk) S.sel_result[0] = mine;
+            if (r == kk + 1) { S.sel_result[1] = mine; S.has_second = 1; }
+        }
+        __syncthreads();
+        v1 = S.sel_result[0];
+        second = S.has_second != 0;
+        if (second) v2 = S.sel_result[1];
+    }
+    MED_STAMP(4);
+#ifdef MSX_STAMPS
+    if (tid == 0) g_med_stamps[blockIdx.x * 8 + 6] = cnt;
+#endif
+    if (!second) {
+        v2 = S.above[0];
+        for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
+    }
+    *med_out = need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+    return true;
+}
+
+}  // namespace
+
+#endif  // MSX_MEDIAN_H

@@ -1,0 +1,592 @@
+// recipe.h -- part of the single translation unit msx.hip (included there, in this order).
+// phase 0 of the hot kernel: prior gates, isochrone lookup, node brackets, bilinear weights, prior and band terms (generic memory-walking form and the register-resident wave form).
+#ifndef MSX_RECIPE_H
+#define MSX_RECIPE_H
+
+namespace {
+
+// mft6.py:439-453 / :467-477.  Nearest node first (first index on ties), then its neighbour on the
+// other side; Python index semantics: -1 wraps to the last node, == n is an IndexError.
+__device__ int bracket_nodes(const double *nodes, int n, double v, int *i1, int *i2) {
+    int best = 0;
+    double bd = fabs(nodes[0] - v);
+    for (int i = 1; i < n; ++i) {
+        double d = fabs(nodes[i] - v);
+        if (d < bd) { bd = d; best = i; }
+    }
+    int other;
+    if (nodes[best] == v) other = best;
+    else if (nodes[best] > v) other = best - 1;
+    else other = best + 1;
+    if (other == -1) other = n - 1;
+    if (other >= n) return MSX_W_INDEXERROR;
+    *i1 = best;
+    *i2 = other;
+    return MSX_W_OK;
+}
+
+// Build the corner list + weights for every star (A2 + A4) and the band terms (A5/A6).
+// Executed by ONE lane.  rad[] is the reference's rad_guess = [R1, R2/R1, (R3/R1)].
+__device__ void build_desc(const DevProblem &P, const double *teff, const double *logg, const double *rad,
+                           bool use_distance, double plx, double a_v, WalkerDesc *D) {
+    const int ns = P.nspec;
+    D->status = MSX_W_OK;
+    D->ncorner = ns * 4;
+    double starscale[MSX_MAX_SPEC];
+    for (int s = 0; s < ns; ++s) {
+        int t1, t2, g1, g2;
+        int st = bracket_nodes(P.teff_nodes, P.nt, teff[s], &t1, &t2);
+        if (st == MSX_W_OK) st = bracket_nodes(P.logg_nodes, P.ng, logg[s], &g1, &g2);
+        if (st != MSX_W_OK) { D->status = st; return; }
+        // the reference looks up all four keys unless both axes are on-node (mft6.py:488-500)
+        int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+        if (!P.present[n11] || !P.present[n12] || !P.present[n21] || !P.present[n22]) {
+            D->status = MSX_W_KEYERROR;
+            return;
+        }
+        double a = (g1 == g2) ? 0.0 : (logg[s] - P.logg_nodes[g1]) / (P.logg_nodes[g2] - P.logg_nodes[g1]);
+        double b = (t1 == t2) ? 0.0 : (teff[s] - P.teff_nodes[t1]) / (P.teff_nodes[t2] - P.teff_nodes[t1]);
+        double sc;
+        if (use_distance) {
+            double di = 1.0 / plx;  // mft6.py:690
+            double r = (s == 0) ? rad[0] : rad[0] * rad[s];
+            double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+            sc = q * q;
+        } else {
+            sc = (s == 0) ? 1.0 : rad[s - 1] * rad[s - 1];  // mft6.py:703
+        }
+        starscale[s] = sc;
+        D->node[4 * s + 0] = n11; D->w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
+        D->node[4 * s + 1] = n12; D->w[4 * s + 1] = (1.0 - b) * a * sc;
+        D->node[4 * s + 2] = n21; D->w[4 * s + 2] = b * (1.0 - a) * sc;
+        D->node[4 * s + 3] = n22; D->w[4 * s + 3] = b * a * sc;
+    }
+    (void)starscale;
+    const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
+    D->redc = redden ? -0.4 * kLog2Of10 * a_v : 0.0;
+    const int nb = P.nc + P.np;
+    double chi = 0.0;
+    // contrasts: instrumental magnitude of each star through each filter (A5)
+    for (int f = 0; f < P.nc; ++f) {
+        double mag[MSX_MAX_SPEC];
+        for (int s = 0; s < ns; ++s) {
+            double m = 0.0;
+            for (int c = 0; c < 4; ++c) m += D->w[4 * s + c] * P.band_tab[(int64_t)D->node[4 * s + c] * nb + f];
+            mag[s] = -2.5 * log10(m);  // mft6.py:733
+        }
+        int sec = 1;
+        if (ns == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+        double con = mag[sec] - mag[0];
+        D->contrast[f] = con;
+        double z = (con - P.cmag[f]);
+        chi += (z * z) / (P.cerr[f] * P.cerr[f]);  // mft6.py:120,1182
+    }
+    // unresolved photometry of the composite (A6) + reddening of the magnitudes (mft6.py:1163)
+    for (int f = 0; f < P.np; ++f) {
+        double flux = 0.0;
+        for (int c = 0; c < ns * 4; ++c) flux += D->w[c] * P.band_tab[(int64_t)D->node[c] * nb + P.nc + f];
+        double mag = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+        D->phot[f] = mag;
+        double mred = redden ? mag + a_v * P.pk[f] : mag;
+        double z = mred - P.pmag[f];
+        chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
+    }
+    D->chi_extra = chi;
+}
+
+// The hard gates of logprior (a value of -inf, not an error) for theta = [T.., A_V, R1, ratios.., plx]:
+//   dist_fit, binary   : T box, every radius entry >= 0.05, R1 <= 1.5, 1/3000 <= plx <= 1/4   mft6.py:1227
+//   dist_fit, triple   : T box, every radius entry >= 0.05, 1/1000 <= plx <= 1/4               mft6.py:1347
+//   no dist_fit, binary: T box, both radius entries >= 0.05                                    mft6.py:1286
+//   no dist_fit, triple: T box, the two RATIOS >= 0.05 (R1 is not tested), plx >= 0            mft6.py:1411
+//   and A_V >= 0 whenever extinction is fitted                                                 mft6.py:1229
+template <int NS>
+__device__ __forceinline__ bool prior_gates(const DevProblem &P, const double *t) {
+    const double a_v = t[NS], plx = t[2 * NS + 1];
+    const double *rad = t + NS + 1;
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ok = ok && !(t[s] > P.tmax) && !(t[s] < P.tmin);
+    if (P.dist_fit) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ok = ok && !(rad[s] < 0.05);
+        if (NS == 2) ok = ok && !(rad[0] > 1.5) && !(plx < 1.0 / 3000) && !(plx > 1.0 / 4);
+        else ok = ok && !(plx < 1.0 / 1000) && !(plx > 1.0 / 4);
+    } else if (NS == 2) {
+        ok = ok && !(rad[0] < 0.05) && !(rad[1] < 0.05);
+    } else {
+#pragma unroll
+        for (int s = 1; s < NS; ++s) ok = ok && !(rad[s] < 0.05);
+        ok = ok && !(plx < 0.0);
+    }
+    if (P.use_av) ok = ok && !(a_v < 0.0);
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-parallel recipe helpers (phase 0 of the hot kernel runs on wave 0, all 64 lanes)
+// ------------------------------------------------------------------------------------------------
+// number of entries of the sorted table xs[0..n) that are <= x (an upper_bound), 64 entries per step
+__device__ __forceinline__ int wave_count_le(const double *__restrict__ xs, int n, double x, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += kWave) {
+        const int i = base + lane;
+        const bool pred = (i < n) && (xs[i] <= x);
+        cnt += __popcll(__ballot(pred));
+    }
+    return cnt;
+}
+
+// np.interp on a sorted table given cnt = #{xs <= x}; caller has checked xs[0] <= x <= xs[n-1]
+__device__ __forceinline__ double interp_from_count(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                    int n, double x, int cnt) {
+    const int j = cnt - 1;
+    if (j >= n - 1) return ys[n - 1];
+    const double x0 = xs[j], y0 = ys[j];
+    if (x0 == x) return y0;
+    const double slope = (ys[j + 1] - y0) / (xs[j + 1] - x0);
+    return slope * (x - x0) + y0;
+}
+
+// mft6.py:439-453 / :467-477 for SORTED, unique node values (staging sorts them; so does the
+// reference, :436,:457-465): the nearest node is one of the two neighbours of v, ties go to the lower
+// index like argmin; then the neighbour on the other side of v.  Python index semantics as in
+// bracket_nodes(): -1 wraps to the last node, == n is an IndexError.
+__device__ __forceinline__ int wave_bracket(const double *__restrict__ nodes, int n, double v, int lane, int *i1,
+                                            int *i2, double *e1, double *e2) {
+    const int j = wave_count_le(nodes, n, v, lane) - 1;  // nodes[j] <= v < nodes[j+1]
+    int best;
+    if (j < 0) best = 0;
+    else if (j >= n - 1) best = n - 1;
+    else best = (fabs(nodes[j + 1] - v) < fabs(nodes[j] - v)) ? j + 1 : j;
+    const double nb = nodes[best];
+    int other;
+    if (nb == v) other = best;
+    else if (nb > v) other = best - 1;
+    else other = best + 1;
+    if (other == -1) other = n - 1;
+    if (other >= n) return MSX_W_INDEXERROR;
+    *i1 = best;
+    *i2 = other;
+    *e1 = nb;
+    *e2 = nodes[other];
+    return MSX_W_OK;
+}
+
+// The small lookup tables of phase 0.  The hot kernel copies them into LDS (into the region that later
+// holds the model vector) with all threads at once, so the recipe's dependent lookups cost an LDS
+// round trip (~100 cycles) instead of an L2/MALL one (~500+); pointers are generic on purpose.
+struct RecipeTabs {
+    const double *iso_t, *iso_g, *iso_l, *av_edges, *av_mu, *av_sig, *teff_nodes, *logg_nodes;
+};
+
+// Phase 0 on wave 0: prior gate (f1), A1, A2, A4 weights, A5/A6 band terms.  Writes D (LDS).
+template <int NS>
+__device__ __forceinline__ void build_recipe_wave(const DevProblem &P, const RecipeTabs &T, int mode, const double *__restrict__ th,
+                                  int ndim, WalkerDesc &D, int lane, int64_t wk) {
+    double t[2 * NS + 2];
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) {
+        t[k] = th[k];
+        alive = alive && isfinite(t[k]);  // emcee refuses non-finite coordinates anyway
+    }
+    const double a_v = t[NS];
+    const double plx = t[2 * NS + 1];
+    const double *rad = &t[NS + 1];
+    int st = MSX_W_OK;
+    double lp = 0.0;
+    if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) {
+        alive = alive && prior_gates<NS>(P, t);
+        if (alive && P.use_av) {
+            if (P.nav > 0) {
+                const double d = 1.0 / plx;  // pc, mft6.py:1233
+                int b = wave_count_le(T.av_edges, P.nav + 1, d, lane) - 1;
+                b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
+                double sig = T.av_sig[b];
+                if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
+                const double z = (a_v - T.av_mu[b]) / sig;
+                lp += -0.5 * (z * z);
+            }
+        }
+        if (alive && P.has_prior) {
+#pragma clang loop unroll(full)
+            for (int k = 0; k < 2 * NS + 2; ++k) {
+                if (P.pmean[k] != 0.0) {  // mft6.py:1258
+                    const double z = (t[k] - P.pmean[k]) / P.psig[k];
+                    lp += -0.5 * (z * z);
+                }
+            }
+        }
+        if (alive && P.rad_prior) {  // mft6.py:1262-1269
+            double mr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!(t[s] >= T.iso_t[0]) || !(t[s] <= T.iso_t[P.niso - 1])) { st = MSX_W_VALUEERROR; mr[s] = 1.0; continue; }
+                const int cnt = wave_count_le(T.iso_t, P.niso, t[s], lane);
+                const double lum = interp_from_count(T.iso_t, T.iso_l, P.niso, t[s], cnt);
+                const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
+                const double t2 = t[s] * t[s];
+                mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double target = (s == 0) ? mr[0] : mr[s] / mr[0];
+                const double z = (rad[s] - target) / (0.02 * target);
+                lp += -0.5 * (z * z);
+            }
+        }
+    }
+    if (st != MSX_W_OK || !alive) {
+        if (lane == 0) D.status = (st != MSX_W_OK) ? st : MSX_W_REJECT;
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {
+        if (lane == 0) { D.lp = lp; D.status = MSX_W_OK; }
+        return;
+    }
+    // A1 + A2 + A4
+    int node[NS * 4];
+    double w[NS * 4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!(t[s] >= T.iso_t[0]) || !(t[s] <= T.iso_t[P.niso - 1])) { st = MSX_W_VALUEERROR; break; }
+        const int cnt = wave_count_le(T.iso_t, P.niso, t[s], lane);
+        const double lg = interp_from_count(T.iso_t, T.iso_g, P.niso, t[s], cnt);  // mft6.py:1149
+        int t1, t2, g1, g2;
+        double te1, te2, ge1, ge2;
+        st = wave_bracket(T.teff_nodes, P.nt, t[s], lane, &t1, &t2, &te1, &te2);
+        if (st == MSX_W_OK) st = wave_bracket(T.logg_nodes, P.ng, lg, lane, &g1, &g2, &ge1, &ge2);
+        if (st != MSX_W_OK) break;
+        const int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+        if (!P.present[n11] || !P.present[n12] || !P.present[n21] || !P.present[n22]) { st = MSX_W_KEYERROR; break; }
+        const double a = (g1 == g2) ? 0.0 : (lg - ge1) / (ge2 - ge1);
+        const double b = (t1 == t2) ? 0.0 : (t[s] - te1) / (te2 - te1);
+        const double di = 1.0 / plx;  // mft6.py:690
+        const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
+        const double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+        const double sc = q * q;
+        node[4 * s + 0] = n11; w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
+        node[4 * s + 1] = n12; w[4 * s + 1] = (1.0 - b) * a * sc;
+        node[4 * s + 2] = n21; w[4 * s + 2] = b * (1.0 - a) * sc;
+        node[4 * s + 3] = n22; w[4 * s + 3] = b * a * sc;
+    }
+    if (st != MSX_W_OK) {
+        if (lane == 0) D.status = st;
+        return;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NS * 4; ++c) { D.node[c] = node[c]; D.w[c] = w[c]; }
+    }
+    // same-wave LDS hand-off (lane 0 -> all lanes): LDS ops of one wave complete in order; the fence
+    // keeps the compiler from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // A5/A6: one (filter, star) or one photometric band per lane; magnitudes land in LDS
+    const bool redden = redden_rule(mode, P.use_av, a_v);
+    const int nb = P.nc + P.np;
+    const int njobs = P.nc * NS + P.np;
+    if (lane < njobs) {
+        double val;
+        if (lane < P.nc * NS) {
+            const int f = lane / NS, s = lane - f * NS;
+            double m = 0.0;
+            for (int c = 0; c < 4; ++c) m += D.w[4 * s + c] * P.band_tab[(int64_t)D.node[4 * s + c] * nb + f];
+            val = -2.5 * log10(m);  // mft6.py:733
+        } else {
+            const int f = lane - P.nc * NS;
+            double flux = 0.0;
+            for (int c = 0; c < NS * 4; ++c) flux += D.w[c] * P.band_tab[(int64_t)D.node[c] * nb + P.nc + f];
+            val = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+        }
+        D.mag[lane] = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double chi = 0.0;
+        for (int f = 0; f < P.nc; ++f) {
+            int sec = 1;
+            if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+            const double con = D.mag[f * NS + sec] - D.mag[f * NS];  // mft6.py:741
+            const double z = con - P.cmag[f];
+            chi += (z * z) / (P.cerr[f] * P.cerr[f]);  // mft6.py:120,1182
+        }
+        for (int f = 0; f < P.np; ++f) {
+            const double mag = D.mag[P.nc * NS + f];
+            const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
+            const double z = mred - P.pmag[f];
+            chi += (z * z) / (P.perr[f] * P.perr[f]);  // mft6.py:1188
+        }
+        D.chi_extra = chi;
+        D.redc = redden ? -0.4 * kLog2Of10 * a_v : 0.0;
+        D.lp = lp;
+        D.status = MSX_W_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 0, fast form: every small table is loaded ONCE into registers of wave 0 (one batch of
+// independent loads), searches are ballots on registers and element fetches are v_readlane with a
+// uniform index -- no dependent memory round trips.  Same arithmetic as build_recipe_wave.
+// Limits (checked by the caller): niso <= 256, nt, ng <= 64, nt*ng <= 128, nav+1 <= 128.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pick4(const double (&r)[4], int idx) {  // idx uniform, 0..255
+    const int k = idx >> 6;
+    const double v = (k == 0) ? r[0] : (k == 1) ? r[1] : (k == 2) ? r[2] : r[3];
+    return readlane_f64(v, idx & 63);
+}
+__device__ __forceinline__ double pick2(const double (&r)[2], int idx) {  // idx uniform, 0..127
+    return readlane_f64((idx >> 6) ? r[1] : r[0], idx & 63);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// np.interp on the register-resident isochrone; caller checked the range
+__device__ __forceinline__ double iso_interp_regs(const double (&xs)[4], const double (&ys)[4], int n, double x) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(xs[k] <= x));  // pads are +inf
+    const int j = uni(cnt) - 1;
+    if (j >= n - 1) return pick4(ys, n - 1);
+    const double x0 = pick4(xs, j), y0 = pick4(ys, j);
+    if (x0 == x) return y0;
+    const double slope = (pick4(ys, j + 1) - y0) / (pick4(xs, j + 1) - x0);
+    return slope * (x - x0) + y0;
+}
+
+// sorted-node bracket on a register-resident node list (lane i holds nodes[i], pads +inf)
+__device__ __forceinline__ int bracket_regs(double nodes, int n, double v, int *i1, int *i2, double *e1, double *e2) {
+    const int j = uni(__popcll(__ballot(nodes <= v))) - 1;
+    int best;
+    if (j < 0) best = 0;
+    else if (j >= n - 1) best = n - 1;
+    else best = (fabs(readlane_f64(nodes, j + 1) - v) < fabs(readlane_f64(nodes, j) - v)) ? j + 1 : j;
+    best = uni(best);
+    const double nb = readlane_f64(nodes, best);
+    int other;
+    if (nb == v) other = best;
+    else if (nb > v) other = best - 1;
+    else other = best + 1;
+    if (other == -1) other = n - 1;
+    if (other >= n) return MSX_W_INDEXERROR;
+    other = uni(other);
+    *i1 = best;
+    *i2 = other;
+    *e1 = nb;
+    *e2 = readlane_f64(nodes, other);
+    return MSX_W_OK;
+}
+
+// Part 1 (gates phase A): finite + box check, A1 logg, A2 brackets, A4 weights.  Wave 0, before the
+// first barrier.  Writes D.node, D.w, D.redc, D.status.
+template <int NS>
+__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, int mode, const double *__restrict__ th, WalkerDesc &D,
+                                  int lane, int64_t wk, const int star) {
+    // one wave per star (wave `star` of the block): the two or three dependent lookup chains run side by
+    // side; every wave evaluates the (cheap) gates itself and reports through D.stat[star]
+    // ---- one batch of independent loads -------------------------------------------------------------
+    double t[2 * NS + 2];
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) t[k] = th[k];
+    double isot[4], isog[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + kWave * k;
+        const bool ok = i < P.niso;
+        isot[k] = ok ? P.iso_t[i] : INFINITY;
+        isog[k] = ok ? P.iso_g[i] : 0.0;
+    }
+    const double tn = lane < P.nt ? P.teff_nodes[lane] : INFINITY;
+    const double gn = lane < P.ng ? P.logg_nodes[lane] : INFINITY;
+    const int nn = P.nt * P.ng;
+    const int pres0 = lane < nn ? (int)P.present[lane] : 0;
+    const int pres1 = lane + kWave < nn ? (int)P.present[lane + kWave] : 0;
+    MSX_STAMP(P, wk, 9);
+    // ---- the hard gates of the prior (mft6.py:1227-1230 binary, :1347-1350 triple) -----------------------
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(t[k]);  // emcee refuses non-finite coords
+    const double a_v = t[NS];
+    const double plx = t[2 * NS + 1];
+    const double *rad = &t[NS + 1];
+    if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
+        alive = alive && prior_gates<NS>(P, t);
+    }
+    if (!alive) {
+        if (lane == 0) D.stat[star] = MSX_W_REJECT;
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {  // no spectrum pass: the prior terms finish the job
+        if (lane == 0) D.stat[star] = MSX_W_OK;
+        return;
+    }
+    MSX_STAMP(P, wk, 10);
+    // ---- A1 + A2 + A4 -----------------------------------------------------------------------------------
+    const double iso_lo = pick4(isot, 0), iso_hi = pick4(isot, P.niso - 1);
+    int st = MSX_W_OK;
+    int node[4];
+    double w[4];
+    const double di = 1.0 / plx;  // mft6.py:690
+    {
+        const int s = star;
+        do {
+            if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; break; }
+            const double lg = iso_interp_regs(isot, isog, P.niso, t[s]);  // mft6.py:1149
+            int t1, t2, g1, g2;
+            double te1, te2, ge1, ge2;
+            st = bracket_regs(tn, P.nt, t[s], &t1, &t2, &te1, &te2);
+            if (st == MSX_W_OK) st = bracket_regs(gn, P.ng, lg, &g1, &g2, &ge1, &ge2);
+            if (st != MSX_W_OK) break;
+            const int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+            bool have = true;
+            const int four[4] = {n11, n12, n21, n22};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int nd = uni(four[c]);
+                have = have && (__builtin_amdgcn_readlane(nd < kWave ? pres0 : pres1, nd & 63) != 0);
+            }
+            if (!have) { st = MSX_W_KEYERROR; break; }
+            const double a = (g1 == g2) ? 0.0 : (lg - ge1) / (ge2 - ge1);
+            const double b = (t1 == t2) ? 0.0 : (t[s] - te1) / (te2 - te1);
+            const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
+            const double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+            const double sc = q * q;
+            node[0] = n11; w[0] = (1.0 - b) * (1.0 - a) * sc;
+            node[1] = n12; w[1] = (1.0 - b) * a * sc;
+            node[2] = n21; w[2] = b * (1.0 - a) * sc;
+            node[3] = n22; w[3] = b * a * sc;
+        } while (false);
+    }
+    if (lane == 0) {
+        if (st == MSX_W_OK) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { D.node[4 * star + c] = node[c]; D.w[4 * star + c] = w[c]; }
+            if (star == 0) D.redc = redden_rule(mode, P.use_av, a_v) ? -0.4 * kLog2Of10 * a_v : 0.0;
+        }
+        D.stat[star] = st;
+    }
+    MSX_STAMP(P, wk, 11);
+}
+
+// Part 2 (off the critical path): the Gaussian prior terms (f1) and the contrast / photometry chi^2
+// (A5/A6).  They are only read by the last lines of the kernel, so two otherwise idle waves compute
+// them during the median's bin-scan stage (which keeps only wave 0 busy).  Both re-read theta and the
+// small tables (L2 hits) instead of carrying registers across phase A.
+template <int NS>
+__device__ __forceinline__ void recipe_prior_terms(const DevProblem &P, int mode, const double *__restrict__ th, WalkerDesc &D,
+                                   int lane) {
+    double t[2 * NS + 2];
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) t[k] = th[k];
+    const double a_v = t[NS];
+    const double plx = t[2 * NS + 1];
+    const double *rad = &t[NS + 1];
+    double lp = 0.0;
+    int st = MSX_W_OK;
+    if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
+        if (P.use_av && P.nav > 0) {
+            double ave[2], avm[2], avs[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = lane + kWave * k;
+                ave[k] = (i < P.nav + 1) ? P.av_edges[i] : INFINITY;
+                avm[k] = (i < P.nav) ? P.av_mu[i] : 0.0;
+                avs[k] = (i < P.nav) ? P.av_sig[i] : 0.0;
+            }
+            const double d = 1.0 / plx;  // pc, mft6.py:1233
+            int b = uni(__popcll(__ballot(ave[0] <= d)) + __popcll(__ballot(ave[1] <= d))) - 1;
+            b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
+            double sig = pick2(avs, b);
+            if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
+            const double z = (a_v - pick2(avm, b)) / sig;
+            lp += -0.5 * (z * z);
+        }
+        if (P.has_prior) {
+#pragma clang loop unroll(full)
+            for (int k = 0; k < 2 * NS + 2; ++k) {
+                if (P.pmean[k] != 0.0) {  // mft6.py:1258
+                    const double z = (t[k] - P.pmean[k]) / P.psig[k];
+                    lp += -0.5 * (z * z);
+                }
+            }
+        }
+        if (P.rad_prior) {  // mft6.py:1262-1269
+            double isot[4], isol[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + kWave * k;
+                const bool ok = i < P.niso;
+                isot[k] = ok ? P.iso_t[i] : INFINITY;
+                isol[k] = ok ? P.iso_l[i] : 0.0;
+            }
+            const double iso_lo = pick4(isot, 0), iso_hi = pick4(isot, P.niso - 1);
+            double mr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; mr[s] = 1.0; continue; }
+                const double lum = iso_interp_regs(isot, isol, P.niso, t[s]);
+                const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
+                const double t2 = t[s] * t[s];
+                mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double target = (s == 0) ? mr[0] : mr[s] / mr[0];
+                const double z = (rad[s] - target) / (0.02 * target);
+                lp += -0.5 * (z * z);
+            }
+        }
+    }
+    if (lane == 0) {
+        D.lp = lp;
+        if (mode == MSX_MODE_LOGPRIOR) D.status = st;  // only reachable there: part 1 range-checked Teff otherwise
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void recipe_band_terms(const DevProblem &P, int mode, const double *__restrict__ th, WalkerDesc &D,
+                                  int lane) {
+    const double a_v = th[NS];
+    const bool redden = redden_rule(mode, P.use_av, a_v);
+    const int nb = P.nc + P.np;
+    const int njobs = P.nc * NS + P.np;
+    double val = 0.0;
+    if (lane < njobs) {  // one (filter, star) or one photometric band per lane
+        if (lane < P.nc * NS) {
+            const int f = lane / NS, s = lane - f * NS;
+            double m = 0.0;
+            for (int c = 0; c < 4; ++c) m += D.w[4 * s + c] * P.band_tab[(int64_t)D.node[4 * s + c] * nb + f];
+            val = -2.5 * log10(m);  // mft6.py:733
+        } else {
+            const int f = lane - P.nc * NS;
+            double flux = 0.0;
+            for (int c = 0; c < NS * 4; ++c) flux += D.w[c] * P.band_tab[(int64_t)D.node[c] * nb + P.nc + f];
+            val = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+        }
+    }
+    double chi = 0.0;
+    for (int f = 0; f < P.nc; ++f) {
+        int sec = 1;
+        if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+        const double con = readlane_f64(val, f * NS + sec) - readlane_f64(val, f * NS);  // mft6.py:741
+        const double z = con - P.cmag[f];
+        chi += (z * z) * P.civar[f];  // mft6.py:120,1182
+    }
+    for (int f = 0; f < P.np; ++f) {
+        const double mag = readlane_f64(val, P.nc * NS + f);
+        const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
+        const double z = mred - P.pmag[f];
+        chi += (z * z) * P.pivar[f];  // mft6.py:1188
+    }
+    if (lane == 0) D.chi_extra = chi;
+}
+
+}  // namespace
+
+#endif  // MSX_RECIPE_H
