@@ -50,11 +50,22 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //      doubles of LDS).
 template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false>
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && U == 1) ? 2 : 1)
-logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
-               double *__restrict__ logp, int32_t *__restrict__ status) {
+logprob_kernel(const double *theta, const double *__restrict__ iso_t, const double *__restrict__ iso_g,
+               const double *__restrict__ teff_nodes, const double *__restrict__ logg_nodes,
+               const uint8_t *__restrict__ present, int niso_nt, int ng_mode_fast,
+               DevProblem P, int64_t n, int ndim, double *__restrict__ logp, int32_t *__restrict__ status) {
+    // The leading arguments (14 dwords) are compiled for KERNARG PRELOAD (-mllvm -amdgpu-kernarg-preload-count):
+    // the command processor delivers them in SGPRs at wave start, so theta and the recipe's small tables can be
+    // requested in the first instructions, ~1.5 us before the 1.2 KB DevProblem (fetched from the kernel-argument
+    // segment like any argument) is available.  They duplicate P.iso_t, ... and pack niso|nt<<16, ng|mode<<8|fast<<16.
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
     const int64_t wk = blockIdx.x;
+    const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
+    const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
+    const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
+    RecipeRegs RR;
+    if (fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, iso_t, iso_g, teff_nodes, logg_nodes, present, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
     const int tid = threadIdx.x;
@@ -100,9 +111,6 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
     }
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
-    // register-resident tables when they fit one wave (the usual case), else the generic walk
-    const bool fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave &&
-                      P.nav + 1 <= 2 * kWave;
     // Early-histogram path (logbin_median): the median's histogram is filled while phase A computes the model,
     // and the walker's prior terms move to an idle wave of phase 0.  Likelihood / posterior / chi^2 modes with
     // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
@@ -121,7 +129,7 @@ logprob_kernel(DevProblem P, int mode, const double *theta, int64_t n, int ndim,
         }
     }
     if (fast) {
-        if (wave < NS) recipe_part1_regs<NS>(P, mode, th_row, D, lane, wk, wave);
+        if (wave < NS) recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
     } else if (wave == 0) {
         const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
         build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);

@@ -600,6 +600,14 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (B != 256 && B != 512 && B != 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be 256, 512 or 1024");
     hipStream_t s = (hipStream_t)hip_stream;
     const size_t lds = sizeof(double) * (size_t)c->P.npix;
+    // the leading, preloaded kernel arguments (see logprob_kernel): theta, the recipe's small tables and three
+    // packed ints; `fast` = the tables fit the register-resident recipe
+    const DevProblem &Pc = c->P;
+    const bool fast = Pc.niso <= 4 * kWave && Pc.nt <= kWave && Pc.ng <= kWave && Pc.nt * Pc.ng <= 2 * kWave &&
+                      Pc.nav + 1 <= 2 * kWave;
+    const int niso_nt = (int)(std::min<int64_t>(Pc.niso, 0xffff) | ((int64_t)std::min<int64_t>(Pc.nt, 0x7fff) << 16));
+    const int ng_mode_fast = (int)std::min<int64_t>(Pc.ng, 0xff) | (mode << 8) | ((fast ? 1 : 0) << 16);
+#define MSX_LEAD_ARGS d_theta, Pc.iso_t, Pc.iso_g, Pc.teff_nodes, Pc.logg_nodes, Pc.present, niso_nt, ng_mode_fast
     if (c->model_in_global) {
         // long spectra: model vector in global memory, no dynamic LDS, 1024 threads.  The scratch grows on
         // demand (a synchronous hipMalloc: not capturable into a graph the first time a size is seen)
@@ -615,9 +623,9 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         c->P.model_scratch = c->d_model_scratch;
         const dim3 gg((unsigned)n), bb(1024);
         if (c->P.nspec == 2)
-            hipLaunchKernelGGL((logprob_kernel<2, 1, 1024, true>), gg, bb, 0, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+            hipLaunchKernelGGL((logprob_kernel<2, 1, 1024, true>), gg, bb, 0, s, MSX_LEAD_ARGS, c->P, n, ndim, d_logp, d_status);
         else
-            hipLaunchKernelGGL((logprob_kernel<3, 1, 1024, true>), gg, bb, 0, s, c->P, mode, d_theta, n, ndim, d_logp, d_status);
+            hipLaunchKernelGGL((logprob_kernel<3, 1, 1024, true>), gg, bb, 0, s, MSX_LEAD_ARGS, c->P, n, ndim, d_logp, d_status);
         HIP_TRY(c, hipGetLastError());
         return MSX_OK;
     }
@@ -628,7 +636,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // every variant is compiled for, and launched with, exactly its thread count (the canonical summation order
     // relies on it)
 #define MSX_GO(NS_, U_, T_, CP_, PF_, LDS_)                                                                           \
-    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, false, CP_, PF_>), g, b, (LDS_), s, c->P, mode, d_theta, n, ndim, \
+    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, false, CP_, PF_>), g, b, (LDS_), s, MSX_LEAD_ARGS, c->P, n, ndim, \
                        d_logp, d_status)
     const bool cp = c->P.pairs_c != nullptr;
     if (c->P.nspec == 2) {
@@ -645,6 +653,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         else MSX_GO(3, 1, 1024, false, false, lds);
     }
 #undef MSX_GO
+#undef MSX_LEAD_ARGS
     HIP_TRY(c, hipGetLastError());
     return MSX_OK;
 }

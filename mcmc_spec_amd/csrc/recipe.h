@@ -383,75 +383,77 @@ __device__ __forceinline__ int bracket_regs(double nodes, int n, double v, int *
     return MSX_W_OK;
 }
 
-// Part 1 (gates phase A): finite + box check, A1 logg, A2 brackets, A4 weights.  Wave 0, before the
-// first barrier.  Writes D.node, D.w, D.redc, D.status.
-template <int NS>
-__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, int mode, const double *__restrict__ th, WalkerDesc &D,
-                                  int lane, int64_t wk, const int star) {
-    // one wave per star (wave `star` of the block): the two or three dependent lookup chains run side by
-    // side; every wave evaluates the (cheap) gates itself and reports through D.stat[star]
-    // ---- one batch of independent loads -------------------------------------------------------------
-    double t[2 * NS + 2];
-#pragma unroll
-    for (int k = 0; k < 2 * NS + 2; ++k) t[k] = th[k];
-    double isot[4], isog[4];
+// The small tables of the register-resident recipe: loaded by the recipe waves in the kernel's very first
+// instructions, from pointers that arrive PRELOADED in SGPRs (the leading kernel arguments, see logprob_kernel),
+// so these loads do not wait for the 1.5 us fetch of the kernel-argument segment.
+struct RecipeRegs {
+    double isot[4], isog[4];  // isochrone Teff / logg, element i in lane i % 64 of register i / 64 (pads +inf / 0)
+    double tn, gn;            // Teff / logg node lists, one node per lane (pads +inf)
+    int pres0, pres1;         // presence mask of nodes 0..63 / 64..127
+};
+__device__ __forceinline__ void load_recipe_regs(RecipeRegs &R, const double *__restrict__ iso_t,
+                                                 const double *__restrict__ iso_g, const double *__restrict__ teff_nodes,
+                                                 const double *__restrict__ logg_nodes, const uint8_t *__restrict__ present,
+                                                 int niso, int nt, int ng, int lane) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = lane + kWave * k;
-        const bool ok = i < P.niso;
-        isot[k] = ok ? P.iso_t[i] : INFINITY;
-        isog[k] = ok ? P.iso_g[i] : 0.0;
+        const bool ok = i < niso;
+        R.isot[k] = ok ? iso_t[i] : INFINITY;
+        R.isog[k] = ok ? iso_g[i] : 0.0;
     }
-    const double tn = lane < P.nt ? P.teff_nodes[lane] : INFINITY;
-    const double gn = lane < P.ng ? P.logg_nodes[lane] : INFINITY;
-    const int nn = P.nt * P.ng;
-    const int pres0 = lane < nn ? (int)P.present[lane] : 0;
-    const int pres1 = lane + kWave < nn ? (int)P.present[lane + kWave] : 0;
-    MSX_STAMP(P, wk, 9);
-    // ---- the hard gates of the prior (mft6.py:1227-1230 binary, :1347-1350 triple) -----------------------
-    bool alive = true;
+    R.tn = lane < nt ? teff_nodes[lane] : INFINITY;
+    R.gn = lane < ng ? logg_nodes[lane] : INFINITY;
+    const int nn = nt * ng;
+    R.pres0 = lane < nn ? (int)present[lane] : 0;
+    R.pres1 = lane + kWave < nn ? (int)present[lane + kWave] : 0;
+}
+
+// Part 1 (gates phase A): A1 logg, A2 brackets, A4 weights, then the finite + box check.  One wave per star
+// (wave `star` of the block): the two or three dependent lookup chains run side by side; every wave evaluates the
+// (cheap) gates itself and reports through D.stat[star].  Writes D.node, D.w, D.redc, D.stat.
+// Order matters for latency, not for the result: everything up to the weights needs only theta and the tables
+// (preloaded pointers), so it runs while the rest of the kernel-argument segment -- which the gates read -- is
+// still in flight.  It is safe for any theta (no memory access depends on it; NaNs fail the range test), and the
+// gates still take precedence in the reported status, like logprior before loglikelihood in the reference.
+template <int NS>
+__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const RecipeRegs &R, int niso, int nt, int ng, int mode,
+                                  const double *__restrict__ th, WalkerDesc &D, int lane, int64_t wk, const int star) {
+    double t[2 * NS + 2];
 #pragma unroll
-    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(t[k]);  // emcee refuses non-finite coords
+    for (int k = 0; k < 2 * NS + 2; ++k) t[k] = th[k];
+    MSX_STAMP(P, wk, 9);
     const double a_v = t[NS];
     const double plx = t[2 * NS + 1];
     const double *rad = &t[NS + 1];
-    if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
-        alive = alive && prior_gates<NS>(P, t);
-    }
-    if (!alive) {
-        if (lane == 0) D.stat[star] = MSX_W_REJECT;
-        return;
-    }
-    if (mode == MSX_MODE_LOGPRIOR) {  // no spectrum pass: the prior terms finish the job
-        if (lane == 0) D.stat[star] = MSX_W_OK;
-        return;
-    }
-    MSX_STAMP(P, wk, 10);
     // ---- A1 + A2 + A4 -----------------------------------------------------------------------------------
-    const double iso_lo = pick4(isot, 0), iso_hi = pick4(isot, P.niso - 1);
+    const double iso_lo = pick4(R.isot, 0), iso_hi = pick4(R.isot, niso - 1);
     int st = MSX_W_OK;
-    int node[4];
-    double w[4];
+    int node[4] = {0, 0, 0, 0};
+    double w[4] = {0.0, 0.0, 0.0, 0.0};
     const double di = 1.0 / plx;  // mft6.py:690
     {
         const int s = star;
         do {
             if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; break; }
-            const double lg = iso_interp_regs(isot, isog, P.niso, t[s]);  // mft6.py:1149
+            const double lg = iso_interp_regs(R.isot, R.isog, niso, t[s]);  // mft6.py:1149
+            MSX_STAMP(P, wk, 12);
             int t1, t2, g1, g2;
             double te1, te2, ge1, ge2;
-            st = bracket_regs(tn, P.nt, t[s], &t1, &t2, &te1, &te2);
-            if (st == MSX_W_OK) st = bracket_regs(gn, P.ng, lg, &g1, &g2, &ge1, &ge2);
+            st = bracket_regs(R.tn, nt, t[s], &t1, &t2, &te1, &te2);
+            if (st == MSX_W_OK) st = bracket_regs(R.gn, ng, lg, &g1, &g2, &ge1, &ge2);
             if (st != MSX_W_OK) break;
-            const int n11 = t1 * P.ng + g1, n12 = t1 * P.ng + g2, n21 = t2 * P.ng + g1, n22 = t2 * P.ng + g2;
+            MSX_STAMP(P, wk, 13);
+            const int n11 = t1 * ng + g1, n12 = t1 * ng + g2, n21 = t2 * ng + g1, n22 = t2 * ng + g2;
             bool have = true;
             const int four[4] = {n11, n12, n21, n22};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int nd = uni(four[c]);
-                have = have && (__builtin_amdgcn_readlane(nd < kWave ? pres0 : pres1, nd & 63) != 0);
+                have = have && (__builtin_amdgcn_readlane(nd < kWave ? R.pres0 : R.pres1, nd & 63) != 0);
             }
             if (!have) { st = MSX_W_KEYERROR; break; }
+            MSX_STAMP(P, wk, 14);
             const double a = (g1 == g2) ? 0.0 : (lg - ge1) / (ge2 - ge1);
             const double b = (t1 == t2) ? 0.0 : (t[s] - te1) / (te2 - te1);
             const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
@@ -462,6 +464,22 @@ __device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, int mode,
             node[2] = n21; w[2] = b * (1.0 - a) * sc;
             node[3] = n22; w[3] = b * a * sc;
         } while (false);
+    }
+    MSX_STAMP(P, wk, 10);
+    // ---- the hard gates of the prior (mft6.py:1227-1230 binary, :1347-1350 triple) -----------------------
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(t[k]);  // emcee refuses non-finite coords
+    if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
+        alive = alive && prior_gates<NS>(P, t);
+    }
+    if (!alive) {
+        if (lane == 0) D.stat[star] = MSX_W_REJECT;
+        return;
+    }
+    if (mode == MSX_MODE_LOGPRIOR) {  // no spectrum pass: the prior terms finish the job
+        if (lane == 0) D.stat[star] = MSX_W_OK;
+        return;
     }
     if (lane == 0) {
         if (st == MSX_W_OK) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-clock shares of the hot kernel (build with -DMSX_STAMPS, never shipped).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=8 -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
     MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 256 --block 1024
 """
 import argparse
@@ -50,6 +50,9 @@ def main():
     de = np.diff(e, axis=1)
     for i, nm in enumerate(['stage tables+barrier', 'theta load', 'prior', 'iso+bracket', 'band loads+log10', 'chi combine', 'barrier']):
         print('    phase0/{:22s} median {:8d} cycles'.format(nm, int(np.median(de[:, i]))))
+    e2 = out[:, [10, 12, 13, 14, 11]].astype(np.int64)
+    for i, nm in enumerate(['iso interp', 'two brackets', 'presence mask', 'weights + LDS store']):
+        print('    recipe/{:24s} median {:8d} cycles'.format(nm, int(np.median(np.diff(e2, axis=1)[:, i]))))
     med = np.zeros((n, 8), dtype=np.uint64)
     fm = eng.ctx.lib.msx_diag_read_med_stamps
     fm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
