@@ -289,7 +289,10 @@ def main():
     # into one hipGraph and replayed; the timed region still executes exactly K steps (K // chunk replays, the
     # remainder issued eagerly).  Any capture failure falls back to the eager loop on every rank.
     graph, chunk = None, 0
-    if use_gather and not direct and os.environ.get('MSX_BENCH_GRAPH', '1') == '1' and args.steps >= 8:
+    # also at N = 1: back-to-back launches of one stream leave ~1 us between kernels that the graph does not
+    # (20.3 -> 19.3 us per step, same box); MSX_BENCH_GRAPH=0 gives the eager loop
+    want_graph = os.environ.get('MSX_BENCH_GRAPH', '1') == '1'
+    if want_graph and not direct and args.steps >= 8:
         chunk = min(int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '40')), args.steps) // (2 * nbatch) * (2 * nbatch)
         try:
             torch.cuda.synchronize(dev)
@@ -300,7 +303,8 @@ def main():
                 for i in range(chunk):
                     reuse_guard(i)
                     launch(i, tab)
-                    gather(i)
+                    if use_gather:
+                        gather(i)
                 drain()
             graph.replay()  # one untimed replay
             torch.cuda.synchronize(dev)
@@ -308,10 +312,11 @@ def main():
             print('[bench] hipGraph capture of the step loop failed ({}); eager loop'.format(exc), file=sys.stderr, flush=True)
             graph = None
             works[0] = works[1] = None
-        ok_t = torch.tensor([1 if graph is not None else 0], device=dev)
-        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        if int(ok_t.item()) == 0:
-            graph = None
+        if use_gather:
+            ok_t = torch.tensor([1 if graph is not None else 0], device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            if int(ok_t.item()) == 0:
+                graph = None
     # HIP events on the launch stream bracket runs of `ev_run` consecutive launches inside the timed region
     # (an event pair around every single launch would put two extra packets between back-to-back kernels
     # and inflate what it measures); kernel_ms = elapsed / ev_run, i.e. duration + the stream's launch gap
@@ -324,11 +329,17 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     first_eager = 0
+    gev = []
     if graph is not None:
         for _ in range(args.steps // chunk):
+            if not use_gather:  # kernels only in the graph: a replay's elapsed time / chunk is the kernel time
+                gev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                gev[-1][0].record(stream)
             graph.replay()
+            if not use_gather:
+                gev[-1][1].record(stream)
         first_eager = args.steps // chunk * chunk
-        nev = 0  # kernel timed separately below
+        nev = 0  # (N > 1: kernel timed separately below)
     for i in range(first_eager, args.steps):
         reuse_guard(i)
         g, k = divmod(i, ev_run)
@@ -358,7 +369,10 @@ def main():
         okt = torch.tensor([1 if ok else 0], device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         gather_ok = bool(int(okt.item()))
-    if nev > 0 and world == 1 and graph is None:
+    if gev:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in gev])) / chunk
+        kern_samples = len(gev) * chunk
+    elif nev > 0 and world == 1 and graph is None:
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:nev]])) / ev_run
         kern_samples = nev * ev_run
     else:  # N > 1: collectives share the stream timeline; time the kernel alone after the timed region
