@@ -755,3 +755,44 @@ def test_compact_pair_storage_is_opt_in_and_stays_inside_the_bar():
                                   torch.cuda.current_stream(dev).cuda_stream, _lib.MODE_LOGLIKE, block)
         torch.cuda.synchronize()
         assert np.array_equal(lp.cpu().numpy(), got, equal_nan=True), block
+
+
+def test_fuzzed_problems_against_the_oracle():
+    """Randomised problems on the golden grid: pixel counts from 3 to 1500 (unsorted wavelengths, ragged against
+    every workgroup size), random errors, with / without photometry, prior list, radius prior -- log-posterior of
+    ten walkers each against the oracle."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    from oracle import mft6_oracle as orc
+    c = golden_case('B')
+    bl = bands.make_bands(c.tables, *c.vega)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    rng = np.random.default_rng(2024)
+    lo, hi = float(np.min(c.data[0])), float(np.max(c.data[0]))
+    worst = 0.0
+    for case in range(40):
+        npix = int(rng.choice([3, 5, 63, 64, 65, 255, 257, 511, 700, 1023, 1500])) if case < 11 else int(rng.integers(3, 1500))
+        wl = rng.uniform(lo, hi, size=npix)
+        data = [wl, 1.0 + 0.1 * rng.normal(size=npix)]
+        err = rng.uniform(0.01, 0.2, size=npix)
+        r = [wl.min(), wl.max()]
+        phot = bool(rng.integers(0, 2))
+        rad_prior = bool(rng.integers(0, 2))
+        with_prior = bool(rng.integers(0, 2))
+        ptm = c.ptm if phot else [[], [], [], []]
+        fr = list(c.fr) if phot else [c.fr[0], c.fr[1], c.fr[2], np.zeros(0), [], np.array([])]
+        tmi, tma = common.tm_extrema(c.ctm, ptm)
+        prior = c.prior if with_prior else 0
+        eng.stage_problem(data, err, fr, r, c.ctm, ptm, tmi, tma, c.matrix, nspec=2, bands=bl,
+                          av_table=common.av_table_exact(), tmin=c.tmin, tmax=c.tmax, prior=prior, rad_prior=rad_prior)
+        th = c.theta[rng.choice(len(c.theta), size=10, replace=False)]
+        got = eng.logposterior(th)
+        want = np.array([orc.logposterior(list(t), fr, 2, data, err, r, c.specs, c.ctm, ptm, tmi, tma, c.tmin, c.tmax,
+                                          c.matrix, common.av_prior, prior=prior, rad_prior=rad_prior,
+                                          bandlib=c.bandlib) for t in th])
+        assert np.array_equal(np.isinf(got), np.isinf(want)), (case, npix)
+        e = rel_err(got, want).max()
+        worst = max(worst, float(e))
+        assert e < TIGHT, (case, npix, phot, rad_prior, with_prior, e)
+    print('fuzz: worst relative deviation from the oracle', worst)
