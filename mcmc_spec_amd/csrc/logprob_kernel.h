@@ -354,7 +354,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     double med_model = 0.0;
     bool solved = false;
     if (early) {
-        solved = logbin_median(model, npix, kmin, kmax, S, chi_elem, &med_model);
+        solved = logbin_median<MAXT>(model, npix, kmin, kmax, S, chi_elem, &med_model);
         chi_done = solved;
         if (!solved) {  // not a positive vector spanning < 8 binades, or > 256 equal-bin candidates: start over
             __syncthreads();  // every wave decided from the counters by itself: none may still be reading them

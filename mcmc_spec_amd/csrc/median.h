@@ -312,10 +312,11 @@ __device__ __forceinline__ unsigned int logbin(double x) {
     return ((unsigned int)__double2hiint(x) >> 12) & (unsigned int)(kLogBins - 1);
 }
 
-template <class Elem>
+template <int BT, class Elem>
 __device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
                                               BlockScratch &S, Elem &elem, double *med_out) {
-    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    constexpr int B = BT, nw = BT >> 6;  // the workgroup size is a compile-time constant of every kernel variant
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
     const bool need_two = (npix & 1) == 0;
     if (!(kmin > key_of(0.0)) || kmin == kmax) return false;
