@@ -684,13 +684,14 @@ int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, 
     double *h_out = h_theta + cap * MSX_MAX_DIM;  // [cap] log-probs followed by [cap] int32 statuses
     memcpy(h_theta, theta, sizeof(double) * n * ndim);
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, h_theta, sizeof(double) * n * ndim, hipMemcpyHostToDevice, c->stream));
-    int rc = msx_logprob_batch_dev(c, mode, c->d_theta, n, ndim, c->d_logp, c->d_status, c->stream, 0);
+    // the statuses go right behind this call's n log-probs, so that one copy brings both back
+    int32_t *d_st = reinterpret_cast<int32_t *>(c->d_logp + n);
+    int rc = msx_logprob_batch_dev(c, mode, c->d_theta, n, ndim, c->d_logp, d_st, c->stream, 0);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_logp, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(h_out + cap, c->d_status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_logp, (sizeof(double) + sizeof(int32_t)) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(logp_out, h_out, sizeof(double) * n);
-    memcpy(status_out, reinterpret_cast<int32_t *>(h_out + cap), sizeof(int32_t) * n);
+    memcpy(status_out, reinterpret_cast<int32_t *>(h_out + n), sizeof(int32_t) * n);
     return MSX_OK;
 }
 
