@@ -196,10 +196,11 @@ def main():
     import ctypes as C
     fn = eng.ctx.lib.msx_logprob_batch_dev
     h = eng.ctx.h
-    # With a collective in flight RCCL's kernel holds a CU or two: 512-thread workgroups (one per CU, all 256
-    # CUs needed at once) would then run a second round for the displaced walkers; 256-thread workgroups
-    # (three per CU) absorb it.  So N > 1 defaults to 256 threads, N = 1 to the library's own choice (512).
-    block = args.block if args.block else (256 if use_gather else 0)
+    # With a collective in flight RCCL's kernel holds a CU or two.  The N = 1 variant (512 threads + 136 KB of LDS:
+    # one workgroup per CU, all 256 CUs needed at once) would run a second round for the displaced walkers, so
+    # N > 1 launches the 512-thread variant that fits two workgroups per CU (<= 128 VGPRs, 44 KB of LDS;
+    # MSX_BLOCK_512_SHARED): 20.2 us alone against 19.1 us, and 23.5 us for 256-thread workgroups.  Same bits.
+    block = args.block if args.block else (_lib.BLOCK_512_SHARED if use_gather else 0)
     def calls_for(sp):
         return [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
                   C.c_void_p(status[b].data_ptr()), C.c_void_p(sp), block) for b in range(2)] for t in thetas]
@@ -417,7 +418,7 @@ def main():
                            if graph is not None else 'eager')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'logprob_kernel<NS=2,U=2,512 threads,PF>' if not block else 'logprob_kernel<NS=2>, %d threads' % block,
+                         'kernel': 'logprob_kernel<NS=2,U=2,512 threads,PF>' if not block else ('logprob_kernel<NS=2,U=1,512 threads> (two workgroups per CU)' if block == _lib.BLOCK_512_SHARED else 'logprob_kernel<NS=2>, %d threads' % block),
                          'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples, 'algorithmic_bytes_per_launch': n * b_alg,
                          'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
                          'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,

@@ -133,8 +133,12 @@ int msx_stage_problem(msx_ctx *ctx, const msx_problem *p);
 /* theta is [n][ndim] row-major (ndim = 2*nspec+2); logp_out [n]; status_out [n] (MSX_W_*).        */
 int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n, int32_t ndim,
                       double *logp_out, int32_t *status_out);
-/* same with device pointers on a caller stream; does not synchronise.  block_threads: 0 = auto (512 when
- * n <= #CUs, else 256; 1024 for >= 8192 pixels) or one of 256 / 512 / 1024.                          */
+/* same with device pointers on a caller stream; does not synchronise.  block_threads: 0 = auto (1024 for >= 8192
+ * pixels; else 512 up to 4 x #CUs walkers, 256 beyond), or one of 256 / 512 / 1024, or MSX_BLOCK_512_SHARED = 512
+ * threads in the <= 128-VGPR variant that can share its CU with a second workgroup (what a launch wants when
+ * another kernel, e.g. a collective, holds CUs at the same time).  The choice affects speed only: every variant
+ * produces the same bits.                                                                                    */
+#define MSX_BLOCK_512_SHARED 1512
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
 

@@ -18,6 +18,7 @@ MSX_OK = 0
 MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
 W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR = 0, 1, 2, 3, 4
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
+BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)

@@ -596,6 +596,8 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if ((mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT) && !c->P.opt_flux)
         return fail(c, MSX_ERR_STATE, "optimiser modes go through msx_opt_init / msx_opt_step");
     if (n == 0) return MSX_OK;
+    const bool shared512 = block_threads == MSX_BLOCK_512_SHARED;  // 512 threads, the <= 128-VGPR variant that
+    if (shared512) block_threads = 512;                            // shares a CU with another workgroup
     int B = block_threads > 0 ? block_threads : pick_block(c, n, c->P.npix);
     // the median's bin scan assigns kBins/B bins to each thread and the radix fallback clears its
     // 256-bin histogram with tid < 256
@@ -634,7 +636,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     const dim3 g((unsigned)n), b((unsigned)B);
     // pixel statics staged in LDS by the idle waves: 512-thread workgroups that own their CU (one per CU anyway)
     // and whose 4 npix doubles fit beside the scratch
-    const bool pf = B == 512 && n <= c->prop.multiProcessorCount && !c->P.pairs_c && c->pf_ok && c->use_pf;
+    const bool pf = B == 512 && !shared512 && n <= c->prop.multiProcessorCount && !c->P.pairs_c && c->pf_ok && c->use_pf;
     // every variant is compiled for, and launched with, exactly its thread count (the canonical summation order
     // relies on it)
 #define MSX_GO(NS_, U_, T_, CP_, PF_, LDS_)                                                                           \
@@ -646,7 +648,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         else if (B == 512) {
             if (pf) MSX_GO(2, 2, 512, false, true, 4 * lds);
             else if (cp) MSX_GO(2, 2, 512, true, false, lds);
-            else if (n > c->prop.multiProcessorCount) MSX_GO(2, 1, 512, false, false, lds);  // two workgroups per CU
+            else if (shared512 || n > c->prop.multiProcessorCount) MSX_GO(2, 1, 512, false, false, lds);  // two workgroups per CU
             else MSX_GO(2, 2, 512, false, false, lds);
         } else MSX_GO(2, 1, 1024, false, false, lds);
     } else {
