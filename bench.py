@@ -200,7 +200,7 @@ def main():
     # one workgroup per CU, all 256 CUs needed at once) would run a second round for the displaced walkers, so
     # N > 1 launches the 512-thread variant that fits two workgroups per CU (<= 128 VGPRs, 44 KB of LDS;
     # MSX_BLOCK_512_SHARED): 20.2 us alone against 19.1 us, and 23.5 us for 256-thread workgroups.  Same bits.
-    block = args.block if args.block else (_lib.BLOCK_512_SHARED if use_gather else 0)
+    block = args.block if args.block else (_lib.BLOCK_512_SHARED if use_gather and args.npix < 8192 else 0)
     def calls_for(sp):
         return [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
                   C.c_void_p(status[b].data_ptr()), C.c_void_p(sp), block) for b in range(2)] for t in thetas]
