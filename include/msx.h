@@ -86,7 +86,8 @@ typedef struct msx_problem {
     double prior_mean[MSX_MAX_DIM]; /* Gaussian priors; mean == 0 -> unused         mft6.py:1257-1260 */
     double prior_sig[MSX_MAX_DIM];
     int32_t use_av;         /* `a` / `av` flag                                      mft6.py:1161,1229 */
-    int32_t dist_fit;       /* only dist_fit = 1 is implemented                     mft6.py:1212    */
+    int32_t dist_fit;       /* 1: the parallax is a fitted parameter with its box / Gaussian terms (mft6.py:1212-1272);
+                             * 0: the `dist_fit=False` branch, radius-ratio scaling only (mft6.py:1275-1327)  */
     int32_t rad_prior;      /*                                                      mft6.py:1262    */
     int32_t has_prior_list; /* `prior != 0`                                         mft6.py:1241    */
     int32_t no_spectrum;    /* 1 = the mft6_nospec.py variant: total = contrast + photometry chi^2 only
@@ -156,10 +157,12 @@ int msx_opt_step(msx_ctx *ctx, const double *theta, const int32_t *chain, int64_
 
 /* ---- f2 on the device: nsteps iterations of the affine-invariant stretch move (Goodman & Weare 2010, the
  * default move of emcee 3; the loop the reference drives at mft6.py:1494-1524) with the walker state resident in
- * HBM: per half-step a proposal kernel, the fused log-probability launch and an accept kernel, queued back to
- * back with no host round trip.  The host supplies the randomness of every half-step h = 2*step + half, each an
- * array of nw/2 entries: the active walkers sidx, the complementary half cidx, partner (index into cidx),
- * z = ((a-1)u+1)^2/a, zfac = (ndim-1) ln z and logu = ln(u') for the accept test logu < zfac + lp(q) - lp(s).
+ * HBM.  Per half-step there is ONE launch of the fused log-probability kernel: its first lines build each active
+ * walker's proposal q = c - (c - s) z from the resident coordinates, its last lines apply the accept rule and write
+ * the walker's row of the chain -- no separate proposal / accept kernels and no host round trip.  The host supplies
+ * the randomness of every half-step h = 2*step + half, each an array of nw/2 entries: the active walkers sidx, the
+ * complementary half cidx, partner (index into cidx), z = ((a-1)u+1)^2/a, zfac = (ndim-1) ln z and logu = ln(u')
+ * for the accept test logu < zfac + lp(q) - lp(s).
  * coords/logp are updated in place; chain_out [nsteps][nw][ndim] and logp_out [nsteps][nw] hold the state after
  * every step; naccept[nw] accumulates; worst_status returns the largest MSX_W_* error seen (0 = none).        */
 int msx_sampler_run(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int64_t nsteps, double *coords, double *logp,

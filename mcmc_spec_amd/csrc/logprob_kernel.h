@@ -32,11 +32,16 @@ __device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDes
 
 // ------------------------------------------------------------------------------------------------
 // THE HOT KERNEL: one workgroup per walker.
-//   phase 0  wave 0 builds the walker's recipe on 64 lanes (prior gate, A1, A2, A4, A5, A6)
-//   phase A  blend + redden + resample into LDS; fit sums; value range           (A2, A4, A7, A8.1)
-//   phase B  exact median: 1024 linear value bins -> <=256 candidates -> all-pairs rank
-//            (falls back to the bitwise radix select for adversarial distributions)     (A8.2)
-//   phase C  continuum fit coefficients, chi^2                                          (A8.3, A9)
+//   phase 0    one wave per star builds the walker's recipe from register-resident tables (prior gate, A1, A2,
+//              A4); an idle wave computes the Gaussian prior terms (f1); with PF the remaining waves stage
+//              pixel statics in LDS
+//   phase A    blend + redden + resample into the model vector (LDS); fit sums, value range and the median's
+//              logarithmic histogram are accumulated on the way                       (A2, A4, A7, A8.1)
+//              wave 0 computes the contrast / photometry terms (A5/A6) while it waits at phase A's barrier
+//   phase B+C  exact median (per-wave bin scan -> ONE pass that also carries the chi^2 terms and gathers the
+//              median bin's candidates -> wave-0 rank); scale, chi^2 and the combine   (A8.2, A8.3, A9)
+//              vectors the early histogram cannot handle take block_median (linear bins, radix fallback); the
+//              pre-optimiser modes keep a separate chi^2 pass (phase C proper)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 

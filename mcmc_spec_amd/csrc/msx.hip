@@ -666,6 +666,10 @@ int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, 
                       int32_t *status_out) {
     if (!c) return MSX_ERR_INVALID;
     if (!theta || !logp_out || !status_out || n < 0) return fail(c, MSX_ERR_INVALID, "msx_logprob_batch: bad arguments");
+    // everything the copy below relies on is checked BEFORE the pinned staging buffer is sized or written
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_logprob_batch: no problem staged");
+    if (ndim != 2 * c->P.nspec + 2 || ndim > MSX_MAX_DIM)
+        return fail(c, MSX_ERR_INVALID, "P0 doesn't match what I was expecting (ndim must be 2*nspec+2)");
     if (n == 0) return MSX_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if (n > c->cap_walkers) {
@@ -756,6 +760,7 @@ int msx_opt_step(msx_ctx *c, const double *theta, const int32_t *chain, int64_t 
 struct SamplerRun {
     int32_t mode = 0, ndim = 0;
     int64_t nw = 0, ns = 0, cap_steps = 0;
+    bool failed = false;  // an enqueue returned an error after queuing part of its launches
     char *d_state = nullptr;
     double *d_coords = nullptr, *d_logp = nullptr, *d_q = nullptr, *d_newlp = nullptr;
     int64_t *d_nacc = nullptr;
@@ -850,6 +855,8 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
     if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: call msx_sampler_begin first");
     if (slot < 0 || slot > 1 || nsteps < 1 || nsteps > r->cap_steps || !sidx || !cidx || !partner || !zz || !zfac || !logu)
         return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue: bad arguments");
+    if (r->failed)
+        return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: an earlier enqueue failed part-way; end this run (msx_sampler_end) and begin again");
     SamplerRun::Slot &sl = r->slot[slot];
     if (sl.busy) return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: slot not collected yet");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -891,7 +898,12 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
         }
     }
     P.smp_on = 0;
-    if (rc != MSX_OK) return rc;
+    if (rc != MSX_OK) {
+        // some of this chunk's half-steps may already be queued: the resident state is no longer the state any
+        // host-side bookkeeping expects.  Refuse everything but msx_sampler_end from here on.
+        r->failed = true;
+        return rc;
+    }
     // acceptance counters keep running while this chunk's results travel: snapshot them in stream order
     HIP_TRY(c, hipMemcpyAsync(d_nacc_snap, r->d_nacc, sizeof(int64_t) * nw, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(sl.kernels_done, c->stream));

@@ -597,6 +597,59 @@ def test_device_resident_sampler_walks_the_same_chain_as_the_host_loop():
     assert np.all(np.isfinite(st.log_prob)) and flat[:, 1].min() >= 3000.0 and flat[:, 2].min() >= 0.0
 
 
+def test_device_resident_sampler_against_the_oracle_stretch_move():
+    """Independent pin of f2 on the device: the fused kernel's proposal + accept lines against the walker-by-walker
+    restatement in oracle/stretch_move.py driving the ORACLE's logposterior, from the same random numbers.  The
+    coordinates depend on the log-probabilities only through accept decisions, so the chains must agree exactly;
+    the log-probabilities agree to the parity tolerance."""
+    from oracle import stretch_move as osm
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    c = golden_case('B')
+    eng = make_engine(c, rad_prior=False)
+    rng = np.random.default_rng(12)
+    nw, nsteps = 16, 10
+    p0 = c.theta[0] + rng.normal(size=(nw, 6)) * np.array([30, 30, 0.02, 0.02, 0.02, 2e-5])
+    p0[:, 1] = np.clip(p0[:, 1], 3001.0, None)
+    dev = DeviceEnsembleSampler(nw, 6, eng, seed=31, chunk=4)
+    dev.run_mcmc(p0, nsteps)
+    twin = EnsembleSampler(nw, 6, None, vectorize=True, seed=31)
+    sidx, cidx, partner, zz, zfac, logu = twin._draw_steps(nsteps)
+    f = lambda q: np.array([oracle_logpost(c, t) for t in q])  # noqa: E731
+    chain, lpc, nacc = osm.run_chain(p0, f(p0), (sidx, cidx, partner, zz, logu), f)
+    assert np.array_equal(dev.get_chain(), chain)
+    assert rel_err(dev.get_log_prob(), lpc).max() < TIGHT
+    assert np.array_equal(dev.acceptance_fraction, nacc / nsteps) and 0 < nacc.sum() < nw * nsteps
+
+
+def test_device_resident_sampler_statistics():
+    """Moments / acceptance of DeviceEnsembleSampler itself: two device-resident runs from different seeds and a
+    host-driven run sample the same posterior, so their pooled means must agree within a few standard errors and
+    the acceptance fraction must sit where the stretch move's does for a 6-dimensional target."""
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    c = golden_case('B')
+    eng = make_engine(c, rad_prior=False)
+    rng = np.random.default_rng(2)
+    nw = 64
+    p0 = c.theta[0] + rng.normal(size=(nw, 6)) * np.array([5, 5, 0.005, 0.005, 0.005, 5e-6])
+    p0[:, 1] = np.clip(p0[:, 1], 3001.0, None)
+    runs = []
+    for seed, cls in ((1, DeviceEnsembleSampler), (2, DeviceEnsembleSampler), (3, None)):
+        s = cls(nw, 6, eng, seed=seed, chunk=64) if cls else EnsembleSampler(nw, 6, eng.logposterior, vectorize=True, seed=seed)
+        st = s.run_mcmc(p0, 400)
+        s.reset()
+        s.run_mcmc(st, 600)
+        flat = s.get_chain(flat=True)
+        runs.append((flat.mean(0), flat.std(0), s.acceptance_fraction.mean(), s.get_autocorr_time(quiet=True)))
+    for m, sd, acc, tau in runs:
+        assert 0.1 < acc < 0.8, acc
+    m0, sd0, _, tau0 = runs[0]
+    neff = nw * 600 / max(np.nanmax(tau0), 1.0)
+    for m, sd, _, _ in runs[1:]:
+        z = np.abs(m - m0) / (np.maximum(sd0, sd) / np.sqrt(neff / 2.0))
+        assert z.max() < 6.0, z
+        assert np.all(sd / sd0 < 2.0) and np.all(sd0 / sd < 2.0)
+
+
 def test_pipelined_sampler_entry_points_guard_their_arguments():
     """msx_sampler_begin/_enqueue/_collect/_end: indices that would be dereferenced on the device are range-checked
     on the host, slots cannot be overwritten or collected twice, and a run continued from a State is the same

@@ -88,3 +88,41 @@ def test_randomness_is_independent_of_chunking():
     assert sorted(np.concatenate([sidx[0, 0], sidx[0, 1]]).tolist()) == list(range(64))   # a true split
     assert np.array_equal(cidx[0, 0], sidx[0, 1]) and np.array_equal(cidx[0, 1], sidx[0, 0])
     assert partner.min() >= 0 and partner.max() < 32 and zz.min() >= 0.5 and zz.max() <= 2.0
+
+
+def test_host_sampler_walks_the_chain_of_the_oracle_stretch_move():
+    """Independent pin of the move (f2): the walker-by-walker restatement under oracle/ and the vectorised host
+    sampler, fed the same random numbers, must produce the same chain, log-probabilities and acceptance counts --
+    including proposals that fall outside the support (-inf) and a walker that starts there."""
+    from oracle import stretch_move as osm
+
+    def lnp(x):
+        x = np.atleast_2d(x)
+        inside = np.all(np.abs(x) < 3.0, axis=1)
+        return np.where(inside, -0.5 * np.sum((x / np.array([0.5, 1.0, 2.0])) ** 2, axis=1), -np.inf)
+
+    nw, nd, nsteps = 12, 3, 40
+    p0 = np.random.default_rng(8).normal(size=(nw, nd)) * 0.8
+    p0[3] = [5.0, 0.0, 0.0]                                  # starts outside: log p = -inf until a move is accepted
+    s = EnsembleSampler(nw, nd, lnp, vectorize=True, seed=21)
+    s.run_mcmc(p0, nsteps)
+    twin = EnsembleSampler(nw, nd, lnp, vectorize=True, seed=21)   # same seed: the numbers the run above consumed
+    sidx, cidx, partner, zz, zfac, logu = twin._draw_steps(nsteps)
+    chain, lpc, nacc = osm.run_chain(p0, lnp(p0), (sidx, cidx, partner, zz, logu), lnp)
+    assert np.array_equal(chain, s.get_chain())
+    assert np.array_equal(lpc, s.get_log_prob())
+    assert np.array_equal(nacc / nsteps, s.acceptance_fraction)
+    assert 0 < nacc.sum() < nw * nsteps and np.isinf(lnp(p0)[3])
+
+
+def test_stretch_factor_law():
+    """z = ((a-1)u+1)^2/a has density ∝ 1/sqrt(z) on [1/a, a] (Goodman & Weare 2010): check support and CDF."""
+    from oracle import stretch_move as osm
+    u = np.random.default_rng(0).random(200000)
+    z = osm.stretch_factor(u, 2.0)
+    assert z.min() >= 0.5 and z.max() <= 2.0
+    for q in (0.7, 1.0, 1.5):                                # CDF(z) = (sqrt(a z) - 1) / (a - 1)
+        assert abs(np.mean(z <= q) - (np.sqrt(2.0 * q) - 1.0)) < 5e-3
+    s = EnsembleSampler(8, 2, lambda x: np.zeros(len(x)), vectorize=True, seed=3)
+    _, _, _, zz, zfac, _ = s._draw_steps(50)
+    assert zz.min() >= 0.5 and zz.max() <= 2.0 and np.allclose(zfac, (2 - 1.0) * np.log(zz), rtol=0, atol=1e-15)
