@@ -143,6 +143,19 @@ int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
 
+/* Two forms of the same path, same bits.  FUSED: one launch, one workgroup per walker (latency-optimal for a few
+ * hundred walkers of <= 8k pixels).  SPLIT: recipe kernel -> tile planner -> walker-tiled blend kernel (the walkers
+ * of one grid cell share ONE load of their 4*nspec pair rows; pixels spread over all CUs) -> per-walker median /
+ * chi^2 kernel, in sub-batches whose model vectors stay cache-resident.  MSX_PATH_AUTO takes the split form at or
+ * above MSX_SPLIT_MIN walkers / MSX_SPLIT_MIN_NPIX pixels (environment variables read by msx_stage_problem; unset =
+ * never: on MI355X the fused kernel measured faster at every size).  All scratch is sized by
+ * msx_stage_problem: no launch allocates or synchronises.  MSX_PATH_SPLIT fails with MSX_ERR_STATE for modes / problems that have no split form
+ * (logprior alone, the no-spectrum variant, compact pairs, the optimiser modes, tables beyond the register recipe). */
+#define MSX_PATH_AUTO 0
+#define MSX_PATH_FUSED 1
+#define MSX_PATH_SPLIT 2
+int msx_set_path(msx_ctx *ctx, int32_t path);
+
 /* ---- f4: the pre-optimiser's chi^2 (fit_spec, mft6.py:856-1137) on the same kernel --------------- */
 /* msx_opt_init: one chain per row of theta0 [nchains][ndim].  Normalises the data against each chain's
  * initial (un-reddened) model like mft6.py:884-889, keeps the normalised vector and its median on the

@@ -19,6 +19,7 @@ MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
 W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR = 0, 1, 2, 3, 4
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
+PATH_AUTO, PATH_FUSED, PATH_SPLIT = 0, 1, 2  # include/msx.h MSX_PATH_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)
@@ -90,6 +91,7 @@ def load():
         'msx_stage_problem': (C.c_int, [vp, C.POINTER(MsxProblem)]),
         'msx_logprob_batch': (C.c_int, [vp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_logprob_batch_dev': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32]),
+        'msx_set_path': (C.c_int, [vp, C.c_int32]),
         'msx_opt_init': (C.c_int, [vp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_opt_step': (C.c_int, [vp, _dp, C.POINTER(C.c_int32), C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_sampler_run': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, C.POINTER(C.c_int32),
@@ -120,7 +122,7 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
+            'msx_logprob_batch_dev', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
@@ -243,6 +245,10 @@ class Context:
         self.check(self.lib.msx_logprob_batch_dev(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim),
                                                   C.c_void_p(d_logp_ptr), C.c_void_p(d_status_ptr),
                                                   C.c_void_p(stream_ptr), int(block_threads)))
+
+    def set_path(self, path):
+        """PATH_AUTO / PATH_FUSED / PATH_SPLIT: which form of the hot path launches take (same bits either way)."""
+        self.check(self.lib.msx_set_path(self.h, int(path)))
 
     def opt_init(self, theta0):
         theta0 = as_f64(theta0)

@@ -72,7 +72,8 @@ struct DevProblem {
     double *opt_flux;          // [nchains][npix]
     double *opt_med;           // [nchains]
     const int32_t *opt_chain;  // [n] (OPT_STEP launches)
-    double *model_scratch;     // [n][npix] only when the model vector does not fit LDS (GM kernel variants)
+    double *model_scratch;     // [n][npix]: the model vectors of the split path (stages 3 -> 4) and of the GM variants
+    struct WalkerRec *rec;     // [n] split path: what stage 1 (the recipe) leaves for stages 3 and 4
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;
@@ -116,6 +117,36 @@ struct WalkerDesc {
     int64_t smp_s;                        // its index in the ensemble
     int64_t smp_nacc;                     // its acceptance count so far
 };
+
+constexpr int kTileWalkers = 8;     // split path: walkers that share one load of the pair rows
+
+// What the recipe leaves behind for stages 3 and 4.
+struct alignas(16) WalkerRec {
+    double w[kMaxCorners];      // bilinear weight x (R/d)^2 per corner, corners in canonical (sorted-node) order
+    double redc, lp, chi_extra;
+    unsigned long long key;     // hash of node[0 .. 4*NS)  (top bit always set: 0 marks an empty planner slot)
+    int32_t node[kMaxCorners];
+    int32_t status;             // MSX_W_OK: stages 3 and 4 run; anything else: stage 1 has written the final value
+    int32_t pad[3];
+};
+static_assert(sizeof(WalkerRec) == 192, "WalkerRec layout");
+
+struct alignas(16) TileHdr {
+    int32_t start, count;       // walkers perm[start .. start + count) share node[]
+    int32_t node[kMaxCorners];
+    int32_t pad[2];
+};
+static_assert(sizeof(TileHdr) == 64, "TileHdr layout");
+
+__device__ __forceinline__ unsigned long long hash_nodes(const int *node, int nc) {
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int c = 0; c < nc; ++c) {
+        h ^= (unsigned long long)(unsigned int)node[c] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 31;
+    }
+    return h | 0x8000000000000000ull;
+}
 
 }  // namespace
 

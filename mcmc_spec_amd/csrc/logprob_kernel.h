@@ -53,7 +53,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //      resample weight t) into LDS; phase A and the chi^2 pass then read them from LDS, which takes 160 of the
 //      786 KB a walker pulls through its CU's L2 port off the critical path (one workgroup per CU only: 4 npix
 //      doubles of LDS).
-template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false>
+// STAGE = 0: the fused kernel.  The split path (split_kernels.h) runs the same code in two pieces:
+//   STAGE = 1  phase 0 only: the walker's recipe goes to P.rec[wk] (rejected / failed walkers get their final
+//              value here, like the fused kernel); launched with 256 threads, no dynamic LDS
+//   STAGE = 2  everything after the blend: the model vector comes from P.model_scratch (written by
+//              blend_tiles_kernel), the recipe's scalars from P.rec[wk]
+template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false, int STAGE = 0>
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && U == 1) ? 2 : 1)
 logprob_kernel(const double *theta, const double *__restrict__ iso_t, const double *__restrict__ iso_g,
                const double *__restrict__ teff_nodes, const double *__restrict__ logg_nodes,
@@ -70,9 +75,11 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
     RecipeRegs RR;
-    if (fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, iso_t, iso_g, teff_nodes, logg_nodes, present, niso, nt, ng, threadIdx.x & 63);
+    if (STAGE != 2 && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, iso_t, iso_g, teff_nodes, logg_nodes, present, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
+    if (STAGE == 2 && P.rec[wk].status != MSX_W_OK) return;  // stage 1 wrote this walker's final value (uniform branch)
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
+    const double *__restrict__ model_in = STAGE == 2 ? P.model_scratch + wk * P.npix : nullptr;
     const int tid = threadIdx.x;
     constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
     const int lane = tid & 63, wave = tid >> 6;
@@ -121,10 +128,13 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
     const bool early = !GM && fast && !P.no_spectrum &&
                        (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    if (STAGE == 2) {  // the recipe's scalars come from stage 1's record; no phase 0
+        if (tid == 0) { D.lp = P.rec[wk].lp; D.chi_extra = P.rec[wk].chi_extra; D.status = MSX_W_OK; }
+    }
     // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
     // mode (rejected walkers never read them)
-    if (fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
-    if (PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
+    if (STAGE != 2 && fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    if (STAGE != 2 && PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
         const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
 #pragma unroll 4
         for (int p = id; p < npix; p += nthr) {
@@ -133,15 +143,17 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             lds_t[p] = P.pix_t[p];
         }
     }
-    if (fast) {
-        if (wave < NS) recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
-    } else if (wave == 0) {
-        const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
-        build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
+    if (STAGE != 2) {
+        if (fast) {
+            if (wave < NS) recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
+        } else if (wave == 0) {
+            const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
+            build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
+        }
     }
     __syncthreads();
     int wst = D.status;
-    if (fast) {  // first star that failed decides, like the reference's star-by-star loop
+    if (STAGE != 2 && fast) {  // first star that failed decides, like the reference's star-by-star loop
         wst = D.stat[0];
 #pragma unroll
         for (int k = 1; k < NS; ++k) wst = (wst == MSX_W_OK) ? D.stat[k] : wst;
@@ -149,6 +161,25 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     if (wst != MSX_W_OK) {
         if (tid == 0) {
             walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
+            if (STAGE == 1) P.rec[wk].status = wst;
+        }
+        return;
+    }
+    if (STAGE == 1) {
+        // (the host only takes the split path for the likelihood / posterior / chi^2 modes of a problem with a
+        // spectrum term and the register-resident recipe)  The walker is alive: finish its scalars -- wave NS left
+        // D.lp before the barrier above, wave 0 adds the contrast / photometry chi^2 -- and leave the record.
+        if (wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+        __syncthreads();
+        WalkerRec *R = P.rec + wk;
+        if (tid < NS * 4) { R->node[tid] = D.node[tid]; R->w[tid] = D.w[tid]; }
+        if (tid == kWave) {
+            R->redc = D.redc; R->lp = D.lp; R->chi_extra = D.chi_extra;
+            int nd[NS * 4];
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) nd[c] = D.node[c];
+            R->key = hash_nodes(nd, NS * 4);
+            R->status = MSX_W_OK;
         }
         return;
     }
@@ -182,12 +213,12 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     double w[NS * 4];
 #pragma unroll
     for (int c = 0; c < NS * 4; ++c) {
-        const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
+        const int64_t off = STAGE == 2 ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
         rows[c] = P.pairs + off;
         rows_c[c] = CP ? P.pairs_c + off : nullptr;
-        w[c] = D.w[c];
+        w[c] = STAGE == 2 ? 0.0 : D.w[c];
     }
-    const double redc = D.redc;
+    const double redc = STAGE == 2 ? 0.0 : D.redc;
     const bool redden = redc != 0.0;
     // Sums are taken in an order that does not depend on the workgroup size: pixel p belongs to row p / B of the
     // launch, i.e. to 64-pixel chunk c = p / 64, and chunk c is owned by VIRTUAL wave c mod 16.  A real wave of a
@@ -211,52 +242,42 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         if (base >= npix) break;
         double2 v[U][NS * 4];
         double2 kk[U];
-        double tt[U], ff[U], uu[U];
+        double tt[U], ff[U], uu[U], mm[U];
         int pp[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = base + u * B + tid;
             pp[u] = p < npix ? p : npix - 1;
+            if (STAGE == 2) {
+                mm[u] = model_in[pp[u]];  // blend_tiles_kernel's output for this walker
+            } else {
 #pragma unroll
-            for (int c = 0; c < NS * 4; ++c) {
-                if (CP) {
-                    const PairC pc = rows_c[c][pp[u]];
-                    v[u][c] = make_double2(pc.lo, (double)pc.d);  // .y holds the DIFFERENCE in compact mode
-                } else {
-                    v[u][c] = rows[c][pp[u]];
+                for (int c = 0; c < NS * 4; ++c) {
+                    if (CP) {
+                        const PairC pc = rows_c[c][pp[u]];
+                        v[u][c] = make_double2(pc.lo, (double)pc.d);  // .y holds the DIFFERENCE in compact mode
+                    } else {
+                        v[u][c] = rows[c][pp[u]];
+                    }
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            kk[u] = redden ? P.pix_k[pp[u]] : make_double2(0.0, 0.0);
-            tt[u] = PF ? lds_t[pp[u]] : P.pix_t[pp[u]];
-            ff[u] = PF ? lds_f[pp[u]] : P.pix_flux[pp[u]];
-            uu[u] = PF ? lds_u[pp[u]] : P.pix_u[pp[u]];
+            if (STAGE != 2) {
+                kk[u] = redden ? P.pix_k[pp[u]] : make_double2(0.0, 0.0);
+                tt[u] = PF ? lds_t[pp[u]] : P.pix_t[pp[u]];
+            }
+            ff[u] = (PF && STAGE != 2) ? lds_f[pp[u]] : P.pix_flux[pp[u]];
+            uu[u] = (PF && STAGE != 2) ? lds_u[pp[u]] : P.pix_u[pp[u]];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            double ylo = 0.0, yhi = 0.0;
-#pragma unroll
-            for (int c = 0; c < NS * 4; ++c) {
-                ylo = fma(w[c], v[u][c].x, ylo);
-                yhi = fma(w[c], v[u][c].y, yhi);
-            }
-            if (CP) yhi += ylo;  // blended difference -> blended upper sample
-            if (redden) {
-                const double elo = exp2(redc * kk[u].x);  // 10^(-0.4 A_V k)     mft6.py:62-63
-                // neighbouring grid samples: y = ln2 * c * (k_hi - k_lo) is tiny, so e^y from four series
-                // terms is exact to < 1e-17 for |y| < 1e-3; anything larger takes the full exp2
-                const double y = 0.6931471805599453 * (redc * (kk[u].y - kk[u].x));
-                const double ehi = (fabs(y) < 1e-3)
-                                       ? elo * fma(y, fma(y, fma(y, fma(y, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0)
-                                       : exp2(redc * kk[u].y);
-                ylo *= elo;
-                yhi *= ehi;
-            }
-            const double m = fma(yhi - ylo, tt[u], ylo);  // mft6.py:1169-1170
+            // the model value of this pixel (blend.h; the split path's blend kernel calls the same function)
+            const double m = STAGE == 2 ? mm[u] : blend_pixel<NS * 4, CP>(v[u], w, kk[u], tt[u], redc, redden);
             if (base + u * B + tid < npix) {
-                model[pp[u]] = m;
+                if (!(GM && STAGE == 2)) model[pp[u]] = m;  // (GM stage 2: the scratch row IS the model vector)
+                if (PF && STAGE == 2) { lds_u[pp[u]] = uu[u]; lds_f[pp[u]] = ff[u]; }  // for the chi^2 pass
                 const double f = ff[u] / m;  // frac before the median scale, mft6.py:194
                 const double f1 = f * uu[u], f2 = f * (uu[u] * uu[u]);
                 const int slot = (sub * U + u) & (vk - 1);  // static: sub and u are unrolled
@@ -275,7 +296,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
     // bound by the CU's L2 port and wave 0's loads are served first, so wave 0 leaves the pixel loop thousands of
     // cycles before the last wave: it computes the terms in that wait.  (Other modes: inside block_median.)
-    if (early && wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+    if (STAGE != 2 && early && wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
     {
 #pragma unroll
         for (int k = 0; k < vk; ++k) {
@@ -315,7 +336,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
     const double *th_w = th_row;
     auto side = [&]() __attribute__((always_inline)) {
-        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
+        if (STAGE != 2 && fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
     };
     // The spectrum chi^2 factorises: with P(u) = c0 + c1 u + c2 u^2 the raw fit of data/model (from the q
     // sums), the fit of data/(scale*model) is P/scale, data' = scale*data/P and

@@ -16,9 +16,11 @@
 // Layout of the translation unit (device code in headers, included below in this order):
 //   dev_types.h        constants, DevProblem (by-value kernel argument), WalkerDesc (LDS)
 //   wave_ops.h         DPP reductions / scans, order-preserving keys
+//   blend.h            the per-pixel model arithmetic shared by the fused and the walker-tiled kernels
 //   recipe.h           phase 0: gates, isochrone, brackets, weights, prior and band terms
 //   median.h           exact median selects (block_median, logbin_median, radix fallback)
-//   logprob_kernel.h   the hot kernel and its variants
+//   logprob_kernel.h   the hot kernel and its variants (fused; recipe-only and median/chi^2-only stages)
+//   split_kernels.h    the split path's planner and walker-tiled blend kernel
 //   staging_kernels.h  CCM89, pair gather, band integrals, broadening, resample, composite, stream copy
 //   msx.hip            host context + the C ABI of include/msx.h
 //
@@ -48,9 +50,11 @@
 // The device code lives in the headers below (one translation unit; every kernel variant is instantiated here).
 #include "dev_types.h"
 #include "wave_ops.h"
+#include "blend.h"
 #include "recipe.h"
 #include "median.h"
 #include "logprob_kernel.h"
+#include "split_kernels.h"
 #include "staging_kernels.h"
 
 // ================================================================================================
@@ -96,6 +100,18 @@ struct msx_ctx {
     int comm_world = 0, comm_rank = 0;
     double *d_model_scratch = nullptr;
     int64_t cap_model_scratch = 0;  // doubles
+    // split path (split_kernels.h): per-sub-batch records, walker order, tiles; sized at msx_stage_problem
+    WalkerRec *d_rec = nullptr;
+    int32_t *d_perm = nullptr, *d_hdr = nullptr, *d_tmp = nullptr;
+    TileHdr *d_tiles = nullptr;
+    int64_t split_batch = 0;        // walkers per sub-batch (0 = split path unavailable for this problem)
+    // MSX_PATH_AUTO takes the split path at / above these sizes.  Measured: the fused kernel is bound by
+    // VALU issue, not by the L2 port, once a few workgroups share a CU, so sharing row loads buys nothing and the
+    // split form's extra round trip through the model scratch costs; the defaults therefore never pick it.
+    // MSX_SPLIT_MIN / MSX_SPLIT_MIN_NPIX (environment, read at msx_stage_problem) lower them.
+    int64_t split_min_walkers = INT64_MAX, split_min_npix = INT64_MAX;
+    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _SPLIT (msx_set_path)
+    bool recipe_fast = false;       // the register-resident recipe applies (small tables)
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
 };
 static void sampler_free(msx_ctx *c);
@@ -134,6 +150,8 @@ RcclApi &rccl() {
 }
 constexpr int kNcclFloat64 = 8;  // ncclFloat64 / ncclDouble (rccl.h)
 
+int raise_dynamic_lds_limits(msx_ctx *c);  // (defined next to the launchers)
+
 int fail(msx_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
     return code;
@@ -170,6 +188,11 @@ void free_problem(msx_ctx *c) {
     if (c->d_opt_med) (void)hipFree(c->d_opt_med);
     c->d_opt_flux = c->d_opt_med = nullptr;
     c->opt_chains = 0;
+    void *sp[] = {c->d_rec, c->d_perm, c->d_hdr, c->d_tmp, c->d_tiles, c->d_model_scratch};
+    for (void *p : sp)
+        if (p) (void)hipFree(p);
+    c->d_rec = nullptr; c->d_perm = c->d_hdr = c->d_tmp = nullptr; c->d_tiles = nullptr;
+    c->d_model_scratch = nullptr; c->cap_model_scratch = 0; c->split_batch = 0;
 }
 
 void free_grid(msx_ctx *c) {
@@ -234,6 +257,108 @@ int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
 
 }  // namespace
 
+// ---- launchers ------------------------------------------------------------------------------------------------
+namespace {
+
+struct LaunchArgs {
+    const double *theta;
+    double *logp;
+    int32_t *status;
+    int64_t n;
+    int32_t ndim, mode;
+    hipStream_t s;
+    int niso_nt, ng_mode_fast;
+};
+
+// A copy of the staged problem whose per-walker pointers start at walker `off` of the caller's batch (sub-batches)
+DevProblem problem_at(const DevProblem &P0, int64_t off, int mode, int ndim) {
+    DevProblem P = P0;
+    if (off == 0) return P;
+    if (P.opt_chain) P.opt_chain += off;
+    if (mode == MSX_MODE_OPT_INIT) { P.opt_flux += off * P.npix; P.opt_med += off; }
+    if (P.smp_on) {
+        P.smp_sidx += off; P.smp_cidx += off; P.smp_partner += off;
+        P.smp_zz += off; P.smp_zfac += off; P.smp_logu += off;
+        P.smp_q += off * ndim;
+    }
+    return P;
+}
+
+// One launch of logprob_kernel<..., STAGE> over A.n walkers with workgroups of B threads.
+//   STAGE 0 fused, STAGE 2 median / chi^2 from the stored model vectors: every variant of the table in pick_block();
+//   STAGE 1 the recipe alone: 256 threads, no dynamic LDS.
+template <int STAGE>
+int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
+    const dim3 g((unsigned)A.n);
+    const size_t lds = sizeof(double) * (size_t)P.npix;
+#define MSX_LEAD_ARGS A.theta, P.iso_t, P.iso_g, P.teff_nodes, P.logg_nodes, P.present, A.niso_nt, A.ng_mode_fast
+#define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                      \
+    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, STAGE>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
+                       A.n, A.ndim, A.logp, A.status)
+    if constexpr (STAGE == 1) {
+        if (P.nspec == 2) MSX_GO(2, 1, 256, false, false, false, 0); else MSX_GO(3, 1, 256, false, false, false, 0);
+    } else if (c->model_in_global) {
+        // spectra longer than the LDS: the model vector lives in the global scratch (STAGE 0 writes it there itself)
+        if (P.nspec == 2) MSX_GO(2, 1, 1024, true, false, false, 0); else MSX_GO(3, 1, 1024, true, false, false, 0);
+    } else {
+        // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 4 npix doubles fit
+        const bool cp = STAGE == 0 && P.pairs_c != nullptr;
+        const bool pf = B == 512 && !shared512 && A.n <= c->prop.multiProcessorCount && !cp && c->pf_ok && c->use_pf;
+        if (P.nspec == 2) {
+            if (B == 256) { if (cp) MSX_GO(2, 2, 256, false, STAGE == 0, false, lds); else MSX_GO(2, 2, 256, false, false, false, lds); }
+            else if (B == 512) {
+                if (pf) MSX_GO(2, 2, 512, false, false, true, 4 * lds);
+                else if (cp) MSX_GO(2, 2, 512, false, STAGE == 0, false, lds);
+                else if (shared512 || A.n > c->prop.multiProcessorCount) MSX_GO(2, 1, 512, false, false, false, lds);  // two per CU
+                else MSX_GO(2, 2, 512, false, false, false, lds);
+            } else MSX_GO(2, 1, 1024, false, false, false, lds);
+        } else {
+            if (B == 256) MSX_GO(3, 1, 256, false, false, false, lds);
+            else if (B == 512) { if (pf) MSX_GO(3, 1, 512, false, false, true, 4 * lds); else MSX_GO(3, 1, 512, false, false, false, lds); }
+            else MSX_GO(3, 1, 1024, false, false, false, lds);
+        }
+    }
+#undef MSX_GO
+#undef MSX_LEAD_ARGS
+    HIP_TRY(c, hipGetLastError());
+    return MSX_OK;
+}
+
+// Every variant that takes dynamic LDS may be launched with up to the CU's 160 KiB minus its own static LDS.
+// The limit is a property of the FUNCTION in this process, not of a context: it is raised once, to the maximum,
+// so that contexts staged with different spectrum lengths can never lower it under one another.
+template <typename K>
+hipError_t raise_one(K kernel) {
+    hipFuncAttributes at;
+    hipError_t e = hipFuncGetAttributes(&at, (const void *)kernel);
+    if (e != hipSuccess) return e;
+    const int room = (160 * 1024 - (int)at.sharedSizeBytes) & ~15;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room);
+}
+template <int STAGE>
+hipError_t raise_stage() {
+    hipError_t e = hipSuccess;
+#define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__, STAGE>)
+    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 512, false, false, false); MSX_R(2, 1, 512, false, false, false);
+    MSX_R(2, 1, 1024, false, false, false); MSX_R(2, 2, 512, false, false, true);
+    MSX_R(3, 1, 256, false, false, false); MSX_R(3, 1, 512, false, false, false); MSX_R(3, 1, 1024, false, false, false);
+    MSX_R(3, 1, 512, false, false, true);
+    if (STAGE == 0) { MSX_R(2, 2, 256, false, STAGE == 0, false); MSX_R(2, 2, 512, false, STAGE == 0, false); }
+#undef MSX_R
+    return e;
+}
+int raise_dynamic_lds_limits(msx_ctx *c) {
+    static bool done[16] = {};
+    if (c->device < 0 || c->device >= 16 || done[c->device]) return MSX_OK;
+    HIP_TRY(c, raise_stage<0>());
+    HIP_TRY(c, raise_stage<2>());
+    HIP_TRY(c, raise_one(broaden_conv_kernel));
+    done[c->device] = true;
+    return MSX_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int msx_create(int device, msx_ctx **out) {
@@ -258,8 +383,7 @@ void msx_destroy(msx_ctx *c) {
     sampler_free(c);
     free_problem(c);
     free_grid(c);
-    void *ptrs[] = {c->d_theta, c->d_logp, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain,
-                    c->d_model_scratch};
+    void *ptrs[] = {c->d_theta, c->d_logp, c->d_misc, c->d_spec, c->d_opt_flux, c->d_opt_med, c->d_opt_chain};
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -537,26 +661,32 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     }
     P.band_tab = d_tab;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // the hot kernel may need more than the default 64 KiB of dynamic LDS
     c->max_dyn_lds = (int)need_lds;
     c->model_in_global = model_in_global;
-    if (need_lds > 48 * 1024 && !model_in_global) {
-        const void *variants[] = {(const void *)logprob_kernel<2, 2, 256>, (const void *)logprob_kernel<2, 2, 512>,
-                                  (const void *)logprob_kernel<2, 1, 512>,
-                                  (const void *)logprob_kernel<2, 1, 1024>,
-                                  (const void *)logprob_kernel<2, 2, 256, false, true>,
-                                  (const void *)logprob_kernel<2, 2, 512, false, true>,
-                                  (const void *)logprob_kernel<3, 1, 256>, (const void *)logprob_kernel<3, 1, 512>,
-                                  (const void *)logprob_kernel<3, 1, 1024>};
-        for (const void *k : variants)
-            HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_lds));
-    }
-    c->pf_ok = !model_in_global && 4 * need_lds <= 148 * 1024;  // + ~9 KB static scratch <= 160 KB
-    if (c->pf_ok) {
-        const void *variants[] = {(const void *)logprob_kernel<2, 2, 512, false, false, true>,
-                                  (const void *)logprob_kernel<3, 1, 512, false, false, true>};
-        for (const void *k : variants)
-            HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * need_lds)));
+    c->pf_ok = !model_in_global && 4 * need_lds <= 148 * 1024;  // + ~12 KB static scratch <= 160 KB
+    if ((rc = raise_dynamic_lds_limits(c))) return rc;
+    c->recipe_fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave && P.nav + 1 <= 2 * kWave;
+    // Scratch of the split path, sized once here so that no launch ever allocates or synchronises: a batch is
+    // cut into sub-batches whose model vectors (walkers x npix doubles) stay inside the Infinity Cache between the
+    // blend kernel that writes them and the median / chi^2 kernel that reads them back.
+    {
+        int64_t budget = 96ll << 20;
+        if (const char *e = getenv("MSX_SPLIT_SCRATCH_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
+        int64_t sb = budget / (int64_t)(sizeof(double) * p->npix);
+        sb = std::max<int64_t>(256, std::min<int64_t>(sb, 16384));
+        if (const char *e = getenv("MSX_SPLIT_BATCH")) sb = std::max<int64_t>(1, atoll(e));
+        HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * sb * p->npix));
+        c->cap_model_scratch = sb * p->npix;
+        HIP_TRY(c, hipMalloc((void **)&c->d_rec, sizeof(WalkerRec) * sb));
+        HIP_TRY(c, hipMalloc((void **)&c->d_perm, sizeof(int32_t) * sb));
+        HIP_TRY(c, hipMalloc((void **)&c->d_tmp, sizeof(int32_t) * 2 * sb));
+        HIP_TRY(c, hipMalloc((void **)&c->d_tiles, sizeof(TileHdr) * sb));
+        HIP_TRY(c, hipMalloc((void **)&c->d_hdr, 64));
+        c->split_batch = sb;
+        P.model_scratch = c->d_model_scratch;
+        P.rec = c->d_rec;
+        if (const char *e = getenv("MSX_SPLIT_MIN")) c->split_min_walkers = std::max<int64_t>(1, atoll(e));
+        if (const char *e = getenv("MSX_SPLIT_MIN_NPIX")) c->split_min_npix = std::max<int64_t>(1, atoll(e));
     }
 #ifdef MSX_STAMPS
     {   // diagnostic build only: per-walker shader-clock stamps
@@ -585,6 +715,12 @@ int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
 }
 #endif
 
+int msx_set_path(msx_ctx *c, int32_t path) {
+    if (!c || path < MSX_PATH_AUTO || path > MSX_PATH_SPLIT) return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path");
+    c->path = path;
+    return MSX_OK;
+}
+
 int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
                           int32_t *d_status, void *hip_stream, int32_t block_threads) {
     if (!c) return MSX_ERR_INVALID;
@@ -598,67 +734,66 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (n == 0) return MSX_OK;
     const bool shared512 = block_threads == MSX_BLOCK_512_SHARED;  // 512 threads, the <= 128-VGPR variant that
     if (shared512) block_threads = 512;                            // shares a CU with another workgroup
-    int B = block_threads > 0 ? block_threads : pick_block(c, n, c->P.npix);
-    // the median's bin scan assigns kBins/B bins to each thread and the radix fallback clears its
-    // 256-bin histogram with tid < 256
-    if (B != 256 && B != 512 && B != 1024) return fail(c, MSX_ERR_INVALID, "block_threads must be 256, 512 or 1024");
+    if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 1024)
+        return fail(c, MSX_ERR_INVALID, "block_threads must be 0, 256, 512, 1024 or MSX_BLOCK_512_SHARED");
     hipStream_t s = (hipStream_t)hip_stream;
-    const size_t lds = sizeof(double) * (size_t)c->P.npix;
+    const DevProblem &Pc = c->P;
     // the leading, preloaded kernel arguments (see logprob_kernel): theta, the recipe's small tables and three
     // packed ints; `fast` = the tables fit the register-resident recipe
-    const DevProblem &Pc = c->P;
-    const bool fast = Pc.niso <= 4 * kWave && Pc.nt <= kWave && Pc.ng <= kWave && Pc.nt * Pc.ng <= 2 * kWave &&
-                      Pc.nav + 1 <= 2 * kWave;
-    const int niso_nt = (int)(std::min<int64_t>(Pc.niso, 0xffff) | ((int64_t)std::min<int64_t>(Pc.nt, 0x7fff) << 16));
-    const int ng_mode_fast = (int)std::min<int64_t>(Pc.ng, 0xff) | (mode << 8) | ((fast ? 1 : 0) << 16);
-#define MSX_LEAD_ARGS d_theta, Pc.iso_t, Pc.iso_g, Pc.teff_nodes, Pc.logg_nodes, Pc.present, niso_nt, ng_mode_fast
-    if (c->model_in_global) {
-        // long spectra: model vector in global memory, no dynamic LDS, 1024 threads.  The scratch grows on
-        // demand (a synchronous hipMalloc: not capturable into a graph the first time a size is seen)
-        const int64_t need = n * c->P.npix;
-        if (need > c->cap_model_scratch) {
-            HIP_TRY(c, hipSetDevice(c->device));
-            HIP_TRY(c, hipStreamSynchronize(s));
-            if (c->d_model_scratch) (void)hipFree(c->d_model_scratch);
-            c->d_model_scratch = nullptr; c->cap_model_scratch = 0;
-            HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * need));
-            c->cap_model_scratch = need;
+    const bool fast = c->recipe_fast;
+    LaunchArgs A;
+    A.ndim = ndim; A.mode = mode; A.s = s;
+    A.niso_nt = (int)(std::min<int64_t>(Pc.niso, 0xffff) | ((int64_t)std::min<int64_t>(Pc.nt, 0x7fff) << 16));
+    A.ng_mode_fast = (int)std::min<int64_t>(Pc.ng, 0xff) | (mode << 8) | ((fast ? 1 : 0) << 16);
+
+    // ---- which form of the path -------------------------------------------------------------------------
+    // split (split_kernels.h): many walkers (shared row loads) or long spectra (pixels over all CUs).  Only the
+    // likelihood / posterior / chi^2 modes of a problem with a spectrum term, float64 pairs and small recipe tables.
+    const bool can_split = c->split_batch > 0 && fast && !Pc.no_spectrum && !Pc.pairs_c && !Pc.smp_on &&
+                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    bool split = can_split && (n >= c->split_min_walkers || Pc.npix >= c->split_min_npix);
+    if (c->path == MSX_PATH_FUSED) split = false;
+    if (c->path == MSX_PATH_SPLIT) {
+        if (!can_split) return fail(c, MSX_ERR_STATE, "msx_set_path(SPLIT): this problem / mode has no split form");
+        split = true;
+    }
+    // sub-batches: the split path's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
+    // hold split_batch walkers
+    const int64_t step = (split || c->model_in_global) ? c->split_batch : n;
+    const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    for (int64_t off = 0; off < n; off += step) {
+        const int64_t m = std::min<int64_t>(step, n - off);
+        A.theta = d_theta + off * ndim; A.logp = d_logp + off; A.status = d_status + off; A.n = m;
+        const DevProblem P = problem_at(Pc, off, mode, ndim);
+        const int B = block_threads > 0 ? block_threads : pick_block(c, m, Pc.npix);
+        int rc;
+        if (!split) {
+            if ((rc = launch_logprob<0>(c, P, A, B, shared512))) return rc;
+            continue;
         }
-        c->P.model_scratch = c->d_model_scratch;
-        const dim3 gg((unsigned)n), bb(1024);
-        if (c->P.nspec == 2)
-            hipLaunchKernelGGL((logprob_kernel<2, 1, 1024, true>), gg, bb, 0, s, MSX_LEAD_ARGS, c->P, n, ndim, d_logp, d_status);
-        else
-            hipLaunchKernelGGL((logprob_kernel<3, 1, 1024, true>), gg, bb, 0, s, MSX_LEAD_ARGS, c->P, n, ndim, d_logp, d_status);
+        // 1. recipes -> records (rejected walkers are finished here)
+        if ((rc = launch_logprob<1>(c, P, A, 256, false))) return rc;
+        // 2. group by grid cell, cut into tiles
+        hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kPlanThreads), 0, s, c->d_rec, (int)m, Pc.nspec * 4, c->d_perm,
+                           c->d_tiles, c->d_hdr, c->d_tmp, c->d_tmp + c->split_batch);
         HIP_TRY(c, hipGetLastError());
-        return MSX_OK;
+        // 3. blend: (tile, pixel chunk) work items, grid-strided; the grid is a multiple of 8 (XCD-local chunks)
+        {
+            constexpr int U = 2;
+            const int64_t nchunk = (Pc.npix + 256 * U - 1) / (256 * U);
+            const int64_t items = m * nchunk;  // upper bound: one tile per walker
+            const unsigned grid = (unsigned)(std::min<int64_t>((items + 7) / 8 * 8, cus * 8));
+            if (Pc.nspec == 2)
+                hipLaunchKernelGGL((blend_tiles_kernel<2, U>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles,
+                                   c->d_hdr, Pc.pairs, Pc.pix_k, Pc.pix_t, (int)Pc.npix, c->d_model_scratch);
+            else
+                hipLaunchKernelGGL((blend_tiles_kernel<3, U>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles,
+                                   c->d_hdr, Pc.pairs, Pc.pix_k, Pc.pix_t, (int)Pc.npix, c->d_model_scratch);
+            HIP_TRY(c, hipGetLastError());
+        }
+        // 4. per walker: fit sums, exact median, chi^2, combine
+        if ((rc = launch_logprob<2>(c, P, A, B, shared512))) return rc;
     }
-    const dim3 g((unsigned)n), b((unsigned)B);
-    // pixel statics staged in LDS by the idle waves: 512-thread workgroups that own their CU (one per CU anyway)
-    // and whose 4 npix doubles fit beside the scratch
-    const bool pf = B == 512 && !shared512 && n <= c->prop.multiProcessorCount && !c->P.pairs_c && c->pf_ok && c->use_pf;
-    // every variant is compiled for, and launched with, exactly its thread count (the canonical summation order
-    // relies on it)
-#define MSX_GO(NS_, U_, T_, CP_, PF_, LDS_)                                                                           \
-    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, false, CP_, PF_>), g, b, (LDS_), s, MSX_LEAD_ARGS, c->P, n, ndim, \
-                       d_logp, d_status)
-    const bool cp = c->P.pairs_c != nullptr;
-    if (c->P.nspec == 2) {
-        if (B == 256) { if (cp) MSX_GO(2, 2, 256, true, false, lds); else MSX_GO(2, 2, 256, false, false, lds); }
-        else if (B == 512) {
-            if (pf) MSX_GO(2, 2, 512, false, true, 4 * lds);
-            else if (cp) MSX_GO(2, 2, 512, true, false, lds);
-            else if (shared512 || n > c->prop.multiProcessorCount) MSX_GO(2, 1, 512, false, false, lds);  // two workgroups per CU
-            else MSX_GO(2, 2, 512, false, false, lds);
-        } else MSX_GO(2, 1, 1024, false, false, lds);
-    } else {
-        if (B == 256) MSX_GO(3, 1, 256, false, false, lds);
-        else if (B == 512) { if (pf) MSX_GO(3, 1, 512, false, true, 4 * lds); else MSX_GO(3, 1, 512, false, false, lds); }
-        else MSX_GO(3, 1, 1024, false, false, lds);
-    }
-#undef MSX_GO
-#undef MSX_LEAD_ARGS
-    HIP_TRY(c, hipGetLastError());
     return MSX_OK;
 }
 

@@ -56,10 +56,10 @@ __device__ void build_desc(const DevProblem &P, const double *teff, const double
             sc = (s == 0) ? 1.0 : rad[s - 1] * rad[s - 1];  // mft6.py:703
         }
         starscale[s] = sc;
-        D->node[4 * s + 0] = n11; D->w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
-        D->node[4 * s + 1] = n12; D->w[4 * s + 1] = (1.0 - b) * a * sc;
-        D->node[4 * s + 2] = n21; D->w[4 * s + 2] = b * (1.0 - a) * sc;
-        D->node[4 * s + 3] = n22; D->w[4 * s + 3] = b * a * sc;
+        int nd4[4] = {n11, n12, n21, n22};
+        double w4[4] = {(1.0 - b) * (1.0 - a) * sc, (1.0 - b) * a * sc, b * (1.0 - a) * sc, b * a * sc};
+        sort4_by_node(nd4, w4);  // canonical corner order (blend.h)
+        for (int k = 0; k < 4; ++k) { D->node[4 * s + k] = nd4[k]; D->w[4 * s + k] = w4[k]; }
     }
     (void)starscale;
     const bool redden = P.use_av && a_v > 0.0;  // mft6.py:1161
@@ -266,10 +266,11 @@ __device__ __forceinline__ void build_recipe_wave(const DevProblem &P, const Rec
         const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
         const double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
         const double sc = q * q;
-        node[4 * s + 0] = n11; w[4 * s + 0] = (1.0 - b) * (1.0 - a) * sc;
-        node[4 * s + 1] = n12; w[4 * s + 1] = (1.0 - b) * a * sc;
-        node[4 * s + 2] = n21; w[4 * s + 2] = b * (1.0 - a) * sc;
-        node[4 * s + 3] = n22; w[4 * s + 3] = b * a * sc;
+        int nd4[4] = {n11, n12, n21, n22};
+        double w4[4] = {(1.0 - b) * (1.0 - a) * sc, (1.0 - b) * a * sc, b * (1.0 - a) * sc, b * a * sc};
+        sort4_by_node(nd4, w4);  // canonical corner order (blend.h)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { node[4 * s + k] = nd4[k]; w[4 * s + k] = w4[k]; }
     }
     if (st != MSX_W_OK) {
         if (lane == 0) D.status = st;
@@ -463,6 +464,7 @@ __device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const Rec
             node[1] = n12; w[1] = (1.0 - b) * a * sc;
             node[2] = n21; w[2] = b * (1.0 - a) * sc;
             node[3] = n22; w[3] = b * a * sc;
+            sort4_by_node(node, w);  // canonical corner order (blend.h): a function of the grid cell alone
         } while (false);
     }
     MSX_STAMP(P, wk, 10);

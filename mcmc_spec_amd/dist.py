@@ -16,6 +16,9 @@ from __future__ import annotations
 import numpy as np
 
 
+_ERR_CODES = [KeyError, IndexError, ValueError]   # the reference's conventions, in status order
+
+
 def shard_bounds(n, world, rank):
     """Contiguous block partition with equal block length m = ceil(n / world).  Returns (lo, hi, m)."""
     m = -(-n // world)
@@ -52,10 +55,33 @@ class ShardedLogProb:
         if len(block) < m:  # ragged tail (or an empty shard): pad with the last walker, dropped below
             pad = np.repeat(coords[-1:], m - len(block), axis=0)
             block = np.concatenate([block, pad], axis=0)
-        local = np.asarray(self.local_eval(block, *args, **kwargs), dtype=float)
+        # The local evaluator follows the reference's error conventions: it may RAISE (KeyError for a missing grid
+        # node, IndexError, ValueError -- data-dependent, so possibly on one rank only).  A rank that raised before
+        # the collective would leave the others blocked in it, so the exception is held back, every rank learns the
+        # worst outcome through the same collective sequence, and then every rank raises the same exception.
+        err, local = None, None
+        try:
+            local = np.asarray(self.local_eval(block, *args, **kwargs), dtype=float)
+            if local.shape != (m,):
+                raise ValueError('local_eval returned shape {} for a block of {} walkers'.format(local.shape, m))
+        except Exception as exc:  # noqa: BLE001 - re-raised below, on every rank
+            err = exc
+            local = np.full(m, np.nan)
+        code = 0 if err is None else (_ERR_CODES.index(type(err)) + 1 if type(err) in _ERR_CODES else len(_ERR_CODES) + 1)
+        flag = torch.tensor([code, self.rank if code else -1], dtype=torch.int64, device=self.device)
+        flags = torch.empty(2 * self.world, dtype=torch.int64, device=self.device)
+        self.dist.all_gather_into_tensor(flags, flag, group=self.group)
         send = torch.from_numpy(np.ascontiguousarray(local)).to(self.device)
         recv = torch.empty(m * self.world, dtype=torch.float64, device=self.device)
         self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        codes = flags.cpu().numpy().reshape(self.world, 2)[:, 0]
+        if codes.any():
+            first = int(np.nonzero(codes)[0][0])           # the lowest failing rank decides, on every rank
+            if first == self.rank:
+                raise err
+            c = int(codes[first])
+            cls = _ERR_CODES[c - 1] if c <= len(_ERR_CODES) else RuntimeError
+            raise cls('walker evaluation failed on rank {} ({}); raised on every rank'.format(first, cls.__name__))
         out = recv.cpu().numpy()
         # rank r's valid entries are the first (hi_r - lo_r) of its block
         parts = []

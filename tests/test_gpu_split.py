@@ -1,0 +1,149 @@
+"""The SPLIT form of the hot path (recipe kernel -> tile planner -> walker-tiled blend kernel -> per-walker median /
+chi^2 kernel, mcmc_spec_amd/csrc/split_kernels.h) against the fused kernel and the reference goldens.
+
+The contract is stronger than the parity bar: both forms call the same per-pixel function and sum in the same
+canonical order, so a walker's value must have the SAME BITS whichever form evaluates it, whatever tile it lands
+in, whatever the sub-batch size.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from common import golden_case, rel_err
+from test_gpu_parity import make_engine
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-9
+
+
+def both(eng, fn, *a, **k):
+    from mcmc_spec_amd import _lib
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    f = fn(*a, **k)
+    eng.ctx.set_path(_lib.PATH_SPLIT)
+    s = fn(*a, **k)
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    return f, s
+
+
+@pytest.mark.parametrize('which', ['A', 'B'])
+def test_split_matches_reference_golden_and_fused_bits(which):
+    c = golden_case(which)
+    eng = make_engine(c)
+    f, s = both(eng, eng.loglikelihood, c.theta)
+    assert np.array_equal(f, s)
+    assert rel_err(s, c.g[which + '_loglike']).max() < TIGHT
+    f, s = both(eng, eng.loglikelihood, c.theta, optimize=True)
+    assert np.array_equal(f, s)
+    if which == 'A':
+        th = c.g['theta_post']          # includes walkers outside the prior box: -inf from stage 1 alone
+        f, s = both(eng, eng.logposterior, th)
+        assert np.array_equal(f, s) and np.isinf(s).sum() == 8
+        assert rel_err(s, c.g['A_logpost_noradprior']).max() < TIGHT
+
+
+def test_split_triple_system_and_batch_shapes():
+    c = golden_case('C')
+    eng = make_engine(c, rad_prior=True)
+    th = c.theta
+    f, s = both(eng, eng.logposterior, th)
+    assert np.array_equal(f, s)
+    assert rel_err(s, c.g['C_logpost']).max() < TIGHT
+    # every batch length around the tile size (8 walkers share one load) and a walker at a time
+    for n in (1, 2, 7, 8, 9, 15, 16, 17):
+        f, s = both(eng, eng.logposterior, th[:n])
+        assert np.array_equal(f, s), n
+
+
+def test_split_values_do_not_depend_on_tiling_or_sub_batches(monkeypatch):
+    """Many walkers in few grid cells (tiles of 8 + ragged tails), then the same walkers shuffled, duplicated
+    and cut into tiny sub-batches: identical bits every time."""
+    from mcmc_spec_amd import _lib
+    c = golden_case('B')
+    rng = np.random.default_rng(17)
+    th = c.theta[0] + rng.normal(size=(700, 6)) * np.array([120, 120, 0.05, 0.05, 0.05, 1e-4])
+    th[:, 0:2] = np.clip(th[:, 0:2], 3000.0, 4200.0)
+    th[:, 2] = np.abs(th[:, 2])
+    th[:, 3:5] = np.clip(th[:, 3:5], 0.05, 1.4)
+    th[5, 0] = 3800.0                    # Teff exactly on a node: duplicated corners with weight 0
+    th[6, 2] = 0.0                       # A_V = 0: no reddening
+    th[7, 1] = 2999.0                    # outside the box in posterior mode
+    eng = make_engine(c)
+    f, s = both(eng, eng.logposterior, th)
+    assert np.array_equal(f, s) and np.isinf(s[7])
+    perm = rng.permutation(len(th))
+    eng.ctx.set_path(_lib.PATH_SPLIT)
+    assert np.array_equal(eng.logposterior(th[perm]), s[perm])
+    dup = np.concatenate([th[:40], th[:40], th[100:140]])
+    assert np.array_equal(eng.logposterior(dup), np.concatenate([s[:40], s[:40], s[100:140]]))
+    # sub-batches of 48 walkers (the scratch is sized at staging from the environment)
+    monkeypatch.setenv('MSX_SPLIT_BATCH', '48')
+    eng2 = make_engine(c)
+    eng2.ctx.set_path(_lib.PATH_SPLIT)
+    assert np.array_equal(eng2.logposterior(th), s)
+    # the automatic choice takes the split form from MSX_SPLIT_MIN walkers on (unset: never)
+    monkeypatch.setenv('MSX_SPLIT_MIN', '1024')
+    eng3 = make_engine(c)
+    big = np.concatenate([th, th[:400]])
+    assert np.array_equal(eng3.logposterior(big), np.concatenate([s, s[:400]]))
+
+
+def test_split_error_statuses_and_modes_without_a_split_form():
+    from mcmc_spec_amd import _lib, bands
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    eng = make_engine(c)
+    eng.ctx.set_path(_lib.PATH_SPLIT)
+    bad = c.theta[:12].copy()
+    bad[3, 1] = 2800.0                   # outside the isochrone table: ValueError in likelihood mode (mft6.py:95)
+    with pytest.raises(ValueError):
+        eng.loglikelihood(bad)
+    lp = eng.logposterior(bad)           # the prior box rejects it first: a value
+    assert lp[3] == -np.inf and np.all(np.isfinite(np.delete(lp, 3)))
+    with pytest.raises(_lib.MsxError):   # logprior alone has no spectrum pass, hence no split form
+        eng.logprior(c.theta)
+    specs = dict(c.specs)
+    del specs['3800, 5.0']
+    e2 = Engine(0)
+    e2.stage_specs(specs)
+    e2.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                     bands=bands.make_bands(c.tables, *c.vega))
+    e2.ctx.set_path(_lib.PATH_SPLIT)
+    with pytest.raises(KeyError):
+        e2.loglikelihood(c.theta[:9])
+
+
+@pytest.mark.parametrize('npix,phot,n', [(4096, False, 2304), (16384, True, 160)], ids=['config2', 'config4'])
+def test_split_full_size_bits(npix, phot, n):
+    """BASELINE config 2 / 3 (many walkers) and config 4 (long spectrum + photometry, a GPU's share of walkers)."""
+    import bench
+    from mcmc_spec_amd import synth
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    W = bench.build_workload(eng, npix, phot)
+    th = synth.draw_walkers(n, seed=9, tmin=W['tmin'], tmax=W['tmax'])
+    f, s = both(eng, eng.logposterior, th)
+    assert np.array_equal(f, s) and np.all(np.isfinite(s))
+
+
+def test_split_spectrum_longer_than_lds():
+    """> 19,200 pixels: the model vector never fits LDS; stage 4 reads it straight from the scratch."""
+    from mcmc_spec_amd import synth
+    c = golden_case('B')
+    rng = np.random.default_rng(3)
+    wl = np.sort(rng.uniform(0.56, 0.89, 21000))
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    f, s = both(eng, eng.loglikelihood, c.theta[:20])
+    assert np.array_equal(f, s) and np.all(np.isfinite(s))
+    one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(s[0], one) < TIGHT

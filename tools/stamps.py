@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--walkers', type=int, default=256)
     ap.add_argument('--block', type=int, default=0)
     ap.add_argument('--npix', type=int, default=4096)
+    ap.add_argument('--path', default='fused', help='fused | split (split: the stamps are those of the LAST kernel, stage 2)')
     args = ap.parse_args()
     import torch
     from bench import build_workload
@@ -32,6 +33,7 @@ def main():
     lp = torch.empty(n, dtype=torch.float64, device=dev)
     st = torch.empty(n, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
+    eng.ctx.set_path(_lib.PATH_SPLIT if args.path == 'split' else _lib.PATH_FUSED)
     for _ in range(20):
         eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), s, _lib.MODE_LOGPOST, args.block)
     torch.cuda.synchronize()
@@ -40,6 +42,23 @@ def main():
     fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     fn.restype = C.c_int
     assert fn(eng.ctx.h, n, out.ctypes.data) == 0
+    if args.path == 'split':
+        o = out.astype(np.int64)
+        tot = o[:, 7] - o[:, 0]
+        print('split path, stage 2 (median / chi^2 kernel), walkers {} block {}: median total {} cycles'.format(n, args.block or 'auto', int(np.median(tot))))
+        for nm, a, b in [('start -> phase A done', 0, 2), ('reduce q/minmax', 2, 3), ('median + chi2 pass', 3, 4), ('finish', 4, 7)]:
+            v = o[:, b] - o[:, a]
+            print('  {:24s} median {:8d} cycles  ({:5.1f} %)'.format(nm, int(np.median(v)), 100 * np.median(v) / np.median(tot)))
+        med = np.zeros((n, 8), dtype=np.uint64)
+        fm = eng.ctx.lib.msx_diag_read_med_stamps
+        fm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        fm.restype = C.c_int
+        assert fm(eng.ctx.h, n, med.ctypes.data) == 0
+        dm = np.diff(med[:, :5].astype(np.int64), axis=1)
+        for i, nm in enumerate(['(entry)', 'bin scan', 'chi2+gather pass+barrier', 'rank']):
+            print('    median/{:24s} median {:8d} cycles'.format(nm, int(np.median(dm[:, i]))))
+        print('  first start -> last end: {} cycles'.format(int(o[:, 7].max() - o[:, 0].min())))
+        return
     d = np.diff(out[:, :8].astype(np.int64), axis=1)
     names = ['phase0 recipe', 'phaseA blend', 'reduce q/minmax', 'radix select', 'second rank', 'phaseC chi2', 'reduce chi2']
     tot = (out[:, 7] - out[:, 0]).astype(np.int64)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Batch-size x workgroup-size sweep of the hot kernel (kernel time from HIP events on the launch stream)."""
+"""Batch-size x workgroup-size x path (fused / split) sweep of the hot path: device time per batch from HIP events
+on the launch stream.  `--graph` replays each batch from a hipGraph (no host launch gaps between the split path's
+launches)."""
 import argparse
 import json
 import os
@@ -17,6 +19,8 @@ def main():
     ap.add_argument('--walkers', default='128,256,512,1024,2048,4096,16384')
     ap.add_argument('--blocks', default='256,512,1024')
     ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--paths', default='fused,split')
+    ap.add_argument('--graph', action='store_true')
     args = ap.parse_args()
     import torch
     from bench import build_workload
@@ -32,21 +36,36 @@ def main():
         th = torch.from_numpy(synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
         lp = torch.empty(n, dtype=torch.float64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
-        for B in [int(x) for x in args.blocks.split(',')]:
-            def go():
-                eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), stream.cuda_stream,
-                                          _lib.MODE_LOGPOST, B)
-            for _ in range(5):
-                go()
+        for path in args.paths.split(','):
+          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'split': _lib.PATH_SPLIT}[path])
+          for B in [int(x) for x in args.blocks.split(',')]:
+            def go(sp):
+                eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), sp, _lib.MODE_LOGPOST, B)
+            iters = max(3, min(args.iters, int(2e6 / n)))
+            if args.graph:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=torch.cuda.Stream(dev)):
+                    for _ in range(iters):
+                        go(torch.cuda.current_stream(dev).cuda_stream)
+                run = g.replay
+                reps = 3
+            else:
+                def run():
+                    for _ in range(iters):
+                        go(stream.cuda_stream)
+                reps = 1
+            run()
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            for _ in range(args.iters):
-                go()
+            for _ in range(reps):
+                run()
             e1.record(stream)
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / args.iters
-            row = dict(walkers=n, block=B, kernel_us=ms * 1e3, evals_per_s=n / (ms * 1e-3),
-                       alg_GBps=n * b_alg / (ms * 1e-3) / 1e9)
+            ms = e0.elapsed_time(e1) / (iters * reps)
+            row = dict(walkers=n, npix=args.npix, path=path, block=B, batch_us=ms * 1e3, evals_per_s=n / (ms * 1e-3),
+                       alg_GBps=n * b_alg / (ms * 1e-3) / 1e9, graph=bool(args.graph))
             rows.append(row)
             print(json.dumps(row), flush=True)
 
