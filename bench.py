@@ -4,16 +4,17 @@
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config 5            # 8 KOI targets, one independent problem per GPU (replicas, no collective)
 
-One "step" = one fused launch of the per-walker log-posterior (prior gate + two-component spectrum
-synthesis + reddening + resample + median/continuum normalisation + chi^2 + contrast terms) over
-this rank's walkers, inputs resident in HBM, followed -- when N > 1 -- by one RCCL all-gather of the
-log-probabilities (walkers are independent: shard, no other data-path collective).  Workload at
-N = 1 is BASELINE.json configs[1]: binary, 4096-pixel spectrum, 256 walkers; weak scaling keeps
-256 walkers per GPU (N = 8 is configs[2], 2048 walkers).
+One "step" = one fused launch of the per-walker log-posterior (prior gate + two-component spectrum synthesis +
+reddening + resample + median/continuum normalisation + chi^2 + contrast terms) over this rank's walkers, inputs
+resident in HBM, followed -- when N > 1 -- by one RCCL all-gather of the log-probabilities (walkers are
+independent: shard, no other data-path collective).  Workload at N = 1 is BASELINE.json configs[1]: binary,
+4096-pixel spectrum, 256 walkers; weak scaling keeps 256 walkers per GPU (N = 8 is configs[2], 2048 walkers).
 
-Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` and
-`cpu_baseline` objects.
+Rank 0 prints ONE JSON line (contract in the task statement) including `roofline`, `cpu_baseline` and, at N = 1,
+`extra`: the batch-size sweep, BASELINE config 4's per-GPU share and the CPU baseline at the reference's own pool
+width -- every number DESIGN.md quotes comes out of this line or of a file under profiles/.
 """
 import argparse
 import json
@@ -27,17 +28,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-NWIN_DOC = 'B_alg = nspec*4*Nwin*8 + ndim*8 + 8 (SURVEY.md §8d)'
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; L2 ~34.5 TB/s aggregate (66-73 GB/s per CU measured for row gathers
+# served by the XCD's L2); FP32 vector peak 157.3 TFLOP/s -- FP64 vector issues at half that rate (16 lanes per
+# clock per SIMD: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s).
+HBM_PEAK_GBPS = 8000.0
+L2_PEAK_GBPS = 34500.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False):
+def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False, grid=None):
     """Stage the synthetic 26x4x135,000 grid, broaden the data window on the device (A3), synthesise
     a data spectrum at theta* with the GPU's own make_composite and stage the problem."""
     from mcmc_spec_amd import bands, staging, synth
     wl = np.arange(3000, 30000, 0.2)  # mft6.py:343 with specmin/specmax of param_koi2298.txt:15-16
     teffs = np.arange(3000, 5600, 100)
     loggs = np.array([4.0, 4.5, 5.0, 5.5])
-    flux = synth.make_grid(teffs, loggs, wl)
+    flux = grid if grid is not None else synth.make_grid(teffs, loggs, wl)
     eng.stage_grid(wl, teffs, loggs, flux)
     wl_um = synth.data_wavelengths_um(npix)
     r = [float(wl_um.min()), float(wl_um.max())]
@@ -80,6 +86,36 @@ def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid
     return out
 
 
+def build_koi_problem(eng, target_index, grid=None):
+    """BASELINE config 5: one of the eight KOI spectra (prepared exactly like mft6.py:3492-3507; the prepared
+    vectors travel as the committed fixture tests/golden/golden_koi.npz -- /root/reference does not exist on the
+    GPU box) on the full-size synthetic grid, contrast terms through the real lp600 / Kp tables of the fixture."""
+    from mcmc_spec_amd import bands, synth
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_koi.npz'))
+    gr = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_reference.npz'))
+    tag = str(g['targets'][target_index % len(g['targets'])])
+    wl = np.arange(3000, 30000, 0.2)
+    teffs = np.arange(3000, 5600, 100)
+    loggs = np.array([4.0, 4.5, 5.0, 5.5])
+    flux = grid if grid is not None else synth.make_grid(teffs, loggs, wl)
+    eng.stage_grid(wl, teffs, loggs, flux)
+    data, err = [g[tag + '_wl'], g[tag + '_flux']], g[tag + '_err']
+    r = [float(min(data[0])), float(max(data[0]))]
+    eng.broaden_grid_window([np.floor(0.55 * 1e4), np.ceil(0.90 * 1e4)], 1700)  # spmin / spmax of the crop
+    ctm = [[list(gr['ctmA_w0']), list(gr['ctmA_w1'])], [list(gr['ctmA_t0']), list(gr['ctmA_t1'])], [0, 0],
+           [np.mean(gr['ctmA_w0']), np.mean(gr['ctmA_w1'])]]
+    ptm = [[], [], [], []]
+    fr = [synth.EXAMPLE_CMAG, synth.EXAMPLE_CERR, ['lp600', 'Kp'], [], [], []]
+    tmi = min(min(w) for w in ctm[0])
+    tma = max(max(w) for w in ctm[0])
+    tabs, (vw, vf) = synth.synthetic_band_tables(), synth.synthetic_vega()
+    prior = [*np.zeros(10), 2.0732e-3, 0.0277e-3]
+    eng.stage_problem(data, err, fr, r, ctm, ptm, tmi, tma, synth.make_isochrone_matrix(), nspec=2,
+                      bands=bands.make_bands(tabs, vw, vf), av_table=synth.make_av_table(), tmin=float(teffs[0]),
+                      tmax=float(teffs[-1]), prior=prior, rad_prior=True)
+    return dict(tag=tag, npix=len(err), tmin=float(teffs[0]), tmax=float(teffs[-1]), flux=flux)
+
+
 # ------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle driven like emcee drives a pool (BASELINE.md §3).  Only this leg of
 # bench.py touches oracle/.
@@ -95,7 +131,9 @@ def _cpu_one(theta):
                             bandlib=_CPU['bandlib'])
 
 
-def cpu_baseline(W, theta, gpu_logp, budget_s=20.0, procs=0):
+def cpu_baseline(W, theta, gpu_logp, budget_s=20.0, procs=(0,)):
+    """Oracle `logposterior` under multiprocessing.Pool(P) (fork; tables inherited) for each P in `procs`
+    (0 = this job's CPU share, at most 16).  Returns one record per P; the first is `cpu_baseline`."""
     import multiprocessing as mp
     import warnings
     from mcmc_spec_amd import synth
@@ -109,29 +147,55 @@ def cpu_baseline(W, theta, gpu_logp, budget_s=20.0, procs=0):
         b = int(np.clip(np.searchsorted(edges, d, side='right') - 1, 0, len(mu) - 1))
         return mu[b], sig[b]
 
-    _CPU.update(procs=procs, w=W, specs=specs, av_prior=av_prior, bandlib=orc.make_band_library(W['tabs'], *W['vega']))
+    _CPU.update(w=W, specs=specs, av_prior=av_prior, bandlib=orc.make_band_library(W['tabs'], *W['vega']))
     t0 = time.time()
-    first = _cpu_one(theta[0])
+    _cpu_one(theta[0])
     t_one = time.time() - t0
-    # the GPU box gives one GPU's CPU share (16 cores) to this job; never oversubscribe it
-    cores = _CPU.get('procs') or min(len(os.sched_getaffinity(0)), 16)
-    n = int(max(cores, min(len(theta), budget_s * cores / max(t_one, 1e-3))))
-    n = min(n, len(theta))
-    ctx = mp.get_context('fork')  # tables inherited, not pickled per call
-    with ctx.Pool(processes=cores) as pool:
-        pool.map(_cpu_one, theta[:cores])  # warm-up
-        t0 = time.time()
-        res = pool.map(_cpu_one, theta[:n])
-        dt = time.time() - t0
-    res = np.array(res)
-    g = gpu_logp[:n]
-    fin = np.isfinite(res)
-    rel = float(np.max(np.abs(res[fin] - g[fin]) / np.abs(res[fin]))) if fin.any() else 0.0
-    same_inf = bool(np.array_equal(np.isinf(res), np.isinf(g)))
-    return dict(value=n / dt, unit='evals/s', cores=cores, kind='port',
-                sample='{} walkers of the same ensemble, oracle logposterior under multiprocessing.Pool({}) (fork); '
-                       'single eval {:.1f} ms'.format(n, cores, t_one * 1e3),
-                max_rel_err_gpu_vs_oracle=rel, inf_pattern_equal=same_inf)
+    out = []
+    for pw in procs:
+        # the GPU box gives one GPU's CPU share (16 cores) to this job; never oversubscribe it
+        cores = pw or min(len(os.sched_getaffinity(0)), 16)
+        n = int(max(cores, min(len(theta), budget_s * cores / max(t_one, 1e-3))))
+        n = min(n, len(theta))
+        ctx = mp.get_context('fork')  # tables inherited, not pickled per call
+        with ctx.Pool(processes=cores) as pool:
+            pool.map(_cpu_one, theta[:cores])  # warm-up
+            t0 = time.time()
+            res = pool.map(_cpu_one, theta[:n])
+            dt = time.time() - t0
+        res = np.array(res)
+        g = gpu_logp[:n]
+        fin = np.isfinite(res)
+        rel = float(np.max(np.abs(res[fin] - g[fin]) / np.abs(res[fin]))) if fin.any() else 0.0
+        same_inf = bool(np.array_equal(np.isinf(res), np.isinf(g)))
+        out.append(dict(value=n / dt, unit='evals/s', cores=cores, kind='port',
+                        sample='{} walkers of the same ensemble, oracle logposterior under multiprocessing.Pool({}) '
+                               '(fork); single eval {:.1f} ms'.format(n, cores, t_one * 1e3),
+                        max_rel_err_gpu_vs_oracle=rel, inf_pattern_equal=same_inf))
+    return out
+
+
+def device_time_us(eng, theta_dev, lp, st, stream, n, iters):
+    """Mean device time of one launch over `n` walkers (HIP events on the launch stream around `iters` launches)."""
+    import torch
+    from mcmc_spec_amd import _lib
+    def go():
+        eng.ctx.logprob_batch_dev(theta_dev.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), stream.cuda_stream,
+                                  _lib.MODE_LOGPOST, 0)
+    for _ in range(3):
+        go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        go()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def load_profile(name):
+    p = os.path.join(ROOT, 'profiles', name)
+    return json.load(open(p)) if os.path.exists(p) else None
 
 
 def main():
@@ -139,17 +203,26 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--walkers', type=int, default=256, help='walkers per GPU per launch (weak scaling)')
-    ap.add_argument('--npix', type=int, default=4096)
-    ap.add_argument('--phot', action='store_true', help='add the 6-band photometry term (config 4)')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5],
+                    help='BASELINE config: 2/3 = 4096 px + contrast terms (default), 4 = 16384 px + 6-band photometry '
+                         '(128 walkers per GPU), 5 = the eight KOI targets, one independent problem per GPU (512 walkers)')
+    ap.add_argument('--walkers', type=int, default=0, help='walkers per GPU per launch (0 = the config\'s own)')
+    ap.add_argument('--npix', type=int, default=0)
+    ap.add_argument('--phot', action='store_true', help='add the 6-band photometry term')
     ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the sweep / config-4 / P=15 extras of the N = 1 run')
     ap.add_argument('--no-overlap', action='store_true',
                     help='N > 1: wait for each all-gather before the next launch (a single dependent chain)')
-    ap.add_argument('--cpu-budget', type=float, default=20.0)
-    ap.add_argument('--cpu-procs', type=int, default=0, help='CPU baseline pool width (0 = min(affinity, 16))')
+    ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--copy-gib', type=float, default=1.0)
     args = ap.parse_args()
+    if args.config == 4:
+        args.npix, args.phot, args.walkers = args.npix or 16384, True, args.walkers or 128
+    if args.config == 5:
+        args.walkers = args.walkers or 512
+    args.npix = args.npix or 4096
+    args.walkers = args.walkers or 256
 
     # stdout carries exactly ONE line, the result: libraries that print banners there (RCCL does at start-up) are
     # sent to stderr for the duration of the run
@@ -170,14 +243,30 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     force_gather = os.environ.get('MSX_BENCH_FORCE_GATHER') == '1'  # measure collective overhead on one GPU
+    replicas = args.config == 5                                      # independent problems: no collective at all
     if world > 1 or force_gather:
         dist.init_process_group('nccl', device_id=dev)
 
-    eng = Engine(local)
-    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    W = build_workload(eng, args.npix, args.phot, keep_host_grid=want_cpu)
     n = args.walkers
     ndim = 6
+    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline and not replicas)
+    if replicas:
+        # one problem per rank; on ONE GPU the rehearsal keeps all eight staged problems resident and cycles them
+        nprob = 8 if world == 1 else 1
+        engines, infos, grid = [], [], None
+        for k in range(nprob):
+            e = Engine(local)
+            info = build_koi_problem(e, rank if world > 1 else k, grid=grid)
+            grid = info.pop('flux')
+            engines.append(e)
+            infos.append(info)
+        eng = engines[0]
+        W = dict(tmin=infos[0]['tmin'], tmax=infos[0]['tmax'], nwin=None)
+        args.npix = infos[0]['npix']
+    else:
+        eng = Engine(local)
+        engines = [eng]
+        W = build_workload(eng, args.npix, args.phot, keep_host_grid=True)
     # distinct coordinates per rank and a few distinct batches so no launch repeats the previous one
     nbatch = 4
     thetas = [torch.from_numpy(synth.draw_walkers(n, seed=3 + 1000 * rank + b, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
@@ -186,7 +275,7 @@ def main():
     # collective runs on RCCL's stream; a buffer is only reused after its all-gather has completed)
     logp = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
     status = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
-    use_gather = world > 1 or force_gather
+    use_gather = (world > 1 or force_gather) and not replicas
     gathered = [torch.empty(n * world, dtype=torch.float64, device=dev) for _ in range(2)] if use_gather else None
     works = [None, None]
     stream = torch.cuda.current_stream(dev)
@@ -195,31 +284,32 @@ def main():
     # the launch is a plain C call with pre-built arguments (no per-step Python marshalling)
     import ctypes as C
     fn = eng.ctx.lib.msx_logprob_batch_dev
-    h = eng.ctx.h
     # With a collective in flight RCCL's kernel holds a CU or two.  The N = 1 variant (512 threads + 136 KB of LDS:
     # one workgroup per CU, all 256 CUs needed at once) would run a second round for the displaced walkers, so
     # N > 1 launches the 512-thread variant that fits two workgroups per CU (<= 128 VGPRs, 44 KB of LDS;
     # MSX_BLOCK_512_SHARED): 20.2 us alone against 19.1 us, and 23.5 us for 256-thread workgroups.  Same bits.
     block = args.block if args.block else (_lib.BLOCK_512_SHARED if use_gather and args.npix < 8192 else 0)
+
     def calls_for(sp):
-        return [[(h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
-                  C.c_void_p(status[b].data_ptr()), C.c_void_p(sp), block) for b in range(2)] for t in thetas]
+        # step i: problem i mod nprob (config 5 rehearsal), theta batch i mod nbatch, output buffer i mod 2
+        return [[[(e.ctx.h, _lib.MODE_LOGPOST, C.c_void_p(t.data_ptr()), n, ndim, C.c_void_p(logp[b].data_ptr()),
+                   C.c_void_p(status[b].data_ptr()), C.c_void_p(sp), block) for b in range(2)] for t in thetas]
+                for e in engines]
 
     calls = calls_for(sptr)
+    nprob = len(engines)
 
     def launch(i, table=None):
-        if fn(*(table or calls)[i % nbatch][i & 1]) != 0:
-            raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
+        if fn(*(table or calls)[i % nprob][i % nbatch][i & 1]) != 0:
+            raise RuntimeError(eng.ctx.lib.msx_last_error(engines[i % nprob].ctx.h).decode())
 
-    # The collective: one RCCL all-gather of n float64 per rank per step.  Preferred path: the library's own
-    # communicator (msx_comm_*: ncclAllGather enqueued from C on a dedicated stream, ~3 us of host time per
-    # step); its id is broadcast with torch.distributed.  Any failure to set it up falls back to
-    # torch.distributed's all_gather_into_tensor (~12 us of host time per step).  Both are RCCL over xGMI.
+    # The collective: one RCCL all-gather of n float64 per rank per step through torch.distributed (c10d ->
+    # RCCL over xGMI).  (The library's own communicator, msx_comm_*, measured slower per step on one GPU and is
+    # opt-in: MSX_BENCH_COLLECTIVE=rccl.)
     collective = 'none'
+    h = eng.ctx.h
     if use_gather:
         collective = 'torch.distributed'
-        # measured on one GPU (world 1, forced): the direct path costs MORE host time per step (44 us) than
-        # torch.distributed's (33 us), so it is opt-in: MSX_BENCH_COLLECTIVE=rccl
         if os.environ.get('MSX_BENCH_COLLECTIVE', 'torch') == 'rccl':
             try:
                 idt = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -285,21 +375,27 @@ def main():
             gather(i)
     drain()
 
-    # N > 1: the step is launch-bound on the host (kernel launch + collective issue ~ 30 us against a ~25 us
-    # kernel), so a run of `chunk` steps (kernel -> all-gather, double-buffered exactly as above) is captured
-    # into one hipGraph and replayed; the timed region still executes exactly K steps (K // chunk replays, the
-    # remainder issued eagerly).  Any capture failure falls back to the eager loop on every rank.
+    # The step is launch-bound on the host next to a ~20 us kernel (and, N > 1, a collective issue of ~14 us), so a
+    # run of `chunk` steps (kernel -> all-gather, double-buffered exactly as above) is captured into one hipGraph
+    # and replayed; the timed region still executes exactly K steps (K // chunk replays, the remainder eagerly).
+    # Capture only is inside the try: the ranks FIRST agree whether every one of them captured, and only then does
+    # anybody replay (a replay holds `chunk` collectives: a rank that failed to capture must not meet it with an
+    # all-reduce).  MSX_BENCH_GRAPH=0 gives the eager loop; MSX_BENCH_FAIL_CAPTURE_RANK=r makes rank r fail on
+    # purpose; the ordering itself is mcmc_spec_amd.benchutil.capture_agreed (tests/test_dist_gloo.py).
     graph, chunk = None, 0
-    # also at N = 1: back-to-back launches of one stream leave ~1 us between kernels that the graph does not
-    # (20.3 -> 19.3 us per step, same box); MSX_BENCH_GRAPH=0 gives the eager loop
     want_graph = os.environ.get('MSX_BENCH_GRAPH', '1') == '1'
-    if want_graph and not direct and args.steps >= 8:
-        chunk = min(int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '40')), args.steps) // (2 * nbatch) * (2 * nbatch)
-        try:
+    period = 2 * nbatch * nprob // np.gcd(2 * nbatch, nprob)  # a chunk holds whole periods of (problem, batch, buffer)
+    if want_graph and not direct and args.steps >= period:
+        chunk = max(period, min(int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '40')), args.steps) // period * period)
+        from mcmc_spec_amd.benchutil import capture_agreed
+
+        def do_capture():
+            if os.environ.get('MSX_BENCH_FAIL_CAPTURE_RANK') == str(rank):
+                raise RuntimeError('capture failure requested for this rank')
             torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
+            g_ = torch.cuda.CUDAGraph()
             # thread_local: calls made by other threads (c10d's watchdog) must not invalidate the capture
-            with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev), capture_error_mode='thread_local'):
+            with torch.cuda.graph(g_, stream=torch.cuda.Stream(dev), capture_error_mode='thread_local'):
                 tab = calls_for(torch.cuda.current_stream(dev).cuda_stream)
                 for i in range(chunk):
                     reuse_guard(i)
@@ -307,17 +403,22 @@ def main():
                     if use_gather:
                         gather(i)
                 drain()
-            graph.replay()  # one untimed replay
+            return g_
+
+        def do_replay(g_):
+            g_.replay()
             torch.cuda.synchronize(dev)
-        except Exception as exc:  # noqa: BLE001
-            print('[bench] hipGraph capture of the step loop failed ({}); eager loop'.format(exc), file=sys.stderr, flush=True)
-            graph = None
-            works[0] = works[1] = None
-        if use_gather:
-            ok_t = torch.tensor([1 if graph is not None else 0], device=dev)
+
+        def all_min(flag):
+            if not (world > 1 or force_gather):
+                return flag
+            ok_t = torch.tensor([flag], device=dev)
             dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-            if int(ok_t.item()) == 0:
-                graph = None
+            return int(ok_t.item())
+
+        graph = capture_agreed(do_capture, do_replay, all_min, rank)
+        if graph is None:
+            works[0] = works[1] = None
     # HIP events on the launch stream bracket runs of `ev_run` consecutive launches inside the timed region
     # (an event pair around every single launch would put two extra packets between back-to-back kernels
     # and inflate what it measures); kernel_ms = elapsed / ev_run, i.e. duration + the stream's launch gap
@@ -388,52 +489,112 @@ def main():
     bad = int((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item())
 
     if rank == 0:
-        nwin = W['nwin']
-        b_alg = 2 * 4 * nwin * 8 + ndim * 8 + 8  # SURVEY.md §8(d), float64 grid
-        peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md); measured stream copy reported beside it
-        achieved = n * b_alg / (kern_ms * 1e-3) / 1e9
-        copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
+        kern_s = kern_ms * 1e-3
+        req = eng.ctx.bytes_per_eval()  # bytes one walker's workgroup requests from the memory system (L2-served)
+        kernel_name = ('logprob_kernel<NS=2,U=2,512 threads,PF>' if not block else
+                       ('logprob_kernel<NS=2,U=1,512 threads> (two workgroups per CU)' if block == _lib.BLOCK_512_SHARED
+                        else 'logprob_kernel<NS=2>, %d threads' % block))
+        if args.npix >= 8192:
+            kernel_name = 'logprob_kernel<NS=2,U=1,1024 threads>'
+        elif n > 4 * 256 and not block:
+            kernel_name = 'logprob_kernel<NS=2,U=2,256 threads>'
+        elif n > 256 and not block:
+            kernel_name = 'logprob_kernel<NS=2,U=1,512 threads> (two workgroups per CU)'
+        # ---- the roofline that bounds THIS design --------------------------------------------------------------
+        # The kernel never streams the windowed grid from HBM: staging compacts the two samples that bracket each
+        # data pixel into a pixel-major pair table (6.8 MB at config 2) that lives in L2 / Infinity Cache, and a
+        # walker's workgroup pulls its rows through its CU's L2 port.  So the honest bound at this batch size is
+        # L2 -> CU bandwidth (and, from a few workgroups per CU on, FP64 VALU issue: `valu` below).  The contract's
+        # HBM figure is kept, labelled, in `hbm_contract`; it is NOT a bound on this design and may exceed 1.
+        achieved = n * req / kern_s / 1e9
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r1_logprob_traffic.json')
-        if os.path.exists(tpath):  # PMC counters need rocprofv3 around the process: taken from the committed pass
-            tj = json.load(open(tpath))
-            if tj.get('config') == {'walkers': n, 'npix': args.npix, 'phot': bool(args.phot)}:
-                traffic = tj.get('hbm_bytes_per_launch')
-                traffic_src = 'profiles/r1_logprob_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)'
+        tj = load_profile('r2_logprob_traffic.json') or load_profile('r1_logprob_traffic.json')
+        if tj and tj.get('config') == {'walkers': n, 'npix': args.npix, 'phot': bool(args.phot)}:
+            traffic = tj.get('hbm_bytes_per_launch')
+            traffic_src = 'profiles/ (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)'
+        roofline = {
+            'bound': 'l2->cu', 'achieved': achieved, 'peak': L2_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / L2_PEAK_GBPS,
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'kernel': kernel_name, 'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples,
+            'requested_bytes_per_eval': req, 'requested_bytes_per_launch': n * req,
+            'per_cu_GBps': req / kern_s / 1e9 if n <= 256 else None,
+            'per_cu_peak_GBps_guide': [66, 73],
+            'note': 'achieved = bytes the launch requests through the CUs\' L2 ports / kernel time; peak = L2 aggregate '
+                    '(MI355X_MICROARCH.md); one workgroup per CU at <= 256 walkers, so per_cu_GBps is that CU\'s rate '
+                    'averaged over the whole kernel (the blend phase alone runs at the guide\'s 66-73 GB/s per CU)',
+        }
+        if not replicas:
+            nwin = W['nwin']
+            b_alg = 2 * 4 * nwin * 8 + ndim * 8 + 8  # SURVEY.md §8(d), float64 grid
+            alg = n * b_alg / kern_s / 1e9
+            roofline['hbm_contract'] = {
+                'algorithmic_bytes_per_eval': b_alg, 'algorithmic_bytes_per_launch': n * b_alg, 'achieved_GBps': alg,
+                'peak_GBps': HBM_PEAK_GBPS, 'ratio_to_hbm_peak': alg / HBM_PEAK_GBPS,
+                'hbm_traffic_frac_of_peak': (traffic / kern_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                'note': 'SURVEY §8(d) contract figure: B_alg = nspec*4*Nwin*8 + ndim*8 + 8 of the windowed float64 grid. '
+                        'The kernel does not move these bytes (pair table, L2-resident), so this ratio is not a '
+                        'fraction of a bound and exceeds 1; measured HBM traffic is the figure beside it'}
+        copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
+        roofline['measured_stream_copy_GBps'] = copy_gbps
+        vj = load_profile('r2_valu.json')
+        if vj:
+            roofline['valu'] = vj
+        workload = ('BASELINE config 5: KOI targets ({} px each after the (0.55, 0.90) um crop), one independent problem per '
+                    'GPU, {} walkers per launch, logposterior with 2 contrast terms; {}'.format(
+                        args.npix, n, 'ONE GPU rehearsal: 8 staged problems resident, launched round-robin' if world == 1
+                        else 'replicas, no collective')) if replicas else (
+            'binary (T1=3850/T2=3025) {}-pixel spectrum{}, {} walkers per GPU per launch, logposterior (prior gate + '
+            'likelihood){}'.format(args.npix, ' + 6-band photometry' if args.phot else ' + 2 contrast terms', n,
+                                   (', RCCL all-gather of log-probs' + ('' if args.no_overlap else
+                                                                      ' overlapped with the next launch'))
+                                   if world > 1 else ''))
         out = {
             'metric': 'walker log-likelihood evals/sec (whole node)',
             'value': n * world * args.steps / dt, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'binary (T1=3850/T2=3025) {}-pixel spectrum{}, {} walkers per GPU per launch, '
-                                   'logposterior (prior gate + likelihood){}'.format(
-                                       args.npix, ' + 6-band photometry' if args.phot else ' + 2 contrast terms', n,
-                                       (', RCCL all-gather of log-probs' + ('' if args.no_overlap else
-                                                                          ' overlapped with the next launch'))
-                                       if world > 1 else ''),
-                       'walkers_total': n * world, 'npix': args.npix, 'nwin': nwin, 'grid': '26x4x135000 f64 synthetic',
+            'config': {'workload': workload, 'baseline_config': args.config if args.config != 2 or world == 1 else 3,
+                       'walkers_total': n * world, 'npix': args.npix, 'nwin': W.get('nwin'),
+                       'grid': '26x4x135000 f64 synthetic',
                        'block_threads': block or 'auto', 'collective': collective,
                        'step_loop': ('hipGraph of {} steps x {} replays + {} eager'.format(
                            chunk, args.steps // chunk, args.steps - args.steps // chunk * chunk)
                            if graph is not None else 'eager')},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': peak, 'unit': 'GB/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'logprob_kernel<NS=2,U=2,512 threads,PF>' if not block else ('logprob_kernel<NS=2,U=1,512 threads> (two workgroups per CU)' if block == _lib.BLOCK_512_SHARED else 'logprob_kernel<NS=2>, %d threads' % block),
-                         'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples, 'algorithmic_bytes_per_launch': n * b_alg,
-                         'algorithmic_bytes_per_eval': b_alg, 'requested_bytes_per_eval': eng.ctx.bytes_per_eval(),
-                         'measured_stream_copy_GBps': copy_gbps, 'frac_of_measured_copy': achieved / copy_gbps,
-                         # what actually bounds the kernel: bytes a workgroup pulls through its
-                         # CU's L2 port, averaged over the kernel (the guide's per-CU L2 rate is 66-73 GB/s)
-                         'requested_GBps_per_workgroup': eng.ctx.bytes_per_eval() / (kern_ms * 1e-3) / 1e9,
-                         'note': NWIN_DOC},
+            'roofline': roofline,
             'walker_error_statuses': bad, 'gather_verified': gather_ok,
         }
+        out['cpu_baseline'] = None
+        extra = {}
         if want_cpu:
             th_cpu = synth.draw_walkers(8192, seed=77, tmin=W['tmin'], tmax=W['tmax'])
             g, st = eng.ctx.logprob_batch(th_cpu, _lib.MODE_LOGPOST)
-            out['cpu_baseline'] = cpu_baseline(W, th_cpu, g, args.cpu_budget, args.cpu_procs)
-        else:
-            out['cpu_baseline'] = None
+            procs = (0,) if args.no_extras else (0, 15)   # 15 = the reference's hard-coded pool width (mft6.py:1744)
+            recs = cpu_baseline(W, th_cpu, g, args.cpu_budget, procs)
+            out['cpu_baseline'] = recs[0]
+            if len(recs) > 1:
+                extra['cpu_baseline_pool15'] = recs[1]
+        if world == 1 and not replicas and not args.no_extras:
+            # batch-size sweep on the staged problem (device time per launch, automatic variant choice)
+            sweep = []
+            for m in (128, 256, 512, 1024, 2048, 4096, 16384):
+                th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+                lp_, st_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
+                us = device_time_us(eng, th, lp_, st_, stream, m, max(5, min(50, 200000 // m)))
+                sweep.append({'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6,
+                              'requested_GBps': m * req / us / 1e3, 'frac_of_l2_peak': m * req / us / 1e3 / L2_PEAK_GBPS})
+            extra['sweep'] = {'npix': args.npix, 'rows': sweep}
+            if args.npix == 4096 and not args.phot:
+                # BASELINE config 4's per-GPU share: 16,384 px + 6-band photometry, 1,024 walkers / 8 GPUs
+                e4 = Engine(local)
+                W4 = build_workload(e4, 16384, True, grid=W.get('flux'))
+                th = torch.from_numpy(synth.draw_walkers(128, seed=3, tmin=W4['tmin'], tmax=W4['tmax'])).to(dev)
+                lp_, st_ = torch.empty(128, dtype=torch.float64, device=dev), torch.empty(128, dtype=torch.int32, device=dev)
+                us = device_time_us(e4, th, lp_, st_, stream, 128, 50)
+                extra['config4_per_gpu_share'] = {'walkers': 128, 'npix': 16384, 'photometry_bands': 6, 'device_us': us,
+                                                  'evals_per_s': 128 / us * 1e6,
+                                                  'requested_bytes_per_eval': e4.ctx.bytes_per_eval()}
+        if extra:
+            out['extra'] = extra
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     if world > 1 or force_gather:

@@ -76,3 +76,83 @@ def test_world2_gather_equals_single_rank_for_ragged_sizes():
     # each rank evaluated only its own (padded) block: ceil(n/2) walkers per call
     for rank, out, calls in res:
         assert calls == [-(-n // 2) for n in sizes]
+
+
+def _worker_errors(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, common.ROOT)
+    import torch
+    import torch.distributed as dist
+    from mcmc_spec_amd.benchutil import capture_agreed
+    from mcmc_spec_amd.dist import ShardedLogProb
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    log = []
+
+    # (1) a data-dependent exception on ONE rank (a bad walker in its shard) must surface on EVERY rank, after the
+    # collectives, instead of leaving the other rank blocked in all_gather
+    def local_eval(block):
+        if np.any(block[:, 0] < 0):
+            raise KeyError('a model grid node needed by walker ... is not in specs')
+        return block.sum(axis=1)
+
+    f = ShardedLogProb(local_eval, device='cpu')
+    coords = np.arange(24, dtype=float).reshape(8, 3)
+    log.append(('ok', f(coords).tolist()))
+    bad = coords.copy()
+    bad[6, 0] = -1.0                       # lives in rank 1's shard only
+    try:
+        f(bad)
+        log.append(('no exception',))
+    except KeyError as e:
+        log.append(('KeyError', 'rank 1' in str(e) or rank == 1))
+    log.append(('after', f(coords).tolist()))      # the group is still usable: nobody is stuck in a collective
+
+    # (2) bench.py's graph capture: rank 1 fails to capture; nobody may replay (a replay holds collectives)
+    replays = []
+
+    def all_min(flag):
+        t = torch.tensor([flag])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def capture():
+        if rank == 1:
+            raise RuntimeError('capture failure on this rank')
+        return 'graph'
+
+    def replay(g):
+        replays.append(g)
+        t = torch.ones(1)
+        dist.all_reduce(t)                 # what a real replay contains
+
+    log.append(('capture', capture_agreed(capture, replay, all_min, rank), len(replays)))
+    # ... and when every rank captures, every rank replays once
+    log.append(('capture2', capture_agreed(lambda: 'graph', replay, all_min, rank), len(replays)))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, log))
+
+
+@pytest.mark.timeout(120)
+def test_world2_one_rank_failing_does_not_deadlock_the_other():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_errors, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = np.arange(24, dtype=float).reshape(8, 3).sum(axis=1).tolist()
+    for rank in (0, 1):
+        log = res[rank]
+        assert log[0] == ('ok', want)
+        assert log[1] == ('KeyError', True)            # same exception class on both ranks
+        assert log[2] == ('after', want)
+        assert log[3] == ('capture', None, 0)          # nobody replayed
+        assert log[4] == ('capture2', 'graph', 1)
