@@ -384,7 +384,7 @@ def main():
     # purpose; the ordering itself is mcmc_spec_amd.benchutil.capture_agreed (tests/test_dist_gloo.py).
     graph, chunk = None, 0
     want_graph = os.environ.get('MSX_BENCH_GRAPH', '1') == '1'
-    period = 2 * nbatch * nprob // np.gcd(2 * nbatch, nprob)  # a chunk holds whole periods of (problem, batch, buffer)
+    period = int(2 * nbatch * nprob // np.gcd(2 * nbatch, nprob))  # a chunk holds whole periods of (problem, batch, buffer)
     if want_graph and not direct and args.steps >= period:
         chunk = max(period, min(int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '40')), args.steps) // period * period)
         from mcmc_spec_amd.benchutil import capture_agreed
@@ -596,7 +596,7 @@ def main():
         if extra:
             out['extra'] = extra
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + '\n').encode())
+        os.write(result_fd, (json.dumps(out, default=lambda o: o.item() if hasattr(o, 'item') else str(o)) + '\n').encode())
     if world > 1 or force_gather:
         dist.destroy_process_group()
 
