@@ -192,6 +192,15 @@ int msx_sampler_run(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int64_
  * state (coords/logp may be NULL) and frees everything; restaging the problem or destroying the ctx ends a run too. */
 int msx_sampler_begin(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int64_t max_chunk_steps, const double *coords,
                       const double *logp, const int64_t *naccept /* NULL = zeros */);
+/* Sharded form of the same run: call once between msx_sampler_begin and the first enqueue, on every
+ * rank, after msx_comm_init(rank, world).  Every rank holds the whole ensemble in HBM and must be fed the same
+ * randomness; per half-step rank r evaluates block r of the nw/2 proposals (ceil((nw/2)/world) walkers), ONE RCCL
+ * all-gather of that many float64 log-probabilities per rank crosses xGMI on the compute stream, and a small kernel
+ * applies the accept rule for all walkers on every rank -- so every rank's chain is bit-identical to the one-GPU
+ * chain and nothing returns to the host between half-steps.  world = 1 is allowed (no collective): the same three
+ * device steps on one GPU.  A walker error (MSX_W_*) on any rank reaches every rank's worst_status: it travels as
+ * the payload of the NaN log-probability it produces.                                                            */
+int msx_sampler_shard(msx_ctx *ctx, int32_t rank, int32_t world);
 int msx_sampler_enqueue(msx_ctx *ctx, int32_t slot /* 0|1 */, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
                         const int32_t *partner, const double *zz, const double *zfac, const double *logu);
 int msx_sampler_collect(msx_ctx *ctx, int32_t slot, double *chain_out, double *logp_out, int64_t *naccept,

@@ -98,6 +98,7 @@ def load():
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp, _ip,
                                       C.POINTER(C.c_int32)]),
         'msx_sampler_begin': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, _ip]),
+        'msx_sampler_shard': (C.c_int, [vp, C.c_int32, C.c_int32]),
         'msx_sampler_enqueue': (C.c_int, [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32), _dp, _dp, _dp]),
         'msx_sampler_collect': (C.c_int, [vp, C.c_int32, _dp, _dp, _ip, C.POINTER(C.c_int32)]),
@@ -123,7 +124,7 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
             'msx_logprob_batch_dev', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
-            'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
+            'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval']
 
 
@@ -293,6 +294,10 @@ class Context:
         self.check(self.lib.msx_sampler_begin(self.h, int(mode), nw, ndim, int(max_chunk_steps), dptr(coords), dptr(logp),
                                               None if nacc is None else iptr(nacc)))
         self._smp_shape = (nw, ndim)
+
+    def sampler_shard(self, rank, world):
+        """Shard the run begun by sampler_begin over `world` ranks (msx_sampler_shard); world > 1 needs comm_init."""
+        self.check(self.lib.msx_sampler_shard(self.h, int(rank), int(world)))
 
     def sampler_enqueue(self, slot, sidx, cidx, partner, zz, zfac, logu):
         """Queue one chunk (arrays of shape (nsteps, 2, nw/2)) without waiting for it."""

@@ -77,6 +77,8 @@ struct DevProblem {
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;
+    int32_t smp_defer;  // sharded sampler: the kernel only publishes log p(q); accept + state update run in
+                        // sampler_apply_kernel after the ranks' all-gather (every rank applies every walker)
     double *smp_coords, *smp_logp;          // [nw][ndim], [nw]   ensemble state (updated in place)
     double *smp_q;                          // [ns][ndim]         proposals of this half-step
     const int32_t *smp_sidx, *smp_cidx, *smp_partner;  // [ns]; smp_partner holds cidx[partner]: the ensemble

@@ -5,16 +5,27 @@
 
 namespace {
 
+__device__ __forceinline__ double nan_with_status(int st) {
+    return __longlong_as_double(0x7ff8000000000000ll | (long long)(st & 0xff));
+}
+__device__ __forceinline__ int status_of_nan(double v) {  // 0 for anything that is not one of the NaNs above
+    const long long b = __double_as_longlong(v);
+    return ((b & 0x7ff8000000000000ll) == 0x7ff8000000000000ll && (b >> 63) == 0) ? (int)(b & 0xff) : 0;
+}
+
 // Last lines of a walker (one lane): publish the value and, for the device-resident sampler, apply the
 // stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
 // like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
 // own half-step, so its row after the step is written here.
 __device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
                             double *__restrict__ logp, int32_t *__restrict__ status) {
-    logp[wk] = out;
+    // an error status travels inside the NaN it produces (payload = MSX_W_*): the sharded sampler's all-gather
+    // carries log-probabilities only, and every rank must learn of every rank's failures
+    logp[wk] = (st > MSX_W_REJECT) ? nan_with_status(st) : out;
     status[wk] = st;
     if (!P.smp_on) return;
     if (st > MSX_W_REJECT) atomicMax(P.smp_worst, st);
+    if (P.smp_defer) return;  // sharded: sampler_apply_kernel finishes the move after the all-gather
     const int64_t s = D.smp_s;
     const double lnpdiff = (D.smp_zfac + out) - D.smp_old;
     const bool acc = D.smp_logu < lnpdiff;
@@ -490,6 +501,43 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
         walker_done(P, D, wk, ndim, out, MSX_W_OK, logp, status);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sharded device-resident sampler (SURVEY §8e + f2): every rank keeps the whole ensemble in HBM and evaluates its
+// block of the half-step's proposals with smp_defer = 1; the only thing that crosses xGMI is ONE all-gather of
+// log p(q) (ns / G float64 per rank).  This kernel then finishes the half-step on every rank, for every active
+// walker: the proposal is rebuilt from the resident state (its inputs -- the walker itself and its partner in the
+// complementary half -- are untouched until now, and the expression is the fused kernel's, contraction off), the
+// accept rule is the fused kernel's, so all ranks stay bit-identical to each other and to the one-GPU chain.
+// ------------------------------------------------------------------------------------------------
+__global__ void sampler_apply_kernel(DevProblem P, const double *__restrict__ newlp, int64_t ns, int ndim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const int64_t si = P.smp_sidx[i], ci = P.smp_partner[i];
+    const double zz = P.smp_zz[i];
+    const double out = newlp[i];
+    const int st = status_of_nan(out);
+    if (st > MSX_W_REJECT) atomicMax(P.smp_worst, st);
+    const double old = P.smp_logp[si];
+    const double lnpdiff = (P.smp_zfac[i] + out) - old;
+    const bool acc = P.smp_logu[i] < lnpdiff;  // NaN differences compare false, like the host loop
+    for (int d = 0; d < ndim; ++d) {
+#pragma clang fp contract(off)
+        const double sv = P.smp_coords[si * ndim + d];
+        const double cv = P.smp_coords[ci * ndim + d];
+        const double diff = cv - sv;
+        const double prod = diff * zz;
+        const double qv = cv - prod;
+        const double v = acc ? qv : sv;
+        if (acc) P.smp_coords[si * ndim + d] = v;
+        P.smp_chain_row[si * ndim + d] = v;
+    }
+    if (acc) {
+        P.smp_logp[si] = out;
+        P.smp_naccept[si] = P.smp_naccept[si] + 1;
+    }
+    P.smp_lp_row[si] = acc ? out : old;
 }
 
 }  // namespace

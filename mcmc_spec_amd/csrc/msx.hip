@@ -896,6 +896,11 @@ struct SamplerRun {
     int32_t mode = 0, ndim = 0;
     int64_t nw = 0, ns = 0, cap_steps = 0;
     bool failed = false;  // an enqueue returned an error after queuing part of its launches
+    // sharded run (msx_sampler_shard): this rank evaluates block `rank` of every half-step's ns proposals
+    bool sharded = false;
+    int32_t world = 1, rank = 0;
+    int64_t shard_m = 0;            // ceil(ns / world): walkers per rank, and the all-gather's count
+    double *d_newlp_all = nullptr;  // [shard_m * world] gathered log p(q) of the half-step
     char *d_state = nullptr;
     double *d_coords = nullptr, *d_logp = nullptr, *d_q = nullptr, *d_newlp = nullptr;
     int64_t *d_nacc = nullptr;
@@ -931,11 +936,13 @@ static void sampler_free(msx_ctx *c) {
         if (sl.out_ready) (void)hipEventDestroy(sl.out_ready);
     }
     if (r->d_state) (void)hipFree(r->d_state);
+    if (r->d_newlp_all) (void)hipFree(r->d_newlp_all);
     if (r->copy) (void)hipStreamDestroy(r->copy);
     if (r->up) (void)hipStreamDestroy(r->up);
     delete r;
     c->smp = nullptr;
     c->P.smp_on = 0;
+    c->P.smp_defer = 0;
 }
 
 int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t max_chunk_steps, const double *coords,
@@ -980,6 +987,26 @@ int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_
         sampler_free(c);
         return fail(c, MSX_ERR_HIP, std::string("msx_sampler_begin: ") + hipGetErrorString(e));
     }
+    return MSX_OK;
+}
+
+int msx_sampler_shard(msx_ctx *c, int32_t rank, int32_t world) {
+    if (!c) return MSX_ERR_INVALID;
+    SamplerRun *r = c->smp;
+    if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_shard: call msx_sampler_begin first");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, MSX_ERR_INVALID, "msx_sampler_shard: bad rank / world");
+    if (world > 1 && (!c->rccl_comm || c->comm_world != world || c->comm_rank != rank))
+        return fail(c, MSX_ERR_STATE, "msx_sampler_shard: msx_comm_init(rank, world) must come first");
+    for (auto &sl : r->slot)
+        if (sl.busy) return fail(c, MSX_ERR_STATE, "msx_sampler_shard: chunks are already in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    r->world = world; r->rank = rank;
+    r->shard_m = (r->ns + world - 1) / world;
+    if (r->d_newlp_all) (void)hipFree(r->d_newlp_all);
+    r->d_newlp_all = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&r->d_newlp_all, sizeof(double) * (size_t)(r->shard_m * world)));
+    HIP_TRY(c, hipMemset(r->d_newlp_all, 0, sizeof(double) * (size_t)(r->shard_m * world)));
+    r->sharded = true;
     return MSX_OK;
 }
 
@@ -1029,10 +1056,35 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
             P.smp_sidx = d_sidx + off; P.smp_cidx = d_cidx + off; P.smp_partner = d_partner + off;
             P.smp_zz = d_zz + off; P.smp_zfac = d_zfac + off; P.smp_logu = d_logu + off;
             P.smp_chain_row = d_chain + st * nw * ndim; P.smp_lp_row = d_lpchain + st * nw;
-            rc = msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
+            if (!r->sharded) {
+                rc = msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
+                continue;
+            }
+            // sharded: (1) this rank's block of proposals -> log p(q) only; (2) ONE all-gather of shard_m float64
+            // per rank, in place in the gathered vector; (3) every rank finishes the half-step for all ns walkers
+            const int64_t lo = std::min<int64_t>(r->rank * r->shard_m, ns), hi = std::min<int64_t>(lo + r->shard_m, ns);
+            DevProblem keep = P;
+            if (hi > lo) {
+                P.smp_defer = 1;
+                P.smp_sidx += lo; P.smp_cidx += lo; P.smp_partner += lo; P.smp_zz += lo; P.smp_zfac += lo; P.smp_logu += lo;
+                P.smp_q = r->d_q + lo * ndim;
+                rc = msx_logprob_batch_dev(c, r->mode, r->d_q + lo * ndim, hi - lo, ndim, r->d_newlp_all + lo, r->d_wst + lo,
+                                           c->stream, 0);
+            }
+            P = keep;
+            if (rc != MSX_OK) break;
+            if (c->rccl_comm && c->comm_world == r->world) {  // (a one-rank communicator still runs the collective)
+                const int nrc = rccl().AllGather(r->d_newlp_all + r->rank * r->shard_m, r->d_newlp_all, (size_t)r->shard_m,
+                                                 kNcclFloat64, c->rccl_comm, c->stream);
+                if (nrc != 0) { rc = fail(c, MSX_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(nrc)); break; }
+            }
+            hipLaunchKernelGGL(sampler_apply_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, P,
+                               r->d_newlp_all, ns, ndim);
+            if (hipGetLastError() != hipSuccess) rc = fail(c, MSX_ERR_HIP, "sampler_apply_kernel launch failed");
         }
     }
     P.smp_on = 0;
+    P.smp_defer = 0;
     if (rc != MSX_OK) {
         // some of this chunk's half-steps may already be queued: the resident state is no longer the state any
         // host-side bookkeeping expects.  Refuse everything but msx_sampler_end from here on.

@@ -89,3 +89,20 @@ class ShardedLogProb:
             l, h, _ = shard_bounds(n, self.world, r)
             parts.append(out[r * m: r * m + (h - l)])
         return np.concatenate(parts)
+
+
+def init_engine_comm(engine, group=None):
+    """Give ``engine`` (one per rank, on this rank's GPU) the library's own RCCL communicator over the ranks of
+    ``group``: rank 0 creates the id, torch.distributed broadcasts it, every rank joins (``msx_comm_init``).  Needed
+    by the sharded device-resident sampler, whose per-half-step all-gather is enqueued from C on the compute stream.
+    Returns (rank, world)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device('cuda', engine.device) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(engine.ctx.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, src=0, group=group)
+    engine.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    return rank, world

@@ -207,8 +207,15 @@ class DeviceEnsembleSampler(EnsembleSampler):
     ``engine`` is a staged ``mcmc_spec_amd.engine.Engine``; ``mode`` selects ``'logposterior'`` or
     ``'loglikelihood'`` as the target density."""
 
-    def __init__(self, nwalkers, ndim, engine, mode='logposterior', a=2.0, seed=None, chunk=64):
+    def __init__(self, nwalkers, ndim, engine, mode='logposterior', a=2.0, seed=None, chunk=64, shard=None):
+        """``shard = (rank, world)`` runs the SHARDED form: every rank holds the whole ensemble on
+        its GPU, evaluates block ``rank`` of each half-step's proposals, one RCCL all-gather of the new
+        log-probabilities crosses xGMI and every rank applies the accept rule for all walkers on the device.
+        Every rank must construct the sampler with the SAME seed and start from the same state; every rank then
+        holds the same chain, bit-identical to the unsharded one.  ``world > 1`` needs the engine's RCCL
+        communicator (``mcmc_spec_amd.dist.init_engine_comm``)."""
         from . import _lib
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
         self.engine = engine
         self._mode = {'logposterior': _lib.MODE_LOGPOST, 'loglikelihood': _lib.MODE_LOGLIKE}[mode]
         fn = engine.logposterior if mode == 'logposterior' else engine.loglikelihood
@@ -248,6 +255,8 @@ class DeviceEnsembleSampler(EnsembleSampler):
             return
         base_acc = self._accepted.copy()
         ctx.sampler_begin(self._mode, coords, logp, self.chunk)
+        if self.shard is not None:
+            ctx.sampler_shard(*self.shard)
         try:
             with ThreadPoolExecutor(max_workers=2) as pool:
                 queued = deque()

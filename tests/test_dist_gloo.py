@@ -156,3 +156,55 @@ def test_world2_one_rank_failing_does_not_deadlock_the_other():
         assert log[2] == ('after', want)
         assert log[3] == ('capture', None, 0)          # nobody replayed
         assert log[4] == ('capture2', 'graph', 1)
+
+
+def _worker_chain(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, common.ROOT)
+    import torch.distributed as dist
+    from mcmc_spec_amd.dist import ShardedLogProb
+    from mcmc_spec_amd.sampler import EnsembleSampler
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    def lnp(x):
+        return -0.5 * np.sum((x / np.array([0.5, 1.0, 2.0])) ** 2, axis=1) + 0.1 * np.sin(x[:, 0])
+
+    f = ShardedLogProb(lnp, device='cpu')
+    nw = 18                                # half-steps of 9 walkers: ragged over 2 ranks (5 + 4)
+    p0 = np.random.default_rng(8).normal(size=(nw, 3))
+    s = EnsembleSampler(nw, 3, f, vectorize=True, seed=4)   # replicated sampler, shared seed
+    s.run_mcmc(p0, 25)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, s.get_chain(), s.get_log_prob(), s.acceptance_fraction))
+
+
+@pytest.mark.timeout(120)
+def test_world2_sharded_chain_equals_the_one_rank_chain():
+    """The N > 1 sampler protocol on CPU: every rank runs the same sampler from the same seed, each half-step's
+    proposals are evaluated in rank blocks and all-gathered; both ranks must hold the chain a single rank produces,
+    bit for bit (ragged half-steps included)."""
+    from mcmc_spec_amd.sampler import EnsembleSampler
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_chain, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+
+    def lnp(x):
+        return -0.5 * np.sum((x / np.array([0.5, 1.0, 2.0])) ** 2, axis=1) + 0.1 * np.sin(x[:, 0])
+
+    p0 = np.random.default_rng(8).normal(size=(18, 3))
+    one = EnsembleSampler(18, 3, lnp, vectorize=True, seed=4)
+    one.run_mcmc(p0, 25)
+    for rank, chain, lp, acc in res:
+        assert np.array_equal(chain, one.get_chain()) and np.array_equal(lp, one.get_log_prob())
+        assert np.array_equal(acc, one.acceptance_fraction)

@@ -650,6 +650,39 @@ def test_device_resident_sampler_statistics():
         assert np.all(sd / sd0 < 2.0) and np.all(sd0 / sd < 2.0)
 
 
+def test_sharded_device_sampler_on_one_rank_walks_the_fused_chain():
+    """The sharded form's three device steps per half-step (block evaluation with the accept deferred, the
+    all-gather -- a no-op at world size 1 --, the apply kernel) against the fully fused single-launch form: same
+    chain, log-probabilities and acceptance counts, bit for bit, including rejected proposals; and a walker error
+    surfaces through the NaN payload."""
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    c = golden_case('B')
+    eng = make_engine(c, rad_prior=False)
+    rng = np.random.default_rng(6)
+    nw = 48
+    p0 = c.theta[0] + rng.normal(size=(nw, 6)) * np.array([30, 30, 0.02, 0.02, 0.02, 2e-5])
+    fused = DeviceEnsembleSampler(nw, 6, eng, seed=13, chunk=16)
+    fs = fused.run_mcmc(p0, 40)
+    shard = DeviceEnsembleSampler(nw, 6, eng, seed=13, chunk=16, shard=(0, 1))
+    ss = shard.run_mcmc(p0, 40)
+    assert np.array_equal(shard.chain, fused.chain)
+    assert np.array_equal(shard.get_log_prob(), fused.get_log_prob())
+    assert np.array_equal(shard.acceptance_fraction, fused.acceptance_fraction)
+    assert np.array_equal(ss.coords, fs.coords) and 0.05 < shard.acceptance_fraction.mean() < 0.95
+    # the same with the library's RCCL communicator in place (one rank): the all-gather is really enqueued, from C,
+    # on the compute stream between the block evaluation and the apply kernel
+    eng.ctx.comm_init(eng.ctx.comm_unique_id(), 0, 1)
+    coll = DeviceEnsembleSampler(nw, 6, eng, seed=13, chunk=16, shard=(0, 1))
+    coll.run_mcmc(p0, 40)
+    assert np.array_equal(coll.chain, fused.chain) and np.array_equal(coll.get_log_prob(), fused.get_log_prob())
+    # likelihood mode has no prior box: a proposal outside the isochrone table is an error status, not a value
+    like = DeviceEnsembleSampler(nw, 6, eng, mode='loglikelihood', seed=2, chunk=8, shard=(0, 1))
+    wide = p0.copy()
+    wide[:, 1] = 2905.0 + np.abs(rng.normal(size=nw)) * 3      # stretch moves will step below the table's 2900 K
+    with pytest.raises(ValueError):
+        like.run_mcmc(wide, 60)
+
+
 def test_pipelined_sampler_entry_points_guard_their_arguments():
     """msx_sampler_begin/_enqueue/_collect/_end: indices that would be dereferenced on the device are range-checked
     on the host, slots cannot be overwritten or collected twice, and a run continued from a State is the same
