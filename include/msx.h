@@ -92,9 +92,6 @@ typedef struct msx_problem {
     int32_t has_prior_list; /* `prior != 0`                                         mft6.py:1241    */
     int32_t no_spectrum;    /* 1 = the mft6_nospec.py variant: total = contrast + photometry chi^2 only
                              * (mft6_nospec.py:1163-1196); the spectral phases are skipped            */
-    int32_t compact_pairs;  /* 1 = also stage the 12-byte pair table {f64 flux[lo], f32 flux[lo+1]-flux[lo]} and use
-                             * it in the binary hot kernel: -25 % pair bytes, ~1e-9 relative perturbation of the
-                             * upper sample (NOT bit-faithful to float64; off by default)                      */
 } msx_problem;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -134,11 +131,12 @@ int msx_stage_problem(msx_ctx *ctx, const msx_problem *p);
 /* theta is [n][ndim] row-major (ndim = 2*nspec+2); logp_out [n]; status_out [n] (MSX_W_*).        */
 int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n, int32_t ndim,
                       double *logp_out, int32_t *status_out);
-/* same with device pointers on a caller stream; does not synchronise.  block_threads: 0 = auto (1024 for >= 8192
- * pixels; else 512 up to 4 x #CUs walkers, 256 beyond), or one of 256 / 512 / 1024, or MSX_BLOCK_512_SHARED = 512
- * threads in the <= 128-VGPR variant that can share its CU with a second workgroup (what a launch wants when
- * another kernel, e.g. a collective, holds CUs at the same time).  The choice affects speed only: every variant
- * produces the same bits.                                                                                    */
+/* same with device pointers on a caller stream; does not synchronise (no launch allocates: every scratch buffer is
+ * sized by msx_stage_problem).  block_threads: 0 = auto (512 threads, one workgroup per CU with the pixel statics
+ * staged in LDS, up to #CUs walkers and for spectra of >= 8192 pixels; 512 threads two per CU up to 4 x #CUs; 256
+ * threads three per CU beyond), or 256 / 512, or MSX_BLOCK_512_SHARED = 512 threads in the <= 128-VGPR variant that
+ * shares its CU with a second workgroup (what a launch wants when another kernel, e.g. a collective, holds CUs at
+ * the same time).  The choice affects speed only: every variant produces the same bits.                        */
 #define MSX_BLOCK_512_SHARED 1512
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
@@ -150,7 +148,7 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
  * above MSX_SPLIT_MIN walkers / MSX_SPLIT_MIN_NPIX pixels (environment variables read by msx_stage_problem; unset =
  * never: on MI355X the fused kernel measured faster at every size).  All scratch is sized by
  * msx_stage_problem: no launch allocates or synchronises.  MSX_PATH_SPLIT fails with MSX_ERR_STATE for modes / problems that have no split form
- * (logprior alone, the no-spectrum variant, compact pairs, the optimiser modes, tables beyond the register recipe). */
+ * (logprior alone, the no-spectrum variant, the optimiser modes, tables beyond the register recipe).                 */
 #define MSX_PATH_AUTO 0
 #define MSX_PATH_FUSED 1
 #define MSX_PATH_SPLIT 2

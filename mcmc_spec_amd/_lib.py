@@ -41,7 +41,7 @@ class MsxProblem(C.Structure):
         ('tmin', C.c_double), ('tmax', C.c_double),
         ('prior_mean', C.c_double * MAX_DIM), ('prior_sig', C.c_double * MAX_DIM),
         ('use_av', C.c_int32), ('dist_fit', C.c_int32), ('rad_prior', C.c_int32), ('has_prior_list', C.c_int32),
-        ('no_spectrum', C.c_int32), ('compact_pairs', C.c_int32),
+        ('no_spectrum', C.c_int32),
     ]
 
 

@@ -25,30 +25,47 @@ __device__ __forceinline__ void sort4_by_node(int (&node)[4], double (&w)[4]) {
 #undef MSX_CSWAP
 }
 
-// One data pixel of one walker.  v[c] = {flux[lo], flux[lo+1]} of corner c's grid node at this pixel (compact
-// pairs: .y holds the float32 DIFFERENCE), w[c] = bilinear weight x (R/d)^2, kk = CCM89 k at the two samples,
-// t = resample weight, redc = -0.4 log2(10) A_V (0: no reddening).
-template <int NC, bool CP>
-__device__ __forceinline__ double blend_pixel(const double2 (&v)[NC], const double (&w)[NC], const double2 kk, const double t,
-                                              const double redc, const bool redden) {
-    double ylo = 0.0, yhi = 0.0;
+// One data pixel of one walker.  The reference blends the two model samples that bracket the pixel (lo, hi),
+// reddens each and interpolates (mft6.py:508-511, 1161-1170): with y = sum_c w_c * sample_c,
+//     m = e_lo y_lo + (e_hi y_hi - e_lo y_lo) t,        e = 10^(-0.4 A_V k) at the two samples.
+// Reddening acts on the model grid BEFORE the resample, so the two samples get different factors and the resample
+// cannot simply be folded into a table.  But e_hi / e_lo = 1 + eps with eps ~ 4e-5 A_V, and
+//     m = e_lo y_lo + (e_hi y_hi - e_lo y_lo) t = e_lo [ (y_lo + (y_hi - y_lo) t)  +  eps (y_hi t) ]
+// exactly.  Staging therefore stores, per grid node and pixel, R = lo + (hi - lo) t in float64 (8 B) and
+// H = hi t in float32 (4 B): H (and dk) only ever enter multiplied by eps, so their 2^-24 rounding perturbs m by
+// < 2.4e-12 A_V relative (measured on config 2, half the walkers at A_V ~ 1: log-posteriors within 5e-15 of the
+// 16-byte {lo, hi} form) -- 12 bytes per node-pixel instead of 16, eight float64 FMAs instead of sixteen.
+// r[c], h[c]: corner c's R and H; wf = w rounded to float32; kl = k[lo], dk = k[lo+1] - k[lo].
+// With no reddening (A_V <= 0, mft6.py:1161) m = sum_c w_c R_c: the unreddened interpolation itself.
+// (the sums may be taken in pieces -- corners C0 .. C0 + N - 1 at a time, always in ascending corner order -- so
+// that a register-starved variant can load one star's rows, fold them in and load the next: same chain, same bits)
+template <int N>
+__device__ __forceinline__ void blend_accumulate(const double *r, const float *h, const double *w, const float *wf,
+                                                 const bool redden, double &sr, float &sh) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        ylo = fma(w[c], v[c].x, ylo);
-        yhi = fma(w[c], v[c].y, yhi);
-    }
-    if (CP) yhi += ylo;  // blended difference -> blended upper sample
+    for (int c = 0; c < N; ++c) sr = fma(w[c], r[c], sr);
     if (redden) {
-        const double elo = exp2(redc * kk.x);  // 10^(-0.4 A_V k)     mft6.py:62-63
-        // neighbouring grid samples: y = ln2 * c * (k_hi - k_lo) is tiny, so e^y from four series
-        // terms is exact to < 1e-17 for |y| < 1e-3; anything larger takes the full exp2
-        const double y = 0.6931471805599453 * (redc * (kk.y - kk.x));
-        const double ehi = (fabs(y) < 1e-3) ? elo * fma(y, fma(y, fma(y, fma(y, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0)
-                                            : exp2(redc * kk.y);
-        ylo *= elo;
-        yhi *= ehi;
+#pragma unroll
+        for (int c = 0; c < N; ++c) sh = fmaf(wf[c], h[c], sh);
     }
-    return fma(yhi - ylo, t, ylo);  // mft6.py:1169-1170
+}
+__device__ __forceinline__ double blend_finish(const double sr, const float sh, const double kl, const double dk,
+                                               const double redc, const bool redden) {
+    if (!redden) return sr;
+    const double elo = exp2(redc * kl);  // 10^(-0.4 A_V k)     mft6.py:62-63
+    const double y = 0.6931471805599453 * (redc * dk);
+    // eps = e^y - 1: four series terms (exact to < 1e-17 for |y| < 1e-3), else the full exp2
+    const double eps = (fabs(y) < 1e-3) ? y * fma(y, fma(y, fma(y, 1.0 / 24, 1.0 / 6), 0.5), 1.0) : exp2(redc * dk) - 1.0;
+    return elo * fma(eps, (double)sh, sr);
+}
+template <int NC>
+__device__ __forceinline__ double blend_pixel_rh(const double (&r)[NC], const float (&h)[NC], const double (&w)[NC],
+                                                 const float (&wf)[NC], const double kl, const double dk, const double redc,
+                                                 const bool redden) {
+    double sr = 0.0;
+    float sh = 0.0f;
+    blend_accumulate<NC>(r, h, w, wf, redden, sr, sh);
+    return blend_finish(sr, sh, kl, dk, redc, redden);
 }
 
 }  // namespace

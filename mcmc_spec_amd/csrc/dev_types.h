@@ -23,16 +23,6 @@ constexpr double kLog2Of10 = 3.3219280948873623478703194294893901758648313930245
 // ScratchSize 0 for logprob_kernel; tests/test_abi.py checks it.  (Reading the struct through a pointer to a
 // device copy instead was tried: no scratch hazard, but 61 instead of 16 spilled SGPRs and +10 % kernel time
 // for 256-thread workgroups, so by-value + forced inlining stays.)
-// Optional compact pair storage (msx_problem.compact_pairs): {flux[lo] as float64, flux[lo+1]-flux[lo] as
-// float32}, 12 bytes instead of 16.  The difference of neighbouring 0.2 A samples is ~1e-2..1e-3 of the flux,
-// so rounding it to float32 perturbs the upper sample by ~1e-9..1e-10 relative -- NOT bit-faithful to the
-// float64 reference arithmetic; off by default, measured in DESIGN.md.
-struct __attribute__((packed, aligned(4))) PairC {
-    double lo;
-    float d;
-};
-static_assert(sizeof(PairC) == 12, "PairC must be 12 bytes");
-
 struct DevProblem {
     // grid (A0)
     const double *grid;   // [nt*ng][nwl]
@@ -43,9 +33,14 @@ struct DevProblem {
     const double *logg_nodes;
     const uint8_t *present;
     // pixel tables (A8)
-    const double2 *pairs;  // [nt*ng][npix] {flux[lo], flux[lo+1]}
-    const PairC *pairs_c;  // [nt*ng][npix] compact form, or nullptr
-    const double2 *pix_k;  // [npix] {k[lo], k[lo+1]}
+    // Tables of the blend (A2, A4, A7, A8.1), in ELEMENTS of two pixels {pa, pa + 256}, pa = (e >> 8) * 512 +
+    // (e & 255), e < npair (= the pixel count padded to a multiple of 512, halved; pad pixels repeat the last one):
+    const double2 *r2;     // [nt*ng][npair]  R = flux[lo] + (flux[lo+1] - flux[lo]) t   (blend_pixel_rh, blend.h)
+    const float2 *h2;      // [nt*ng][npair]  H = flux[lo+1] t
+    const double2 *kl2;    // [npair]         CCM89 k[lo]
+    const float2 *dk2;     // [npair]         k[lo+1] - k[lo]
+    const double2 *f2, *u2;  // [npair]       data flux, mapped wavelength u (phase A's copies of pix_flux, pix_u)
+    int64_t npair;
     const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
     int64_t npix;
     double median_flux;

@@ -56,21 +56,30 @@ __device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDes
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 
-// MAXT = largest workgroup the variant is launched with.  The 512-thread variants may use up to 256
-// VGPRs (the two-pixels-per-trip body wants ~146: no spills, 3 waves per SIMD); the 1024-thread variants
-// are capped at 128 VGPRs by the hardware and use one pixel per trip.
+// MAXT = the workgroup size the variant is compiled for and launched with: 256 (three workgroups per CU, capped at
+//        168 VGPRs) or 512 (one per CU; with SH: two per CU, capped at 128 VGPRs).  U is the pixels per lane and trip:
+//        always 2, the two pixels of one table element (below).
 // GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
-// PF = while the recipe waves work, the idle waves copy three walker-independent pixel vectors (u, data flux,
-//      resample weight t) into LDS; phase A and the chi^2 pass then read them from LDS, which takes 160 of the
-//      786 KB a walker pulls through its CU's L2 port off the critical path (one workgroup per CU only: 4 npix
-//      doubles of LDS).
+// SH = 512-thread variant that shares its CU with a second workgroup (MSX_BLOCK_512_SHARED).
+// PF = while the recipe waves work, the idle waves copy the walker-independent pixel vectors (u, data flux) into
+//      LDS; phase A and the chi^2 pass then read them from LDS, which takes them off the CU's L2 port -- the
+//      resource phase A is bound by (one workgroup per CU only: 3 npix doubles of LDS).
 // STAGE = 0: the fused kernel.  The split path (split_kernels.h) runs the same code in two pieces:
 //   STAGE = 1  phase 0 only: the walker's recipe goes to P.rec[wk] (rejected / failed walkers get their final
 //              value here, like the fused kernel); launched with 256 threads, no dynamic LDS
 //   STAGE = 2  everything after the blend: the model vector comes from P.model_scratch (written by
 //              blend_tiles_kernel), the recipe's scalars from P.rec[wk]
-template <int NS, int U, int MAXT, bool GM = false, bool CP = false, bool PF = false, int STAGE = 0>
-__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && U == 1) ? 2 : 1)
+//
+// TABLE LAYOUT.  A CU pulls data from L2 at ~32 B per clock when every lane loads 16 bytes, and no faster per
+// instruction when lanes load less -- so every per-pixel table the blend reads is stored in ELEMENTS of two pixels,
+// element e = pixels {pa, pa + 256}, pa = (e >> 8) * 512 + (e & 255): a lane's 16-byte load (8-byte for the float32
+// table) brings both of its pixels, for workgroups of 256 and of 512 threads alike.  Per grid node and pixel the
+// tables hold R = lo + (hi - lo) t (float64) and H = hi t (float32): see blend_pixel_rh (blend.h).
+template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, int STAGE = 0>
+// (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
+// CU <=> k T / 256.  256 threads: three per CU -- two for triples, whose twelve corners do not fit 168 VGPRs;
+// 512 threads sharing a CU: two per CU = four waves per SIMD = 128 VGPRs.)
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? (NS == 2 ? 3 : 2) : (MAXT == 512 && SH) ? 4 : 1)
 logprob_kernel(const double *theta, const double *__restrict__ iso_t, const double *__restrict__ iso_g,
                const double *__restrict__ teff_nodes, const double *__restrict__ logg_nodes,
                const uint8_t *__restrict__ present, int niso_nt, int ng_mode_fast,
@@ -96,9 +105,11 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int nw = B >> 6;
     const int npix = (int)P.npix;
-    double *const lds_u = PF ? reinterpret_cast<double *>(dyn_lds) + npix : nullptr;
-    double *const lds_f = PF ? lds_u + npix : nullptr;
-    double *const lds_t = PF ? lds_f + npix : nullptr;
+    static_assert(U == 2 && (MAXT == 256 || MAXT == 512), "one two-pixel element per lane and trip; 256 or 512 threads");
+    const int ne = (int)P.npair;  // table elements (pixel pairs), a multiple of 256
+    // PF: u and data flux in LDS behind the model vector, in the tables' own pair layout (16-byte aligned)
+    double2 *const lds_u2 = PF ? reinterpret_cast<double2 *>(reinterpret_cast<double *>(dyn_lds) + ((npix + 1) & ~1)) : nullptr;
+    double2 *const lds_f2 = PF ? lds_u2 + ne : nullptr;
 
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
@@ -148,10 +159,9 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     if (STAGE != 2 && PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
         const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
 #pragma unroll 4
-        for (int p = id; p < npix; p += nthr) {
-            lds_u[p] = P.pix_u[p];
-            lds_f[p] = P.pix_flux[p];
-            lds_t[p] = P.pix_t[p];
+        for (int e = id; e < ne; e += nthr) {
+            lds_u2[e] = P.u2[e];
+            lds_f2[e] = P.f2[e];
         }
     }
     if (STAGE != 2) {
@@ -219,82 +229,93 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     MSX_STAMP(P, wk, 1);
 
     // ---- phase A ------------------------------------------------------------------------------------
-    const double2 *rows[NS * 4];
-    const PairC *rows_c[NS * 4];
-    double w[NS * 4];
+    constexpr int NC = NS * 4;
+    const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
+    const float2 *rows_h[NC];   // H = hi t
+    double w[NC];
+    float wf[NC];
 #pragma unroll
-    for (int c = 0; c < NS * 4; ++c) {
-        const int64_t off = STAGE == 2 ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * npix;
-        rows[c] = P.pairs + off;
-        rows_c[c] = CP ? P.pairs_c + off : nullptr;
+    for (int c = 0; c < NC; ++c) {
+        const int64_t off = STAGE == 2 ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
+        rows_r[c] = P.r2 + off;
+        rows_h[c] = P.h2 + off;
         w[c] = STAGE == 2 ? 0.0 : D.w[c];
+        wf[c] = (float)w[c];
     }
     const double redc = STAGE == 2 ? 0.0 : D.redc;
     const bool redden = redc != 0.0;
-    // Sums are taken in an order that does not depend on the workgroup size: pixel p belongs to row p / B of the
-    // launch, i.e. to 64-pixel chunk c = p / 64, and chunk c is owned by VIRTUAL wave c mod 16.  A real wave of a
-    // 4- or 8-wave workgroup plays 4 or 2 virtual waves (its rows alternate between them), each with its own
-    // accumulator; every virtual wave sees its chunks in ascending order, lanes are reduced by the same DPP tree
-    // and the 16 partials are added serially -- the same association for 256, 512 and 1024 threads, so a
-    // walker's log-probability has the same bits whatever launch (batch size, shard, rank) evaluates it.
-    // (every variant is launched with exactly MAXT threads, so the count is a compile-time constant)
-    constexpr int vk = kMaxWaves / (MAXT / kWave);  // virtual waves per real wave: 4, 2 or 1
+    // Sums are taken in an order that does not depend on the workgroup size.  Pixel p belongs to SLOT p mod 1024;
+    // a slot accumulates its pixels in ascending order in ONE lane's register, the 64 slots of VIRTUAL wave v
+    // (slots 64 v .. 64 v + 63, lane = slot mod 64) are reduced by one DPP tree and the 16 partials are added
+    // serially.  Which real lane holds which slot differs with the workgroup size, the association does not:
+    //   256 threads: lane tid walks elements tid + 256 j -> pixels (j & 1) * 512 + tid (+ 256) mod 1024: four slots,
+    //                accumulator k = 2 (j & 1) + u, virtual wave 4 k + wave
+    //   512 threads: elements tid + 512 j -> pixels (tid >> 8) * 512 + (tid & 255) (+ 256) mod 1024: two slots,
+    //                accumulator k = u, virtual wave (wave >> 2) * 8 + 4 u + (wave & 3)
+    // so a walker's log-probability has the same bits whatever launch (batch size, shard, rank) evaluates it.
+    constexpr int vk = kMaxWaves / (MAXT / kWave);  // slots per lane: 4 or 2
+    auto virt_wave = [&](int k) { return MAXT == 256 ? 4 * k + wave : (wave >> 2) * 8 + 4 * k + (wave & 3); };
     double qa[vk][3];
 #pragma unroll
     for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
     double q[3];
     unsigned long long kmin = ~0ull, kmax = 0ull;
-    // rows are taken vk at a time (SUB sub-trips of U rows) so that every row's virtual-wave slot is static
-    constexpr int SUB = (vk > U) ? vk / U : 1;
-    for (int base0 = 0; base0 < npix; base0 += B * U * SUB) {
+    constexpr int SUB = vk / U;  // elements per lane and outer trip: 2 (256 threads) or 1
+    for (int e0 = 0; e0 < ne; e0 += B * SUB) {
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
-        const int base = base0 + sub * B * U;
-        if (base >= npix) break;
-        double2 v[U][NS * 4];
-        double2 kk[U];
-        double tt[U], ff[U], uu[U], mm[U];
-        int pp[U];
+        const int e = e0 + sub * B + tid;
+        const bool live = e < ne;
+        const int ec = live ? e : ne - 1;
+        const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
+        const bool ok[U] = {live && pa < npix, live && pb < npix};
+        const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
+        double2 kl2 = make_double2(0.0, 0.0), f2, u2, m2;
+        float2 dk2 = make_float2(0.f, 0.f);
+        if (STAGE == 2) {
+            m2 = make_double2(model_in[pp[0]], model_in[pp[1]]);  // blend_tiles_kernel's output for this walker
+        } else {
+            // the model values of the two pixels (blend.h; the split path's blend kernel runs the same chain).
+            // All corners' loads are issued together (192 bytes in flight per lane) -- except in the variant that
+            // shares its CU (128 VGPRs), which takes the rows one star at a time.
+            constexpr int G = SH ? 4 : NC;  // corners per group of loads
+            double sra = 0.0, srb = 0.0;
+            float sha = 0.0f, shb = 0.0f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = base + u * B + tid;
-            pp[u] = p < npix ? p : npix - 1;
-            if (STAGE == 2) {
-                mm[u] = model_in[pp[u]];  // blend_tiles_kernel's output for this walker
-            } else {
+            for (int c0 = 0; c0 < NC; c0 += G) {
+                double2 rr[G];
+                float2 hh[G];
 #pragma unroll
-                for (int c = 0; c < NS * 4; ++c) {
-                    if (CP) {
-                        const PairC pc = rows_c[c][pp[u]];
-                        v[u][c] = make_double2(pc.lo, (double)pc.d);  // .y holds the DIFFERENCE in compact mode
-                    } else {
-                        v[u][c] = rows[c][pp[u]];
-                    }
+                for (int c = 0; c < G; ++c) {
+                    rr[c] = rows_r[c0 + c][ec];
+                    hh[c] = redden ? rows_h[c0 + c][ec] : make_float2(0.f, 0.f);
                 }
+                if (c0 == 0 && redden) { kl2 = P.kl2[ec]; dk2 = P.dk2[ec]; }
+                double ra[G], rb[G];
+                float ha[G], hb[G];
+#pragma unroll
+                for (int c = 0; c < G; ++c) { ra[c] = rr[c].x; rb[c] = rr[c].y; ha[c] = hh[c].x; hb[c] = hh[c].y; }
+                blend_accumulate<G>(ra, ha, w + c0, wf + c0, redden, sra, sha);
+                blend_accumulate<G>(rb, hb, w + c0, wf + c0, redden, srb, shb);
             }
+            m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, redden);
+            m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, redden);
         }
+        f2 = (PF && STAGE != 2) ? lds_f2[ec] : P.f2[ec];
+        u2 = (PF && STAGE != 2) ? lds_u2[ec] : P.u2[ec];
+        if (PF && STAGE == 2 && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
+        const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (STAGE != 2) {
-                kk[u] = redden ? P.pix_k[pp[u]] : make_double2(0.0, 0.0);
-                tt[u] = PF ? lds_t[pp[u]] : P.pix_t[pp[u]];
-            }
-            ff[u] = (PF && STAGE != 2) ? lds_f[pp[u]] : P.pix_flux[pp[u]];
-            uu[u] = (PF && STAGE != 2) ? lds_u[pp[u]] : P.pix_u[pp[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // the model value of this pixel (blend.h; the split path's blend kernel calls the same function)
-            const double m = STAGE == 2 ? mm[u] : blend_pixel<NS * 4, CP>(v[u], w, kk[u], tt[u], redc, redden);
-            if (base + u * B + tid < npix) {
+            if (ok[u]) {
+                const double m = mm[u];
                 if (!(GM && STAGE == 2)) model[pp[u]] = m;  // (GM stage 2: the scratch row IS the model vector)
-                if (PF && STAGE == 2) { lds_u[pp[u]] = uu[u]; lds_f[pp[u]] = ff[u]; }  // for the chi^2 pass
                 const double f = ff[u] / m;  // frac before the median scale, mft6.py:194
-                const double f1 = f * uu[u], f2 = f * (uu[u] * uu[u]);
-                const int slot = (sub * U + u) & (vk - 1);  // static: sub and u are unrolled
+                const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
+                const int slot = sub * U + u;  // static: sub and u are unrolled
 #pragma unroll
                 for (int k = 0; k < vk; ++k)
-                    if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2; }
+                    if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2_; }
                 const unsigned long long key = key_of(m);
                 kmin = key < kmin ? key : kmin;
                 kmax = key > kmax ? key : kmax;
@@ -314,7 +335,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const double r = wave_sum(qa[k][i]);
-                if (lane == 0) S.q[i][k * nw + wave] = r;  // virtual wave = row class * nw + wave
+                if (lane == 0) S.q[i][virt_wave(k)] = r;
             }
         }
         const unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
@@ -361,12 +382,17 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         double c0, c1, c2;
         double acc[VK];  // one per virtual wave this wave plays (see phase A): rows k, k + VK, ... of the pass
         bool on;
+        // u and flux by pixel: natural order in global memory; PF keeps them in LDS in the tables' pair layout
+        // (element {p, p + 256}: double index 2 * ((p >> 9) * 256 + (p & 255)) + ((p >> 8) & 1))
+        static __device__ __forceinline__ int at(int p) {
+            return PF ? (((((p >> 9) << 8) | (p & 255)) << 1) | ((p >> 8) & 1)) : p;
+        }
         // four consecutive rows of the pass (row = p / blockDim.x; a trip starts at a multiple of four rows)
         __device__ __forceinline__ void process4(const int (&pp)[4], const double (&xv)[4], const bool (&ok)[4]) {
             if (!on) return;
             double u[4], f[4], e[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { u[k] = pix_u[pp[k]]; f[k] = pix_flux[pp[k]]; e[k] = pix_ivar[pp[k]]; }
+            for (int k = 0; k < 4; ++k) { u[k] = pix_u[at(pp[k])]; f[k] = pix_flux[at(pp[k])]; e[k] = pix_ivar[pp[k]]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double poly = fma(fma(c2, u[k], c1), u[k], c0);
@@ -383,7 +409,8 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             }
         }
     };
-    ChiElem chi_elem{PF ? lds_u : P.pix_u, PF ? lds_f : P.pix_flux, P.pix_ivar,
+    ChiElem chi_elem{PF ? reinterpret_cast<const double *>(lds_u2) : P.pix_u,
+                     PF ? reinterpret_cast<const double *>(lds_f2) : P.pix_flux, P.pix_ivar,
                      P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
                      P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused};

@@ -243,14 +243,13 @@ int launch_conv(msx_ctx *c, const double *d_in, int64_t in_stride, double *d_tmp
 }
 
 int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
-    // Long spectra: one walker over 16 waves.  Otherwise, measured at 4096 px (us, 256 / 512 / 1024 / 4096 /
-    // 16384 walkers):  512 threads, one workgroup per CU, two pixels per trip + LDS-staged statics   20 / -- ...
-    //                  512 threads, two workgroups per CU, one pixel per trip (<= 128 VGPRs)         -- / 31 / 55 / 179 / 668
-    //                  256 threads, three workgroups per CU                                          25 / 34 / 55 / 165 / 590
+    // Measured at 4096 px: up to one walker per CU, 512 threads owning the CU with the pixel statics in
+    // LDS; up to 4 per CU, 512 threads sharing the CU two by two (<= 128 VGPRs); beyond, 256 threads three per CU.
+    // Long spectra (model vector > half the LDS): 512 threads, one workgroup per CU.
     // The choice only affects speed: every variant sums in the same order (see phase A), so a walker's value
     // has the same bits whichever one evaluates it.
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-    if (npix >= 8192) return 1024;
+    if (npix >= 8192) return 512;
     if (n <= 4 * cus) return 512;
     return 256;
 }
@@ -295,27 +294,27 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
 #define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                      \
     hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, STAGE>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
                        A.n, A.ndim, A.logp, A.status)
+    // dynamic LDS: the model vector; PF adds u and the data flux in the tables' pair layout
+    const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
     if constexpr (STAGE == 1) {
-        if (P.nspec == 2) MSX_GO(2, 1, 256, false, false, false, 0); else MSX_GO(3, 1, 256, false, false, false, 0);
+        if (P.nspec == 2) MSX_GO(2, 2, 256, false, false, false, 0); else MSX_GO(3, 2, 256, false, false, false, 0);
     } else if (c->model_in_global) {
         // spectra longer than the LDS: the model vector lives in the global scratch (STAGE 0 writes it there itself)
-        if (P.nspec == 2) MSX_GO(2, 1, 1024, true, false, false, 0); else MSX_GO(3, 1, 1024, true, false, false, 0);
+        if (P.nspec == 2) MSX_GO(2, 2, 512, true, false, false, 0); else MSX_GO(3, 2, 512, true, false, false, 0);
     } else {
-        // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 4 npix doubles fit
-        const bool cp = STAGE == 0 && P.pairs_c != nullptr;
-        const bool pf = B == 512 && !shared512 && A.n <= c->prop.multiProcessorCount && !cp && c->pf_ok && c->use_pf;
+        // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
+        const bool own_cu = A.n <= c->prop.multiProcessorCount || lds > 70 * 1024;  // (long spectra: one per CU anyway)
+        const bool pf = B == 512 && !shared512 && own_cu && c->pf_ok && c->use_pf;
+        const bool sh = B == 512 && !pf && (shared512 || !own_cu);
         if (P.nspec == 2) {
-            if (B == 256) { if (cp) MSX_GO(2, 2, 256, false, STAGE == 0, false, lds); else MSX_GO(2, 2, 256, false, false, false, lds); }
-            else if (B == 512) {
-                if (pf) MSX_GO(2, 2, 512, false, false, true, 4 * lds);
-                else if (cp) MSX_GO(2, 2, 512, false, STAGE == 0, false, lds);
-                else if (shared512 || A.n > c->prop.multiProcessorCount) MSX_GO(2, 1, 512, false, false, false, lds);  // two per CU
-                else MSX_GO(2, 2, 512, false, false, false, lds);
-            } else MSX_GO(2, 1, 1024, false, false, false, lds);
-        } else {
-            if (B == 256) MSX_GO(3, 1, 256, false, false, false, lds);
-            else if (B == 512) { if (pf) MSX_GO(3, 1, 512, false, false, true, 4 * lds); else MSX_GO(3, 1, 512, false, false, false, lds); }
-            else MSX_GO(3, 1, 1024, false, false, false, lds);
+            if (B == 256) MSX_GO(2, 2, 256, false, false, false, lds);
+            else if (pf) MSX_GO(2, 2, 512, false, false, true, lds_pf);
+            else if (sh) MSX_GO(2, 2, 512, false, true, false, lds);   // two workgroups per CU
+            else MSX_GO(2, 2, 512, false, false, false, lds);
+        } else {  // triples: twelve corners do not fit the shared variant's 128 VGPRs -- it is the plain one
+            if (B == 256) MSX_GO(3, 2, 256, false, false, false, lds);
+            else if (pf) MSX_GO(3, 2, 512, false, false, true, lds_pf);
+            else MSX_GO(3, 2, 512, false, false, false, lds);
         }
     }
 #undef MSX_GO
@@ -339,11 +338,10 @@ template <int STAGE>
 hipError_t raise_stage() {
     hipError_t e = hipSuccess;
 #define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__, STAGE>)
-    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 512, false, false, false); MSX_R(2, 1, 512, false, false, false);
-    MSX_R(2, 1, 1024, false, false, false); MSX_R(2, 2, 512, false, false, true);
-    MSX_R(3, 1, 256, false, false, false); MSX_R(3, 1, 512, false, false, false); MSX_R(3, 1, 1024, false, false, false);
-    MSX_R(3, 1, 512, false, false, true);
-    if (STAGE == 0) { MSX_R(2, 2, 256, false, STAGE == 0, false); MSX_R(2, 2, 512, false, STAGE == 0, false); }
+    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 512, false, false, false); MSX_R(2, 2, 512, false, true, false);
+    MSX_R(2, 2, 512, false, false, true);
+    MSX_R(3, 2, 256, false, false, false); MSX_R(3, 2, 512, false, false, false);
+    MSX_R(3, 2, 512, false, false, true);
 #undef MSX_R
     return e;
 }
@@ -622,26 +620,26 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     if ((rc = dev_alloc_copy(c, &tr, p->av_sig, (int64_t)p->nav, &d))) return rc; P.av_sig = d;
 
     const int64_t nn = (int64_t)c->nt * c->ng;
-    // pair table + k pairs
+    // the blend's tables in two-pixel elements (logprob_kernel.h "TABLE LAYOUT"): per node R (f64) + H (f32),
+    // per pixel k[lo], dk, data flux, u
     int64_t *d_lo = nullptr;
     if ((rc = dev_alloc_copy(c, &tr, p->pix_lo, p->npix, &d_lo))) return rc;
-    double2 *d_pairs = nullptr, *d_pk = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d_pairs, sizeof(double2) * nn * p->npix)); tr.push_back(d_pairs);
-    HIP_TRY(c, hipMalloc((void **)&d_pk, sizeof(double2) * p->npix)); tr.push_back(d_pk);
-    dim3 gg((unsigned)((p->npix + 255) / 256), (unsigned)nn);
-    hipLaunchKernelGGL(gather_pairs_kernel, gg, dim3(256), 0, c->stream, c->d_grid, c->nwl, d_lo, p->npix, d_pairs);
+    const int64_t npair = ((p->npix + 511) / 512) * 256;
+    double2 *d_r2 = nullptr, *d_kl2 = nullptr, *d_f2 = nullptr, *d_u2 = nullptr;
+    float2 *d_h2 = nullptr, *d_dk2 = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_r2, sizeof(double2) * nn * npair)); tr.push_back(d_r2);
+    HIP_TRY(c, hipMalloc((void **)&d_h2, sizeof(float2) * nn * npair)); tr.push_back(d_h2);
+    HIP_TRY(c, hipMalloc((void **)&d_kl2, sizeof(double2) * npair)); tr.push_back(d_kl2);
+    HIP_TRY(c, hipMalloc((void **)&d_dk2, sizeof(float2) * npair)); tr.push_back(d_dk2);
+    HIP_TRY(c, hipMalloc((void **)&d_f2, sizeof(double2) * npair)); tr.push_back(d_f2);
+    HIP_TRY(c, hipMalloc((void **)&d_u2, sizeof(double2) * npair)); tr.push_back(d_u2);
+    dim3 gg((unsigned)((npair + 255) / 256), (unsigned)nn);
+    hipLaunchKernelGGL(gather_rh_kernel, gg, dim3(256), 0, c->stream, c->d_grid, c->nwl, d_lo, P.pix_t, p->npix, npair, d_r2, d_h2);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3(gg.x, 1), dim3(256), 0, c->stream, c->d_kgrid, c->nwl, d_lo, p->npix, d_pk);
+    hipLaunchKernelGGL(gather_statics_kernel, dim3(gg.x), dim3(256), 0, c->stream, c->d_kgrid, d_lo, P.pix_flux, P.pix_u,
+                       p->npix, npair, d_kl2, d_dk2, d_f2, d_u2);
     HIP_TRY(c, hipGetLastError());
-    P.pairs = d_pairs; P.pix_k = d_pk;
-    P.pairs_c = nullptr;
-    if (p->compact_pairs) {
-        PairC *d_pc = nullptr;
-        HIP_TRY(c, hipMalloc((void **)&d_pc, sizeof(PairC) * nn * p->npix)); tr.push_back(d_pc);
-        hipLaunchKernelGGL(gather_pairs_compact_kernel, gg, dim3(256), 0, c->stream, c->d_grid, c->nwl, d_lo, p->npix, d_pc);
-        HIP_TRY(c, hipGetLastError());
-        P.pairs_c = d_pc;
-    }
+    P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.npair = npair;
     // band integrals
     double *d_tab = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_tab, sizeof(double) * std::max<int64_t>(1, nn * nb))); tr.push_back(d_tab);
@@ -663,7 +661,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->max_dyn_lds = (int)need_lds;
     c->model_in_global = model_in_global;
-    c->pf_ok = !model_in_global && 4 * need_lds <= 148 * 1024;  // + ~12 KB static scratch <= 160 KB
+    c->pf_ok = !model_in_global && need_lds + 16 + 32 * npair <= 147 * 1024;  // model + u2 + f2, + ~12 KB static <= 160 KB
     if ((rc = raise_dynamic_lds_limits(c))) return rc;
     c->recipe_fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave && P.nav + 1 <= 2 * kWave;
     // Scratch of the split path, sized once here so that no launch ever allocates or synchronises: a batch is
@@ -734,8 +732,8 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     if (n == 0) return MSX_OK;
     const bool shared512 = block_threads == MSX_BLOCK_512_SHARED;  // 512 threads, the <= 128-VGPR variant that
     if (shared512) block_threads = 512;                            // shares a CU with another workgroup
-    if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 1024)
-        return fail(c, MSX_ERR_INVALID, "block_threads must be 0, 256, 512, 1024 or MSX_BLOCK_512_SHARED");
+    if (block_threads != 0 && block_threads != 256 && block_threads != 512)
+        return fail(c, MSX_ERR_INVALID, "block_threads must be 0, 256, 512 or MSX_BLOCK_512_SHARED");
     hipStream_t s = (hipStream_t)hip_stream;
     const DevProblem &Pc = c->P;
     // the leading, preloaded kernel arguments (see logprob_kernel): theta, the recipe's small tables and three
@@ -749,7 +747,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // ---- which form of the path -------------------------------------------------------------------------
     // split (split_kernels.h): many walkers (shared row loads) or long spectra (pixels over all CUs).  Only the
     // likelihood / posterior / chi^2 modes of a problem with a spectrum term, float64 pairs and small recipe tables.
-    const bool can_split = c->split_batch > 0 && fast && !Pc.no_spectrum && !Pc.pairs_c && !Pc.smp_on &&
+    const bool can_split = c->split_batch > 0 && fast && !Pc.no_spectrum && !Pc.smp_on &&
                            (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
     bool split = can_split && (n >= c->split_min_walkers || Pc.npix >= c->split_min_npix);
     if (c->path == MSX_PATH_FUSED) split = false;
@@ -777,18 +775,17 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kPlanThreads), 0, s, c->d_rec, (int)m, Pc.nspec * 4, c->d_perm,
                            c->d_tiles, c->d_hdr, c->d_tmp, c->d_tmp + c->split_batch);
         HIP_TRY(c, hipGetLastError());
-        // 3. blend: (tile, pixel chunk) work items, grid-strided; the grid is a multiple of 8 (XCD-local chunks)
+        // 3. blend: (tile, 512-pixel chunk) work items, grid-strided; the grid is a multiple of 8 (XCD-local chunks)
         {
-            constexpr int U = 2;
-            const int64_t nchunk = (Pc.npix + 256 * U - 1) / (256 * U);
+            const int64_t nchunk = Pc.npair / 256;
             const int64_t items = m * nchunk;  // upper bound: one tile per walker
             const unsigned grid = (unsigned)(std::min<int64_t>((items + 7) / 8 * 8, cus * 8));
             if (Pc.nspec == 2)
-                hipLaunchKernelGGL((blend_tiles_kernel<2, U>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles,
-                                   c->d_hdr, Pc.pairs, Pc.pix_k, Pc.pix_t, (int)Pc.npix, c->d_model_scratch);
+                hipLaunchKernelGGL((blend_tiles_kernel<2>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles, c->d_hdr,
+                                   Pc.r2, Pc.h2, Pc.kl2, Pc.dk2, (int)Pc.npix, (int)Pc.npair, c->d_model_scratch);
             else
-                hipLaunchKernelGGL((blend_tiles_kernel<3, U>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles,
-                                   c->d_hdr, Pc.pairs, Pc.pix_k, Pc.pix_t, (int)Pc.npix, c->d_model_scratch);
+                hipLaunchKernelGGL((blend_tiles_kernel<3>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles, c->d_hdr,
+                                   Pc.r2, Pc.h2, Pc.kl2, Pc.dk2, (int)Pc.npix, (int)Pc.npair, c->d_model_scratch);
             HIP_TRY(c, hipGetLastError());
         }
         // 4. per walker: fit sums, exact median, chi^2, combine
@@ -1252,15 +1249,31 @@ int msx_stream_copy_gbps(msx_ctx *c, int64_t bytes, int32_t iters, double *gbps_
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
-    const int blocks = c->prop.multiProcessorCount * 8;  // 2048 workgroups of 256 threads
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copy_float4_kernel, dim3(blocks), dim3(256), 0, c->stream, a, b, n4);
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(copy_float4_kernel, dim3(blocks), dim3(256), 0, c->stream, a, b, n4);
-    HIP_TRY(c, hipEventRecord(e1, c->stream));
-    HIP_TRY(c, hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
-    *gbps_out = (2.0 * (double)(n4 * 16) * iters) / ((double)ms * 1e-3) / 1e9;
+    const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    double best = 0.0;
+    for (int variant = 0; variant < 4; ++variant) {
+        for (int per_cu : {8, 16, 32}) {
+            const dim3 g((unsigned)(cus * per_cu)), bthreads(256);
+            auto go = [&]() {
+                switch (variant) {
+                    case 0: hipLaunchKernelGGL((copy_float4_kernel<4, false>), g, bthreads, 0, c->stream, a, b, n4); break;
+                    case 1: hipLaunchKernelGGL((copy_float4_kernel<8, false>), g, bthreads, 0, c->stream, a, b, n4); break;
+                    case 2: hipLaunchKernelGGL((copy_float4_kernel<4, true>), g, bthreads, 0, c->stream, a, b, n4); break;
+                    default: hipLaunchKernelGGL((copy_float4_kernel<8, true>), g, bthreads, 0, c->stream, a, b, n4); break;
+                }
+            };
+            go();
+            HIP_TRY(c, hipEventRecord(e0, c->stream));
+            for (int i = 0; i < iters; ++i) go();
+            HIP_TRY(c, hipEventRecord(e1, c->stream));
+            HIP_TRY(c, hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+            const double gbps = (2.0 * (double)(n4 * 16) * iters) / ((double)ms * 1e-3) / 1e9;
+            best = gbps > best ? gbps : best;
+        }
+    }
+    *gbps_out = best;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(a);
@@ -1273,8 +1286,8 @@ int msx_bytes_per_eval(msx_ctx *c, int64_t *requested_bytes) {
     if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_bytes_per_eval: no problem staged");
     const int64_t npix = c->P.npix;
     // pair rows (16 B x corners) + per-pixel statics read in phases A and C
-    const int64_t pair_bytes = (c->P.pairs_c && c->P.nspec == 2) ? 12 : 16;
-    *requested_bytes = npix * (pair_bytes * (int64_t)c->P.nspec * 4 + 16 + 8 * 3 + 8 * 3) + 8 * (2 * c->P.nspec + 2) + 12;
+    // blend: 12-B {R, H} per corner + {k_lo f64, dk f32} + flux, u;  chi^2 pass: u, flux, 1/err^2
+    *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + 24) + 8 * (2 * c->P.nspec + 2) + 12;
     return MSX_OK;
 }
 

@@ -132,23 +132,23 @@ plan_tiles_kernel(const WalkerRec *__restrict__ rec, int n, int nc, int32_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 3: work item = (tile, chunk of 256*U pixels), grid-strided.  With a chunk count that is a multiple of 8
-// (4096 px / 512, 16384 px / 512) and a grid that is a multiple of 8, block b only ever sees chunks = b mod 8:
+// Stage 3: work item = (tile, chunk of 256 table elements = 512 pixels), grid-strided.  With a chunk count that is a
+// multiple of 8 (4096 px / 512, 16384 px / 512) and a grid that is a multiple of 8, block b only ever sees chunks = b mod 8:
 // under round-robin dispatch every XCD's L2 holds one eighth of each pair row (speed only).
 // ------------------------------------------------------------------------------------------------
-template <int NS, int U>
+template <int NS>
 __global__ void __launch_bounds__(256)
 blend_tiles_kernel(const WalkerRec *__restrict__ rec, const int32_t *__restrict__ perm, const TileHdr *__restrict__ tiles,
-                   const int32_t *__restrict__ hdr, const double2 *__restrict__ pairs, const double2 *__restrict__ pix_k,
-                   const double *__restrict__ pix_t, int npix, double *__restrict__ model) {
+                   const int32_t *__restrict__ hdr, const double2 *__restrict__ r2, const float2 *__restrict__ h2,
+                   const double2 *__restrict__ kl2, const float2 *__restrict__ dk2, int npix, int npair,
+                   double *__restrict__ model) {
     constexpr int NC = NS * 4;
-    constexpr int CH = 256 * U;
     __shared__ __attribute__((aligned(16))) double sW[kTileWalkers][NC];
     __shared__ double sRedc[kTileWalkers];
     __shared__ int sWalker[kTileWalkers];
     const int tid = threadIdx.x;
     const int ntiles = hdr[0];
-    const int nchunk = (npix + CH - 1) / CH;
+    const int nchunk = npair / 256;  // one chunk = 256 elements = 512 pixels
     const long long nitems = (long long)ntiles * nchunk;
     for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int chunk = (int)(item % nchunk);
@@ -156,21 +156,18 @@ blend_tiles_kernel(const WalkerRec *__restrict__ rec, const int32_t *__restrict_
         const TileHdr *th = tiles + tile;
         const int start = __builtin_amdgcn_readfirstlane(th->start), count = __builtin_amdgcn_readfirstlane(th->count);
         // rows first: the longest latency of the item
-        const double2 *rows[NC];
+        const int e = chunk * 256 + tid;
+        const int pa = chunk * 512 + tid, pb = pa + 256;
+        double2 rr[NC];
+        float2 hh[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) rows[c] = pairs + (int64_t)__builtin_amdgcn_readfirstlane(th->node[c]) * npix;
-        double2 v[U][NC], kk[U];
-        double tt[U];
-        int pp[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = chunk * CH + u * 256 + tid;
-            pp[u] = p < npix ? p : npix - 1;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[u][c] = rows[c][pp[u]];
-            kk[u] = pix_k[pp[u]];
-            tt[u] = pix_t[pp[u]];
+        for (int c = 0; c < NC; ++c) {
+            const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(th->node[c]) * npair;
+            rr[c] = r2[off + e];
+            hh[c] = h2[off + e];
         }
+        const double2 kl = kl2[e];
+        const float2 dk = dk2[e];
         // the tile's walkers: weights + reddening coefficient to LDS (one element per thread)
         if (tid < count * (NC + 1)) {
             const int wi = tid / (NC + 1), c = tid - wi * (NC + 1);
@@ -179,18 +176,22 @@ blend_tiles_kernel(const WalkerRec *__restrict__ rec, const int32_t *__restrict_
             else { sRedc[wi] = rec[wk].redc; sWalker[wi] = wk; }
         }
         __syncthreads();
+        double ra[NC], rb[NC];
+        float ha[NC], hb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ra[c] = rr[c].x; rb[c] = rr[c].y; ha[c] = hh[c].x; hb[c] = hh[c].y; }
         for (int wi = 0; wi < count; ++wi) {
             double w[NC];
+            float wf[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) w[c] = sW[wi][c];
+            for (int c = 0; c < NC; ++c) { w[c] = sW[wi][c]; wf[c] = (float)w[c]; }
             const double redc = sRedc[wi];
             const bool redden = redc != 0.0;
             double *out = model + (int64_t)sWalker[wi] * npix;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double m = blend_pixel<NC, false>(v[u], w, kk[u], tt[u], redc, redden);
-                if (chunk * CH + u * 256 + tid < npix) out[pp[u]] = m;
-            }
+            const double ma = blend_pixel_rh<NC>(ra, ha, w, wf, kl.x, (double)dk.x, redc, redden);
+            const double mb = blend_pixel_rh<NC>(rb, hb, w, wf, kl.y, (double)dk.y, redc, redden);
+            if (pa < npix) out[pa] = ma;
+            if (pb < npix) out[pb] = mb;
         }
         __syncthreads();  // the next item overwrites sW
     }

@@ -38,26 +38,40 @@ __global__ void ccm89_kernel(const double *__restrict__ wl, int64_t n, double rv
     out[i] = a + b / rv;
 }
 
-// pairs[node][p] = {grid[node][lo_p], grid[node][lo_p+1]};  node = blockIdx.y
-__global__ void gather_pairs_kernel(const double *__restrict__ grid, int64_t nwl, const int64_t *__restrict__ lo,
-                                    int64_t npix, double2 *__restrict__ pairs) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    const double *row = grid + (int64_t)blockIdx.y * nwl;
-    const int64_t j = lo[p];
-    pairs[(int64_t)blockIdx.y * npix + p] = make_double2(row[j], row[j + 1]);
+// The blend's tables (logprob_kernel.h "TABLE LAYOUT"; blend.h blend_pixel_rh).  Element e holds pixels
+// {pa, pa + 256}, pa = (e >> 8) * 512 + (e & 255); pad pixels (>= npix) repeat the last real pixel.
+__device__ __forceinline__ void element_pixels(int64_t e, int64_t npix, int64_t *pa, int64_t *pb) {
+    const int64_t a = ((e >> 8) << 9) | (e & 255), b = a + 256;
+    *pa = a < npix ? a : npix - 1;
+    *pb = b < npix ? b : npix - 1;
 }
-
-__global__ void gather_pairs_compact_kernel(const double *__restrict__ grid, int64_t nwl, const int64_t *__restrict__ lo,
-                                            int64_t npix, PairC *__restrict__ pairs) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
+// R = lo + (hi - lo) t, H = hi t of one grid node (blockIdx.y) at both pixels of element e
+__global__ void gather_rh_kernel(const double *__restrict__ grid, int64_t nwl, const int64_t *__restrict__ lo,
+                                 const double *__restrict__ t, int64_t npix, int64_t npair, double2 *__restrict__ R,
+                                 float2 *__restrict__ H) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npair) return;
+    int64_t pa, pb;
+    element_pixels(e, npix, &pa, &pb);
     const double *row = grid + (int64_t)blockIdx.y * nwl;
-    const int64_t j = lo[p];
-    PairC out;
-    out.lo = row[j];
-    out.d = (float)(row[j + 1] - row[j]);
-    pairs[(int64_t)blockIdx.y * npix + p] = out;
+    const double a0 = row[lo[pa]], a1 = row[lo[pa] + 1], b0 = row[lo[pb]], b1 = row[lo[pb] + 1];
+    R[(int64_t)blockIdx.y * npair + e] = make_double2(fma(a1 - a0, t[pa], a0), fma(b1 - b0, t[pb], b0));
+    H[(int64_t)blockIdx.y * npair + e] = make_float2((float)(a1 * t[pa]), (float)(b1 * t[pb]));
+}
+// CCM89 k[lo], k[lo+1] - k[lo], and phase A's copies of the data flux and mapped wavelength, per element
+__global__ void gather_statics_kernel(const double *__restrict__ kgrid, const int64_t *__restrict__ lo,
+                                      const double *__restrict__ flux, const double *__restrict__ u, int64_t npix,
+                                      int64_t npair, double2 *__restrict__ kl2, float2 *__restrict__ dk2,
+                                      double2 *__restrict__ f2, double2 *__restrict__ u2) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npair) return;
+    int64_t pa, pb;
+    element_pixels(e, npix, &pa, &pb);
+    const int64_t ja = lo[pa], jb = lo[pb];
+    kl2[e] = make_double2(kgrid[ja], kgrid[jb]);
+    dk2[e] = make_float2((float)(kgrid[ja + 1] - kgrid[ja]), (float)(kgrid[jb + 1] - kgrid[jb]));
+    f2[e] = make_double2(flux[pa], flux[pb]);
+    u2[e] = make_double2(u[pa], u[pb]);
 }
 
 // band_tab[node][b] = sum_i w_b[i] * grid[node][i0_b + i];  grid.x = band, grid.y = node
@@ -185,17 +199,29 @@ __global__ void composite_kernel(DevProblem P, const WalkerDesc *__restrict__ Dp
     spec[i] = total;
 }
 
-__global__ void __launch_bounds__(256)
-copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
-    // 4 independent 16-B loads in flight per lane, then 4 stores; grid-stride over 1024-element tiles
-    const int64_t stride = (int64_t)gridDim.x * 1024;
-    for (int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x; base < n4; base += stride) {
-        float4 v[4];
+// Stream copy (the measured-HBM-bandwidth figure quoted beside the roofline): every lane keeps UNROLL independent
+// 16-byte loads in flight, then stores them; workgroups stride over tiles of 256 * UNROLL float4.  NT = nontemporal
+// loads and stores (no reuse: keep the lines out of the way).  msx_stream_copy_gbps times a few (UNROLL, NT, grid)
+// combinations and reports the best: it is a property of the chip that is being measured, not of one kernel shape.
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) copy_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
+    const int64_t tile = 256 * UNROLL;
+    const int64_t stride = (int64_t)gridDim.x * tile;
+    typedef float vf4 __attribute__((ext_vector_type(4)));  // (the nontemporal builtins take native vectors)
+    const vf4 *s4 = reinterpret_cast<const vf4 *>(src);
+    vf4 *d4 = reinterpret_cast<vf4 *>(dst);
+    for (int64_t base = (int64_t)blockIdx.x * tile + threadIdx.x; base < n4; base += stride) {
+        vf4 v[UNROLL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (base + 256 * k < n4) ? src[base + 256 * k] : make_float4(0, 0, 0, 0);
+        for (int k = 0; k < UNROLL; ++k) {
+            const int64_t i = base + 256 * k;
+            if (i < n4) v[k] = NT ? __builtin_nontemporal_load(s4 + i) : s4[i];
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (base + 256 * k < n4) dst[base + 256 * k] = v[k];
+        for (int k = 0; k < UNROLL; ++k) {
+            const int64_t i = base + 256 * k;
+            if (i < n4) { if (NT) __builtin_nontemporal_store(v[k], d4 + i); else d4[i] = v[k]; }
+        }
     }
 }
 

@@ -56,14 +56,12 @@ class Engine:
 
     # ---- problem ------------------------------------------------------------------------------------
     def stage_problem(self, data, err, fr, r, ctm, ptm, tmi, tma, matrix, nspec=2, bands=None, av_table=None,
-                      tmin=-np.inf, tmax=np.inf, prior=0, use_av=True, dist_fit=True, rad_prior=False, spectrum=True,
-                      compact_pairs=False):
+                      tmin=-np.inf, tmax=np.inf, prior=0, use_av=True, dist_fit=True, rad_prior=False, spectrum=True):
         if self.grid is None:
             raise RuntimeError('stage the model grid first')
         st = staging.build_problem(self.ctx, self.grid['wl'], data, err, fr, r, ctm, ptm, tmi, tma, matrix,
                                    nspec=nspec, bands=bands, av_table=av_table, tmin=tmin, tmax=tmax, prior=prior,
-                                   use_av=use_av, dist_fit=dist_fit, rad_prior=rad_prior, spectrum=spectrum,
-                                   compact_pairs=compact_pairs)
+                                   use_av=use_av, dist_fit=dist_fit, rad_prior=rad_prior, spectrum=spectrum)
         self.ctx.stage_problem(st.prob)
         self.tables = st
         self.nspec = int(nspec)

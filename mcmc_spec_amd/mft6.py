@@ -30,6 +30,7 @@ _SPECTRUM = True
 _DEVICE = int(os.environ.get('LOCAL_RANK', '0'))
 _GRIDS = collections.OrderedDict()      # id(specs) -> (specs, Engine)
 _MAX_GRIDS = 2
+_LAST_DATASET = None                    # (specs, fr, data, err, r, ctm, ptm, tmi, tma) of the last staging call
 
 
 def set_device(device):
@@ -131,6 +132,8 @@ def _staged(specs, fr, nspec, data, err, r, ctm, ptm, tmi, tma, matrix, tmin=-np
                           spectrum=_SPECTRUM)
         eng._problem_key = key
         eng._problem_refs = (fr, data, err, ctm, ptm, matrix)  # pin the ids in the key
+    global _LAST_DATASET
+    _LAST_DATASET = (specs, fr, data, err, r, ctm, ptm, tmi, tma)
     return eng
 
 
@@ -162,22 +165,26 @@ def loglikelihood(p0, fr, nspec, ndust, data, err, broadening, r, specs, ctm, pt
 
 def logprior(p0, nspec, ndust, tmin, tmax, matrix, ra, dec, prior=0, ext=True, dist_fit=True, rad_prior=False,
              specs=None):
-    """mft6.py:1207-1272.  The reference signature carries no grid; the prior is evaluated by the
-    engine most recently used (or the one staged for ``specs`` when given), with its dataset."""
+    """mft6.py:1207-1272.  The value depends on ``p0`` and on the arguments above only; the reference signature
+    carries neither grid nor dataset, but the device evaluates priors inside a staged problem, so one is needed:
+    the dataset of the LAST ``logposterior`` / ``loglikelihood`` call (recorded explicitly, not "whichever engine
+    was touched last"), or -- with ``specs=`` -- the last dataset staged on that grid."""
     p = _check_p0(p0, nspec)
-    if specs is not None:
-        eng = _engine_for(specs)
-    elif _GRIDS:
-        eng = next(reversed(_GRIDS.values()))[1]
-    else:
-        raise RuntimeError('logprior needs a staged engine: call logposterior/loglikelihood once, or pass specs=')
-    if eng.tables is None or eng._problem_refs is None:
+    last = _LAST_DATASET
+    if specs is not None and (last is None or last[0] is not specs):
+        hit = _GRIDS.get(id(specs))
+        if hit is None or hit[0] is not specs or hit[1]._problem_refs is None or hit[1].tables is None:
+            raise RuntimeError('logprior(specs=...): nothing has been staged on this grid yet; call '
+                               'logposterior/loglikelihood with it once first')
+        fr, data, err, ctm, ptm, _ = hit[1]._problem_refs
+        st = hit[1].tables
+        last = (specs, fr, data, err, st.r, ctm, ptm, st.tmi, st.tma)
+    if last is None:
         raise RuntimeError('logprior needs a staged dataset: call logposterior/loglikelihood once first')
-    fr, data, err, ctm, ptm, _ = eng._problem_refs
-    st = eng.tables
-    eng2 = _staged(next(reversed(_GRIDS.values()))[0] if specs is None else specs, fr, nspec, data, err, st.r, ctm,
-                   ptm, st.tmi, st.tma, matrix, tmin, tmax, prior, ext, dist_fit, rad_prior, need_prior=True)
-    return eng2.logprior(p)
+    sp, fr, data, err, r, ctm, ptm, tmi, tma = last
+    eng = _staged(sp, fr, nspec, data, err, r, ctm, ptm, tmi, tma, matrix, tmin, tmax, prior, ext, dist_fit, rad_prior,
+                  need_prior=True)
+    return eng.logprior(p)
 
 
 def make_composite(teff, logg, rad, distance, contrast_filt, phot_filt, r, specs, ctm, ptm, tmi, tma, vs, nspec=2,
@@ -224,4 +231,6 @@ def broaden(even_wl, modelspec_interp, res, vsini=0, limb=0, plot=False):
 
 
 def clear_cache():
+    global _LAST_DATASET
     _GRIDS.clear()
+    _LAST_DATASET = None

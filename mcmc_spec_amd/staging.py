@@ -154,7 +154,7 @@ class StagedTables:
 
 def build_problem(ctx, grid_wl, data, err, fr, r, ctm, ptm, tmi, tma, matrix, nspec=2, bands=None,
                   av_table=None, tmin=-np.inf, tmax=np.inf, prior=0, use_av=True, dist_fit=True, rad_prior=False,
-                  spectrum=True, compact_pairs=False):
+                  spectrum=True):
     """Assemble ``struct msx_problem`` for one dataset.  Arguments follow ``logposterior``'s
     (mft6.py:1459): ``data = [wl_um, flux]``, ``fr = [cmag, cerr, cfilt, pmag, perr, pfilt]``,
     ``ctm``/``ptm`` = ``[wls, tras, n_res_el, cwl]``.  ``bands`` maps pyphot-style names to
@@ -248,7 +248,6 @@ def build_problem(ctx, grid_wl, data, err, fr, r, ctm, ptm, tmi, tma, matrix, ns
     P.rad_prior = int(bool(rad_prior))
     P.has_prior_list = has
     P.no_spectrum = 0 if spectrum else 1  # mft6_nospec.py drops the spectrum term
-    P.compact_pairs = int(bool(compact_pairs))
     st.window = (j0, nwin)
     st.r, st.tmi, st.tma = [float(x) for x in r], float(tmi), float(tma)
     st.phot_cwl = np.array(phot_cwl)

@@ -59,7 +59,8 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
     """Every variant of the hot kernel must keep its working set in registers.  (The problem struct is a by-value
     kernel argument: a helper that stops being inlined makes the compiler copy all 1.2 KB of it into per-lane
     scratch, which doubled the kernel time once; every such helper is force-inlined.)  The variants capped at
-    168 / 128 VGPRs by their occupancy target (256 and 1024 threads) may park a few dwords; nothing else may."""
+    168 / 128 VGPRs by their occupancy target (256 threads; 512 threads sharing a CU) may park a few dwords; nothing
+    else may."""
     src = os.path.join(ROOT, 'mcmc_spec_amd', 'csrc', 'msx.hip')
     with tempfile.TemporaryDirectory() as d:
         out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
@@ -73,7 +74,7 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
         if 'Function Name' in ln and 'logprob_kernel' in ln:
             block = '\n'.join(lines[i:i + 14])
             m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', block)
-            capped = 'Li256E' in ln or 'Li1024E' in ln
-            assert m and int(m.group(1)) <= (48 if capped else 0), block
+            capped = 'Li256E' in ln or 'Li512ELb0ELb1E' in ln   # 256 threads, or 512 with SH (shared CU)
+            assert m and int(m.group(1)) <= (64 if capped else 0), block
             seen += 1
-    assert seen >= 12   # binary + triple; 256 / 512 / 1024 threads; global-model, compact-pair, LDS-staged variants
+    assert seen >= 12   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; stages 0-2

@@ -252,7 +252,7 @@ def test_early_histogram_median_branches(shape):
         from mcmc_spec_amd import _lib
         dev = torch.device('cuda', 0)
         tht = torch.from_numpy(np.ascontiguousarray(th)).to(dev)
-        for block in (0, 256, 1024):   # auto = 512 threads with LDS-staged statics; 256 and 1024 without
+        for block in (0, 256, _lib.BLOCK_512_SHARED):   # auto = 512 threads with LDS-staged statics; the others without
             lp = torch.empty(len(th), dtype=torch.float64, device=dev)
             st = torch.empty(len(th), dtype=torch.int32, device=dev)
             eng.ctx.logprob_batch_dev(tht.data_ptr(), len(th), 6, lp.data_ptr(), st.data_ptr(),
@@ -262,7 +262,7 @@ def test_early_histogram_median_branches(shape):
             assert rel_err(lp.cpu().numpy(), want).max() < TIGHT, (shape, npix, block)
 
 
-@pytest.mark.parametrize('block', [256, 512, 1024])
+@pytest.mark.parametrize('block', [256, 512, 1512])   # 1512 = MSX_BLOCK_512_SHARED
 def test_every_workgroup_size_gives_identical_bits(block, engB):
     import torch
     from mcmc_spec_amd import _lib
@@ -283,7 +283,7 @@ def test_every_workgroup_size_gives_identical_bits(block, engB):
 def test_bits_do_not_depend_on_workgroup_size_or_batch():
     """the gathered vector of a sharded run must be bit-identical to the one-GPU vector.  Shards are
     launched with other batch sizes, hence other workgroup sizes, so every sum of the kernel is taken in an order
-    that is independent of both (16 virtual waves).  Weak contrast terms here, so that the spectral chi^2 -- the
+    that is independent of both (1024 accumulator slots, 16 virtual waves).  Weak contrast terms here, so that the spectral chi^2 -- the
     part that is summed over pixels -- carries the value's low bits."""
     import torch
     from mcmc_spec_amd import _lib
@@ -302,7 +302,7 @@ def test_bits_do_not_depend_on_workgroup_size_or_batch():
     tht = torch.from_numpy(np.ascontiguousarray(th)).to(dev)
     out = {}
     for mode in (_lib.MODE_LOGLIKE, _lib.MODE_CHISQ):
-        for block in (256, 512, 1024, 0):
+        for block in (256, 512, _lib.BLOCK_512_SHARED, 0):
             lp = torch.empty(len(th), dtype=torch.float64, device=dev)
             st = torch.empty(len(th), dtype=torch.int32, device=dev)
             eng.ctx.logprob_batch_dev(tht.data_ptr(), len(th), 6, lp.data_ptr(), st.data_ptr(),
@@ -311,7 +311,7 @@ def test_bits_do_not_depend_on_workgroup_size_or_batch():
             out[mode, block] = lp.cpu().numpy()
         ref = out[mode, 256]
         assert np.isfinite(ref).sum() > 100
-        for block in (512, 1024, 0):
+        for block in (512, _lib.BLOCK_512_SHARED, 0):
             assert np.array_equal(out[mode, block], ref, equal_nan=True), (mode, block)
         # a shard of the batch (other n -> other automatic workgroup size, 512 threads with LDS-staged statics)
         lp = torch.empty(100, dtype=torch.float64, device=dev)
@@ -388,6 +388,31 @@ def test_dropin_signatures_match_reference_golden():
         m.logposterior(np.zeros(7), *post_args, **kw)
 
 
+def test_dropin_logprior_with_two_live_datasets():
+    """logprior takes its dataset from the LAST staging call (or from `specs=`), explicitly -- and since the value
+    depends on p0 and the prior arguments only, it is the same whichever dataset carries it."""
+    import mcmc_spec_amd.mft6 as m
+    from mcmc_spec_amd import bands
+    a, b = golden_case('A'), golden_case('B')
+    m.clear_cache()
+    m.set_band_library(bands.make_bands(b.tables, *b.vega))
+    m.set_av_prior(*common.av_table_exact())
+    th = a.g['theta_post']
+    with pytest.raises(RuntimeError):
+        m.logprior(th, 2, 0, a.tmin, a.tmax, a.matrix, 10.0, 20.0, prior=a.prior)
+    m.loglikelihood(th[:4], a.fr, 2, 0, a.data, a.err, 1700, a.r, a.specs, a.ctm, a.ptm, a.tmi, a.tma, None, a.matrix)
+    lp_a = m.logprior(th, 2, 0, a.tmin, a.tmax, a.matrix, 10.0, 20.0, prior=a.prior, rad_prior=True)
+    specs_b = dict(b.specs)     # a second grid object + dataset alive at the same time
+    m.loglikelihood(th[:4], b.fr, 2, 0, b.data, b.err, 1700, b.r, specs_b, b.ctm, b.ptm, b.tmi, b.tma, None, b.matrix)
+    lp_b = m.logprior(th, 2, 0, a.tmin, a.tmax, a.matrix, 10.0, 20.0, prior=a.prior, rad_prior=True)
+    lp_a2 = m.logprior(th, 2, 0, a.tmin, a.tmax, a.matrix, 10.0, 20.0, prior=a.prior, rad_prior=True, specs=a.specs)
+    assert np.array_equal(lp_a, lp_b) and np.array_equal(lp_a, lp_a2)
+    assert rel_err(lp_a, a.g['A_logprior_radprior']).max() < 1e-12
+    with pytest.raises(RuntimeError):
+        m.logprior(th, 2, 0, a.tmin, a.tmax, a.matrix, 10.0, 20.0, prior=a.prior, specs=dict(a.specs))
+    m.clear_cache()
+
+
 def test_dropin_make_composite_and_broaden():
     from oracle import mft6_oracle as orc
     c = golden_case('B')
@@ -445,12 +470,12 @@ def test_triple_system_ndim8_matches_reference_golden():
     assert rel_err(ll, g['C_loglike'][ok]).max() < TIGHT
     lp = eng.logprior(c.theta)
     assert np.array_equal(np.isinf(lp), np.isinf(g['C_logprior'])) and rel_err(lp, g['C_logprior']).max() < 1e-12
-    # the triple-system kernel variants (256 / 512 / 1024 threads) agree to the bit
+    # the triple-system kernel variants (256 / 512 threads, alone or sharing a CU) agree to the bit
     import torch
     from mcmc_spec_amd import _lib
     dev = torch.device('cuda', 0)
     tht = torch.from_numpy(np.ascontiguousarray(c.theta)).to(dev)
-    for block in (256, 512, 1024):
+    for block in (256, 512, _lib.BLOCK_512_SHARED):
         out = torch.empty(len(c.theta), dtype=torch.float64, device=dev)
         st = torch.empty(len(c.theta), dtype=torch.int32, device=dev)
         eng.ctx.logprob_batch_dev(tht.data_ptr(), len(c.theta), 8, out.data_ptr(), st.data_ptr(),
@@ -816,31 +841,21 @@ def test_randomised_edge_walkers_against_oracle(engB):
     assert rel_err(ll, wl).max() < TIGHT
 
 
-def test_compact_pair_storage_is_opt_in_and_stays_inside_the_bar():
-    """msx_problem.compact_pairs: {f64 flux[lo], f32 difference} pair table (12 B).  Not bit-faithful to the
-    float64 arithmetic, so it is off by default; when switched on the log-probabilities must still agree with
-    the reference goldens far inside the 1e-6 bar (measured: 3e-13 at S/N 100, 3e-11 at S/N 1000)."""
-    from mcmc_spec_amd.engine import Engine
-    from mcmc_spec_amd import bands
+def test_resampled_tables_stay_at_rounding_level_under_heavy_extinction():
+    """The blend reads, per grid node and pixel, R = lo + (hi - lo) t (float64) and H = hi t (float32) instead of
+    the two model samples (blend.h): H only ever enters multiplied by e_hi / e_lo - 1 ~ 4e-5 A_V.  Its float32
+    rounding must stay at float64 rounding level in the log-likelihood even at A_V = 3, thirty times the example
+    run's extinction -- against the oracle, which blends, reddens and resamples like the reference."""
     c = golden_case('B')
-    eng = Engine(0)
-    eng.stage_specs(c.specs)
-    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
-                      bands=bands.make_bands(c.tables, *c.vega), compact_pairs=True)
-    got = eng.loglikelihood(c.theta)
-    assert rel_err(got, c.g['B_loglike']).max() < TIGHT
-    assert eng.ctx.bytes_per_eval() < 700 * (16 * 8 + 64)   # 12-byte pairs are in use
-    import torch
-    from mcmc_spec_amd import _lib
-    dev = torch.device('cuda', 0)
-    tht = torch.from_numpy(np.ascontiguousarray(c.theta)).to(dev)
-    for block in (256, 512):   # both compact-pair variants, same bits
-        lp = torch.empty(len(c.theta), dtype=torch.float64, device=dev)
-        st = torch.empty(len(c.theta), dtype=torch.int32, device=dev)
-        eng.ctx.logprob_batch_dev(tht.data_ptr(), len(c.theta), 6, lp.data_ptr(), st.data_ptr(),
-                                  torch.cuda.current_stream(dev).cuda_stream, _lib.MODE_LOGLIKE, block)
-        torch.cuda.synchronize()
-        assert np.array_equal(lp.cpu().numpy(), got, equal_nan=True), block
+    eng = make_engine(c, with_prior=False)
+    th = np.repeat(c.theta[:6], 4, axis=0)
+    th[:, 2] = np.tile([0.0, 0.3, 1.0, 3.0], 6)
+    got = eng.loglikelihood(th)
+    want = np.array([oracle_loglike(c, t) for t in th])
+    e = rel_err(got, want)
+    print('resampled tables, A_V in {0, 0.3, 1, 3}: max relative deviation from the oracle', e.max())
+    assert e.max() < 1e-11
+    assert eng.ctx.bytes_per_eval() == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12   # 12 bytes per node-pixel are in use
 
 
 def test_fuzzed_problems_against_the_oracle():

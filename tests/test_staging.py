@@ -102,3 +102,38 @@ def test_synthetic_generators_are_deterministic():
     assert np.array_equal(synth.draw_walkers(8), synth.draw_walkers(8))
     th = synth.draw_walkers(512)
     assert th[:, 0].min() >= 3000 and th[:, 3].min() >= 0.05 and th[:, 5].max() <= 0.25
+
+
+def test_from_pyphot_adapts_a_library_object():
+    """bands.from_pyphot against a stand-in with pyphot's attribute shapes: quantities carrying `.magnitude`
+    (pint-style) or `.value` (astropy-style), plain arrays, Vega zero points for 2MASS and AB for SDSS
+    (mft6.py:778-782).  pyphot itself is not installed here: the adapter's own logic is what is pinned."""
+    from mcmc_spec_amd import bands
+
+    class Q:
+        def __init__(self, v, attr):
+            setattr(self, attr, v)
+
+    class F:
+        def __init__(self, name, k):
+            self.name = name
+            w = np.linspace(5000.0 + 100 * k, 6000.0 + 100 * k, 11)
+            self.wavelength = Q(w, 'magnitude') if k % 2 else w
+            self.transmit = list(np.exp(-0.5 * ((w - w.mean()) / 300.0) ** 2))
+            self.Vega_zero_flux = Q(1e-9 * (k + 1), 'magnitude') if k % 2 else Q(1e-9 * (k + 1), 'value')
+            self.AB_zero_flux = 2e-9 * (k + 1)
+
+    lib = {n: F(n, k) for k, n in enumerate(bands.BAND_NAMES_6)}
+    out = bands.from_pyphot(lib)
+    assert list(out) == bands.BAND_NAMES_6
+    for k, n in enumerate(bands.BAND_NAMES_6):
+        b = out[n]
+        assert isinstance(b, bands.Band) and b.wavelength.dtype == float and b.wavelength.shape == (11,)
+        assert b.transmit.shape == (11,) and b.transmit.max() == 1.0
+        want = 1e-9 * (k + 1) if '2MASS' in n else 2e-9 * (k + 1)
+        assert b.zero_flux == want
+    three = bands.from_pyphot(lib, bands.BAND_NAMES_3)
+    assert list(three) == bands.BAND_NAMES_3
+    # the adapted band integrates like any other: a flat spectrum has mean flux 1
+    wave = np.arange(4000.0, 8000.0, 1.0)
+    assert abs(out['SDSS_r'].mean_flux(wave, np.ones_like(wave)) - 1.0) < 1e-12
