@@ -59,7 +59,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // MAXT = the workgroup size the variant is compiled for and launched with: 256 (three workgroups per CU, capped at
 //        168 VGPRs) or 512 (one per CU; with SH: two per CU, capped at 128 VGPRs).  U is the pixels per lane and trip:
 //        always 2, the two pixels of one table element (below).
-// GM = the walker's model vector lives in global memory (spectra longer than ~19k pixels) instead of LDS.
+// GM = the walker's model vector lives in global memory (spectra longer than ~17k pixels) instead of LDS.
 // SH = 512-thread variant that shares its CU with a second workgroup (MSX_BLOCK_512_SHARED).
 // PF = while the recipe waves work, the idle waves copy the walker-independent pixel vectors (u, data flux) into
 //      LDS; phase A and the chi^2 pass then read them from LDS, which takes them off the CU's L2 port -- the
@@ -90,6 +90,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // segment like any argument) is available.  They duplicate P.iso_t, ... and pack niso|nt<<16, ng|mode<<8|fast<<16.
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
+    __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
     const int64_t wk = blockIdx.x;
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
@@ -260,6 +261,8 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
     double q[3];
     unsigned long long kmin = ~0ull, kmax = 0ull;
+    double vmin = INFINITY, vmax = -INFINITY;  // value range of the model vector; NaNs are flagged apart
+    bool seen_nan = false;
     constexpr int SUB = vk / U;  // elements per lane and outer trip: 2 (256 threads) or 1
     for (int e0 = 0; e0 < ne; e0 += B * SUB) {
 #pragma unroll
@@ -310,15 +313,15 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             if (ok[u]) {
                 const double m = mm[u];
                 if (!(GM && STAGE == 2)) model[pp[u]] = m;  // (GM stage 2: the scratch row IS the model vector)
-                const double f = ff[u] / m;  // frac before the median scale, mft6.py:194
+                const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
                 const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
                 const int slot = sub * U + u;  // static: sub and u are unrolled
 #pragma unroll
                 for (int k = 0; k < vk; ++k)
                     if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2_; }
-                const unsigned long long key = key_of(m);
-                kmin = key < kmin ? key : kmin;
-                kmax = key > kmax ? key : kmax;
+                vmin = fmin(vmin, m);
+                vmax = fmax(vmax, m);
+                seen_nan = seen_nan || (m != m);
                 if (early) atomicAdd(&S.hist[logbin(m)], 1u);
             }
         }
@@ -330,23 +333,31 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // cycles before the last wave: it computes the terms in that wait.  (Other modes: inside block_median.)
     if (STAGE != 2 && early && wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
     {
-#pragma unroll
-        for (int k = 0; k < vk; ++k) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double r = wave_sum(qa[k][i]);
-                if (lane == 0) S.q[i][virt_wave(k)] = r;
-            }
-        }
-        const unsigned long long a = wave_min_u64(kmin), b = wave_max_u64(kmax);
-        if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
-        __syncthreads();
+        // the three fit sums: one partial per lane to LDS, one wave per quantity finishes (wave_ops.h); value range:
+        // order-preserving keys, a NaN anywhere counts as above +inf
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            double r = 0.0;
-            for (int x = 0; x < kMaxWaves; ++x) r += S.q[i][x];
-            q[i] = r;
+            double a[vk];
+#pragma unroll
+            for (int k = 0; k < vk; ++k) a[k] = qa[k][i];
+            red[i][wave][lane] = lane_partial<vk>(a);
         }
+        const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
+        const bool wave_nan = __ballot(seen_nan) != 0ull;
+        if (lane == 0) {
+            // (a wave whose pixels were all beyond the spectrum's end reports the empty range)
+            // (fmin / fmax do not order -0 and +0: a zero bound stands for both)
+            S.kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
+            S.kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
+        }
+        __syncthreads();
+        if (wave < 3) {
+            const double r = reduce_published<MAXT>(&red[wave][0][0], lane);
+            if (lane == 0) S.q[0][wave] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) q[i] = S.q[0][i];
         kmin = S.kmin[0]; kmax = S.kmax[0];
         for (int x = 1; x < nw; ++x) {
             kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
@@ -380,8 +391,9 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         enum { VK = kMaxWaves / (MAXT / kWave) };  // (a local class cannot have static data members)
         const double *pix_u, *pix_flux, *pix_ivar;
         double c0, c1, c2;
-        double acc[VK];  // one per virtual wave this wave plays (see phase A): rows k, k + VK, ... of the pass
+        double acc[VK];  // one per slot this lane holds (see phase A and pass_pixel)
         bool on;
+        double *red0;    // [MAXT] LDS: the lanes' partials of the chi^2 sum
         // u and flux by pixel: natural order in global memory; PF keeps them in LDS in the tables' pair layout
         // (element {p, p + 256}: double index 2 * ((p >> 9) * 256 + (p & 255)) + ((p >> 8) & 1))
         static __device__ __forceinline__ int at(int p) {
@@ -396,24 +408,20 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double poly = fma(fma(c2, u[k], c1), u[k], c0);
-                const double r = xv[k] - f[k] / poly;  // (model - data/P); mft6.py:196,120 up to scale^2
+                const double r = xv[k] - fast_div(f[k], poly);  // (model - data/P); mft6.py:196,120 up to scale^2
                 acc[k & (VK - 1)] += ok[k] ? (r * r) * e[k] : 0.0;
             }
         }
-        __device__ __forceinline__ void flush(BlockScratch &S) {
+        __device__ __forceinline__ void flush(BlockScratch &) {  // one partial per lane; wave 0 finishes at the very end
             if (!on) return;
-#pragma unroll
-            for (int k = 0; k < VK; ++k) {
-                const double r = wave_sum(acc[k]);
-                if ((threadIdx.x & 63) == 0) S.chi[k * (MAXT / kWave) + (threadIdx.x >> 6)] = r;
-            }
+            red0[threadIdx.x] = lane_partial<VK>(acc);
         }
     };
     ChiElem chi_elem{PF ? reinterpret_cast<const double *>(lds_u2) : P.pix_u,
                      PF ? reinterpret_cast<const double *>(lds_f2) : P.pix_flux, P.pix_ivar,
                      P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
-                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused};
+                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused, &red[0][0][0]};
     bool chi_done = false;
     double med_model = 0.0;
     bool solved = false;
@@ -426,7 +434,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             __syncthreads();
         }
     }
-    if (!solved) med_model = block_median(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
+    if (!solved) med_model = block_median<MAXT>(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
     if (fused && !chi_done) {  // degenerate vectors (all equal): the median took no pass, do it here
         for (int base = 0; base < npix; base += 4 * B) {
             int pp[4];
@@ -434,7 +442,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int p = base + u * B + tid;
+                const int p = pass_pixel<MAXT>(base, u, tid);
                 ok[u] = p < npix;
                 pp[u] = ok[u] ? p : npix - 1;
                 xv[u] = model[pp[u]];
@@ -465,47 +473,43 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
 #pragma unroll
     for (int k = 0; k < vk; ++k) chia[k] = 0.0;
     unsigned long long dmin = ~0ull, dmax = 0ull;
-    for (int p = tid, row = 0; p < npix && !fused; p += B, ++row) {
-        const double ms = model[p] * scale;
-        double dn;
-        if (opt_step) {
-            dn = dflux[p];
-        } else {
-            const double u = P.pix_u[p];
-            const double poly = fma(fma(coef[2], u, coef[1]), u, coef[0]);
-            dn = dflux[p] / poly;  // mft6.py:196
-        }
-        const double r = ms - dn;
-        const double t = (r * r) * P.pix_ivar[p];  // mft6.py:120
-        const int slot = row & (vk - 1);
+    for (int base = 0; base < npix && !fused; base += 4 * B) {
 #pragma unroll
-        for (int k = 0; k < vk; ++k)
-            if (slot == k) chia[k] += t;
-        if (opt_init) {
-            P.opt_flux[wk * npix + p] = dn;
-            model[p] = dn;  // the model value is dead now; reuse the LDS vector for median(data')
-            const unsigned long long key = key_of(dn);
-            dmin = key < dmin ? key : dmin;
-            dmax = key > dmax ? key : dmax;
+        for (int u = 0; u < 4; ++u) {
+            const int p = pass_pixel<MAXT>(base, u, tid);
+            if (p >= npix) continue;
+            const double ms = model[p] * scale;
+            double dn;
+            if (opt_step) {
+                dn = dflux[p];
+            } else {
+                const double uu_ = P.pix_u[p];
+                const double poly = fma(fma(coef[2], uu_, coef[1]), uu_, coef[0]);
+                dn = fast_div(dflux[p], poly);  // mft6.py:196
+            }
+            const double r = ms - dn;
+            chia[u & (vk - 1)] += (r * r) * P.pix_ivar[p];  // mft6.py:120
+            if (opt_init) {
+                P.opt_flux[wk * npix + p] = dn;
+                model[p] = dn;  // the model value is dead now; reuse the LDS vector for median(data')
+                const unsigned long long key = key_of(dn);
+                dmin = key < dmin ? key : dmin;
+                dmax = key > dmax ? key : dmax;
+            }
         }
     }
     MSX_STAMP(P, wk, 6);
-    if (!fused) {
-#pragma unroll
-        for (int k = 0; k < vk; ++k) {
-            const double r = wave_sum(chia[k]);
-            if (lane == 0) S.chi[k * nw + wave] = r;
-        }
-    }
+    if (!fused) red[0][wave][lane] = lane_partial<vk>(chia);
     if (opt_init) {
         const unsigned long long a = wave_min_u64(dmin), b = wave_max_u64(dmax);
         if (lane == 0) { S.kmin[wave] = a; S.kmax[wave] = b; }
         for (int i = tid; i < kBins; i += B) S.hist[i] = 0;
     }
-    if (!fused) __syncthreads();  // (fused: S.chi was published before the median's first barrier)
+    if (!fused) __syncthreads();  // (fused: the partials were published before the median's barrier)
     MSX_STAMP(P, wk, 7);
+    // the chi^2 sum: wave 0 (whose lane 0 finishes the walker) combines the lanes' partials
     double tot = 0.0;
-    for (int x = 0; x < kMaxWaves; ++x) tot += S.chi[x];
+    if (wave == 0) tot = reduce_published<MAXT>(&red[0][0][0], lane);
     if (fused) tot = tot * (scale * scale);
     if (opt_init) {
         dmin = S.kmin[0]; dmax = S.kmax[0];
@@ -516,7 +520,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         const bool bad = dmax > key_of(INFINITY) || dmin < key_of(-INFINITY);
         NoElem no_elem;
         bool unused = false;
-        const double md = bad ? NAN : block_median(model, npix, dmin, dmax, S, NoSide(), no_elem, &unused);  // np.median(flux), :1011
+        const double md = bad ? NAN : block_median<MAXT>(model, npix, dmin, dmax, S, NoSide(), no_elem, &unused);  // np.median(flux), :1011
         if (tid == 0) P.opt_med[wk] = md;
     }
     if (tid == 0) {

@@ -131,12 +131,13 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <class Side, class Elem>
+template <int BT, class Side, class Elem>
 __device__ __forceinline__ double block_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
                                BlockScratch &S, Side side, Elem &elem, bool *elem_done) {
     bool side_done = false;  // `side` runs exactly once, preferably in the stage that keeps only wave 0 busy
     *elem_done = false;
-    const int tid = threadIdx.x, B = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = B >> 6;
+    constexpr int B = BT, nw = BT >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // k1 = lower middle rank (0-based); for even npix the median averages ranks k1 and k1+1.
     const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
     const bool need_two = (npix & 1) == 0;
@@ -156,7 +157,7 @@ __device__ __forceinline__ double block_median(const double *model, int npix, un
                 bool ok[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int p = base + u * B + tid;
+                    const int p = pass_pixel<BT>(base, u, tid);
                     ok[u] = p < npix;
                     pp[u] = ok[u] ? p : npix - 1;
                     xv[u] = model[pp[u]];
@@ -356,13 +357,14 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
     MED_STAMP(2);
     // ---- one pass: chi^2 terms + candidates of the median's bin + smallest key of the later bins -----------
     unsigned long long above = ~0ull;
+    double above_v = INFINITY;
     for (int base = 0; base < npix; base += 4 * B) {
         int pp[4];
         double xv[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int p = base + u * B + tid;
+            const int p = pass_pixel<BT>(base, u, tid);
             ok[u] = p < npix;
             pp[u] = ok[u] ? p : npix - 1;
             xv[u] = model[pp[u]];
@@ -370,14 +372,15 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
         elem.process4(pp, xv, ok);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            // (all values are positive here: the smallest VALUE of the later bins is their smallest key; keys are
+            // only formed for the handful of candidates)
             const unsigned int lx = (logbin(xv[u]) - a) & (unsigned int)(kLogBins - 1);
-            const unsigned long long key = key_of(xv[u]);
-            if (ok[u] && lx == lsel) S.cand[atomicAdd(&S.cand_n, 1u)] = key;
-            else if (ok[u] && lx > lsel && key < above) above = key;
+            if (ok[u] && lx == lsel) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
+            else if (ok[u] && lx > lsel) above_v = fmin(above_v, xv[u]);
         }
     }
     elem.flush(S);
-    above = wave_min_u64(above);
+    above = wave_min_u64(above_v == INFINITY ? ~0ull : key_of(above_v));
     if (lane == 0) S.above[wave] = above;
     __syncthreads();
     MED_STAMP(3);

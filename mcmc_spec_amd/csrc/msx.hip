@@ -572,7 +572,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     if (p->win_j0 < 0 || p->win_n < 1 || p->win_j0 + p->win_n > c->nwl)
         return fail(c, MSX_ERR_RANGE, "composite window is outside the staged grid");
     const int64_t need_lds = (int64_t)sizeof(double) * p->npix;
-    const bool model_in_global = need_lds > 150 * 1024;  // > 19,200 pixels: the GM kernel variants
+    const bool model_in_global = need_lds > 134 * 1024;  // > 17,152 pixels (160 KiB - ~25 KiB of static LDS): the GM variants
     for (int64_t i = 0; i < p->npix; ++i)
         if (p->pix_lo[i] < 0 || p->pix_lo[i] + 1 >= c->nwl)
             return fail(c, MSX_ERR_RANGE, "A value in x_new is outside the interpolation range (data pixel vs model grid)");

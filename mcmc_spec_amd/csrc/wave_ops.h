@@ -79,6 +79,71 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     const unsigned long long ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
 }
+__device__ __forceinline__ double wave_min_f64(double v) {  // fmin / fmax: a NaN operand is ignored (callers flag NaNs apart)
+    v = fmin(v, dpp_f64<kDppQuadSwap1>(v));
+    v = fmin(v, dpp_f64<kDppQuadSwap2>(v));
+    v = fmin(v, dpp_f64<kDppRowRor4>(v));
+    v = fmin(v, dpp_f64<kDppRowRor8>(v));
+    return fmin(fmin(lane_f64(v, 0), lane_f64(v, 16)), fmin(lane_f64(v, 32), lane_f64(v, 48)));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64<kDppQuadSwap1>(v));
+    v = fmax(v, dpp_f64<kDppQuadSwap2>(v));
+    v = fmax(v, dpp_f64<kDppRowRor4>(v));
+    v = fmax(v, dpp_f64<kDppRowRor8>(v));
+    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
+}
+
+// a / b for NORMAL b (model fluxes, continuum polynomials): v_rcp_f64, two Newton steps, one correction of the
+// quotient -- the compiler's own division sequence without its v_div_scale / v_div_fmas / v_div_fixup wrapping
+// (denormal / overflow scaling, special values), four instructions shorter.  b = 0 gives NaN where IEEE gives
+// +-inf: either way the walker's sums stop being finite and its log-probability ends as -inf.
+__device__ __forceinline__ double fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// ---- the canonical sum over pixels (logprob_kernel.h, phase A) --------------------------------------------------
+// Pixel p belongs to slot p mod 1024 = 64 v + l (virtual wave v, lane l); a slot adds its pixels in ascending order
+// in one lane's register.  The 1024 slot sums A[v][l] are combined as
+//     TREE_l ( sum_{r = 0..3} ( (A[r][l] + A[r+4][l]) + (A[r+8][l] + A[r+12][l]) ) )
+// (sum over r serial, TREE = wave_sum's DPP tree).  With 256 threads wave w's lanes hold A[w + 4k][l], k = 0..3: the
+// bracket is a lane-local sum; with 512 threads waves r and r + 4 each hold one of its halves.  Every lane publishes
+// ONE partial per quantity to LDS (red[wave][lane]) and one wave finishes: one DPP tree per quantity and walker
+// instead of one per virtual wave.
+template <int VK>
+__device__ __forceinline__ double lane_partial(const double (&a)[VK]) {
+    static_assert(VK == 2 || VK == 4, "256 or 512 threads");
+    if (VK == 4) return (a[0] + a[1]) + (a[2] + a[3]);
+    return a[0] + a[1];
+}
+template <int BT>
+__device__ __forceinline__ double reduce_published(const double *red /* [BT / 64][64] */, int lane) {
+    double c;
+    if (BT == 256) {
+        c = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+    } else {
+        const double c0 = red[lane] + red[256 + lane], c1 = red[64 + lane] + red[320 + lane];
+        const double c2 = red[128 + lane] + red[384 + lane], c3 = red[192 + lane] + red[448 + lane];
+        c = ((c0 + c1) + c2) + c3;
+    }
+    return wave_sum(c);
+}
+// The four pixels a lane takes per trip of a PASS over the model vector (a trip = 4 BT pixels from `base`), and the
+// slot accumulator each belongs to: 256 threads -- base + 256 u + tid, accumulator u; 512 threads -- the two pixels
+// of elements tid and tid + 512 of the trip (pixel pairs 256 apart, like phase A), accumulator u & 1.
+template <int BT>
+__device__ __forceinline__ int pass_pixel(int base, int u, int tid) {
+    if (BT == 256) return base + u * 256 + tid;
+    const int e = (base >> 1) + (u >> 1) * 512 + tid;
+    return (((e >> 8) << 9) | (e & 255)) + (u & 1) * 256;
+}
+
 // inclusive prefix sum over the 64 lanes: DPP row_shr steps inside each row of 16, then the three row
 // carries through readlane
 __device__ __forceinline__ unsigned int wave_scan_u32(unsigned int v) {

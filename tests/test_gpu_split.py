@@ -129,7 +129,7 @@ def test_split_full_size_bits(npix, phot, n):
 
 
 def test_split_spectrum_longer_than_lds():
-    """> 19,200 pixels: the model vector never fits LDS; stage 4 reads it straight from the scratch."""
+    """> 17,152 pixels: the model vector does not fit LDS; stage 4 reads it straight from the scratch."""
     from mcmc_spec_amd import synth
     c = golden_case('B')
     rng = np.random.default_rng(3)

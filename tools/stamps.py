@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--walkers', type=int, default=256)
     ap.add_argument('--block', type=int, default=0)
     ap.add_argument('--npix', type=int, default=4096)
+    ap.add_argument('--av0', action='store_true', help='all walkers at A_V = 0: no reddening, the blend loads R only')
     ap.add_argument('--path', default='fused', help='fused | split (split: the stamps are those of the LAST kernel, stage 2)')
     args = ap.parse_args()
     import torch
@@ -29,7 +30,10 @@ def main():
     W = build_workload(eng, args.npix, False)
     dev = torch.device('cuda', 0)
     n = args.walkers
-    th = torch.from_numpy(synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+    thn = synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])
+    if args.av0:
+        thn[:, 2] = 0.0
+    th = torch.from_numpy(thn).to(dev)
     lp = torch.empty(n, dtype=torch.float64, device=dev)
     st = torch.empty(n, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
