@@ -39,7 +39,7 @@ struct DevProblem {
     const float2 *h2;      // [nt*ng][npair]  H = flux[lo+1] t
     const double2 *kl2;    // [npair]         CCM89 k[lo]
     const float2 *dk2;     // [npair]         k[lo+1] - k[lo]
-    const double2 *f2, *u2;  // [npair]       data flux, mapped wavelength u (phase A's copies of pix_flux, pix_u)
+    const double2 *f2, *u2, *iv2;  // [npair] data flux, mapped wavelength u, 1/err^2 (element copies of pix_flux, pix_u, pix_ivar)
     int64_t npair;
     const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
     int64_t npix;

@@ -61,9 +61,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //        always 2, the two pixels of one table element (below).
 // GM = the walker's model vector lives in global memory (spectra longer than ~17k pixels) instead of LDS.
 // SH = 512-thread variant that shares its CU with a second workgroup (MSX_BLOCK_512_SHARED).
-// PF = while the recipe waves work, the idle waves copy the walker-independent pixel vectors (u, data flux) into
-//      LDS; phase A and the chi^2 pass then read them from LDS, which takes them off the CU's L2 port -- the
-//      resource phase A is bound by (one workgroup per CU only: 3 npix doubles of LDS).
+// PF = phase A leaves the walker-independent pixel vectors it loads anyway (u, data flux) in LDS, in the tables'
+//      own layout, and the chi^2 pass reads them there instead of pulling them through the CU's L2 port a second
+//      time (one workgroup per CU only: 3 npix doubles of LDS).
 // STAGE = 0: the fused kernel.  The split path (split_kernels.h) runs the same code in two pieces:
 //   STAGE = 1  phase 0 only: the walker's recipe goes to P.rec[wk] (rejected / failed walkers get their final
 //              value here, like the fused kernel); launched with 256 threads, no dynamic LDS
@@ -157,14 +157,6 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
     // mode (rejected walkers never read them)
     if (STAGE != 2 && fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
-    if (STAGE != 2 && PF && wave > NS) {  // the waves with no recipe work stage pixel statics (published by the barrier below)
-        const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
-#pragma unroll 4
-        for (int e = id; e < ne; e += nthr) {
-            lds_u2[e] = P.u2[e];
-            lds_f2[e] = P.f2[e];
-        }
-    }
     if (STAGE != 2) {
         if (fast) {
             if (wave < NS) recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
@@ -304,9 +296,9 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, redden);
             m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, redden);
         }
-        f2 = (PF && STAGE != 2) ? lds_f2[ec] : P.f2[ec];
-        u2 = (PF && STAGE != 2) ? lds_u2[ec] : P.u2[ec];
-        if (PF && STAGE == 2 && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
+        f2 = P.f2[ec];
+        u2 = P.u2[ec];
+        if (PF && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
         const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -389,22 +381,44 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     const bool fused = !(mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT);
     struct ChiElem {  // holds plain pointers, never a reference to the by-value kernel argument (see DevProblem)
         enum { VK = kMaxWaves / (MAXT / kWave) };  // (a local class cannot have static data members)
-        const double *pix_u, *pix_flux, *pix_ivar;
+        // u, data flux and 1/err^2 by table ELEMENT (two pixels 256 apart): the four pixels of a trip are the
+        // elements (base >> 1) + tid and + MAXT (pass_pixel).  u and flux come from LDS with PF, else from the
+        // tables; 1/err^2 always from its table.  Global loads run one trip ahead of their use.
+        const double2 *u2, *f2, *iv2;
+        int ne;
         double c0, c1, c2;
         double acc[VK];  // one per slot this lane holds (see phase A and pass_pixel)
         bool on;
         double *red0;    // [MAXT] LDS: the lanes' partials of the chi^2 sum
-        // u and flux by pixel: natural order in global memory; PF keeps them in LDS in the tables' pair layout
-        // (element {p, p + 256}: double index 2 * ((p >> 9) * 256 + (p & 255)) + ((p >> 8) & 1))
-        static __device__ __forceinline__ int at(int p) {
-            return PF ? (((((p >> 9) << 8) | (p & 255)) << 1) | ((p >> 8) & 1)) : p;
-        }
-        // four consecutive rows of the pass (row = p / blockDim.x; a trip starts at a multiple of four rows)
-        __device__ __forceinline__ void process4(const int (&pp)[4], const double (&xv)[4], const bool (&ok)[4]) {
+        double2 nu[2], nf[2], nv[2];  // the NEXT trip's values
+        __device__ __forceinline__ void prefetch(int base) {
             if (!on) return;
-            double u[4], f[4], e[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { u[k] = pix_u[at(pp[k])]; f[k] = pix_flux[at(pp[k])]; e[k] = pix_ivar[pp[k]]; }
+            for (int j = 0; j < 2; ++j) {
+                int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
+                e = e < ne ? e : ne - 1;
+                nv[j] = iv2[e];
+                if (!PF) { nu[j] = u2[e]; nf[j] = f2[e]; }
+            }
+        }
+        // the four pixels of one trip (pass_pixel order)
+        __device__ __forceinline__ void process4(int base, const int (&)[4], const double (&xv)[4], const bool (&ok)[4]) {
+            if (!on) return;
+            double2 cu[2], cf[2], cv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                cv[j] = nv[j];
+                if (PF) {
+                    int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
+                    e = e < ne ? e : ne - 1;
+                    cu[j] = u2[e]; cf[j] = f2[e];  // LDS
+                } else {
+                    cu[j] = nu[j]; cf[j] = nf[j];
+                }
+            }
+            prefetch(base + 4 * MAXT);
+            const double u[4] = {cu[0].x, cu[0].y, cu[1].x, cu[1].y}, f[4] = {cf[0].x, cf[0].y, cf[1].x, cf[1].y};
+            const double e[4] = {cv[0].x, cv[0].y, cv[1].x, cv[1].y};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double poly = fma(fma(c2, u[k], c1), u[k], c0);
@@ -417,11 +431,10 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             red0[threadIdx.x] = lane_partial<VK>(acc);
         }
     };
-    ChiElem chi_elem{PF ? reinterpret_cast<const double *>(lds_u2) : P.pix_u,
-                     PF ? reinterpret_cast<const double *>(lds_f2) : P.pix_flux, P.pix_ivar,
+    ChiElem chi_elem{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne,
                      P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
-                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused, &red[0][0][0]};
+                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused, &red[0][0][0], {}, {}, {}};
     bool chi_done = false;
     double med_model = 0.0;
     bool solved = false;
@@ -436,6 +449,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     }
     if (!solved) med_model = block_median<MAXT>(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
     if (fused && !chi_done) {  // degenerate vectors (all equal): the median took no pass, do it here
+        chi_elem.prefetch(0);
         for (int base = 0; base < npix; base += 4 * B) {
             int pp[4];
             double xv[4];
@@ -447,7 +461,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
                 pp[u] = ok[u] ? p : npix - 1;
                 xv[u] = model[pp[u]];
             }
-            chi_elem.process4(pp, xv, ok);
+            chi_elem.process4(base, pp, xv, ok);
         }
         chi_elem.flush(S);
         __syncthreads();

@@ -118,10 +118,12 @@ struct NoSide {
     __device__ __forceinline__ void operator()() const {}
 };
 // Per-element work that can ride along the median's first pass over the vector (it already reads every
-// element): process4() gets four (index, value, valid) triples, flush() publishes the wave partials
+// element): prefetch(0) is called before the pass (the element may start loading what its first trip needs),
+// process4() gets the trip's base and four (index, value, valid) triples, flush() publishes the lanes' partials
 // right before the pass's barrier.
 struct NoElem {
-    __device__ __forceinline__ void process4(const int (&)[4], const double (&)[4], const bool (&)[4]) {}
+    __device__ __forceinline__ void prefetch(int) {}
+    __device__ __forceinline__ void process4(int, const int (&)[4], const double (&)[4], const bool (&)[4]) {}
     __device__ __forceinline__ void flush(BlockScratch &) {}
 };
 
@@ -151,6 +153,7 @@ __device__ __forceinline__ double block_median(const double *model, int npix, un
         bool solved = false;
         MED_STAMP(0);
         if (lin_ok) {
+            elem.prefetch(0);
             for (int base = 0; base < npix; base += 4 * B) {  // 4 elements per trip: loads first, then use
                 int pp[4];
                 double xv[4];
@@ -162,7 +165,7 @@ __device__ __forceinline__ double block_median(const double *model, int npix, un
                     pp[u] = ok[u] ? p : npix - 1;
                     xv[u] = model[pp[u]];
                 }
-                elem.process4(pp, xv, ok);
+                elem.process4(base, pp, xv, ok);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     int bin = (int)((xv[u] - vmin) * scale);
@@ -329,6 +332,7 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
     if ((hmax - hmin) + (hmin & (unsigned int)(per - 1)) >= (unsigned int)kLogBins) return false;  // the cycle would lap itself
     MED_STAMP(0);
     MED_STAMP(1);
+    elem.prefetch(0);  // the pass's first loads travel while the counters are scanned
     // ---- per-wave scan: lane l owns the `per` counters from physical bin (a + per*l) mod kLogBins ----------
     const unsigned int phys = (a + (unsigned int)(per * lane)) & (unsigned int)(kLogBins - 1);
     unsigned int own = 0;
@@ -369,7 +373,7 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
             pp[u] = ok[u] ? p : npix - 1;
             xv[u] = model[pp[u]];
         }
-        elem.process4(pp, xv, ok);
+        elem.process4(base, pp, xv, ok);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // (all values are positive here: the smallest VALUE of the later bins is their smallest key; keys are

@@ -625,7 +625,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     int64_t *d_lo = nullptr;
     if ((rc = dev_alloc_copy(c, &tr, p->pix_lo, p->npix, &d_lo))) return rc;
     const int64_t npair = ((p->npix + 511) / 512) * 256;
-    double2 *d_r2 = nullptr, *d_kl2 = nullptr, *d_f2 = nullptr, *d_u2 = nullptr;
+    double2 *d_r2 = nullptr, *d_kl2 = nullptr, *d_f2 = nullptr, *d_u2 = nullptr, *d_iv2 = nullptr;
     float2 *d_h2 = nullptr, *d_dk2 = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_r2, sizeof(double2) * nn * npair)); tr.push_back(d_r2);
     HIP_TRY(c, hipMalloc((void **)&d_h2, sizeof(float2) * nn * npair)); tr.push_back(d_h2);
@@ -633,13 +633,14 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     HIP_TRY(c, hipMalloc((void **)&d_dk2, sizeof(float2) * npair)); tr.push_back(d_dk2);
     HIP_TRY(c, hipMalloc((void **)&d_f2, sizeof(double2) * npair)); tr.push_back(d_f2);
     HIP_TRY(c, hipMalloc((void **)&d_u2, sizeof(double2) * npair)); tr.push_back(d_u2);
+    HIP_TRY(c, hipMalloc((void **)&d_iv2, sizeof(double2) * npair)); tr.push_back(d_iv2);
     dim3 gg((unsigned)((npair + 255) / 256), (unsigned)nn);
     hipLaunchKernelGGL(gather_rh_kernel, gg, dim3(256), 0, c->stream, c->d_grid, c->nwl, d_lo, P.pix_t, p->npix, npair, d_r2, d_h2);
     HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(gather_statics_kernel, dim3(gg.x), dim3(256), 0, c->stream, c->d_kgrid, d_lo, P.pix_flux, P.pix_u,
-                       p->npix, npair, d_kl2, d_dk2, d_f2, d_u2);
+                       P.pix_ivar, p->npix, npair, d_kl2, d_dk2, d_f2, d_u2, d_iv2);
     HIP_TRY(c, hipGetLastError());
-    P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.npair = npair;
+    P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.iv2 = d_iv2; P.npair = npair;
     // band integrals
     double *d_tab = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_tab, sizeof(double) * std::max<int64_t>(1, nn * nb))); tr.push_back(d_tab);

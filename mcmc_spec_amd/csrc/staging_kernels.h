@@ -58,11 +58,12 @@ __global__ void gather_rh_kernel(const double *__restrict__ grid, int64_t nwl, c
     R[(int64_t)blockIdx.y * npair + e] = make_double2(fma(a1 - a0, t[pa], a0), fma(b1 - b0, t[pb], b0));
     H[(int64_t)blockIdx.y * npair + e] = make_float2((float)(a1 * t[pa]), (float)(b1 * t[pb]));
 }
-// CCM89 k[lo], k[lo+1] - k[lo], and phase A's copies of the data flux and mapped wavelength, per element
+// CCM89 k[lo], k[lo+1] - k[lo], and element copies of the data flux, the mapped wavelength and 1/err^2
 __global__ void gather_statics_kernel(const double *__restrict__ kgrid, const int64_t *__restrict__ lo,
-                                      const double *__restrict__ flux, const double *__restrict__ u, int64_t npix,
-                                      int64_t npair, double2 *__restrict__ kl2, float2 *__restrict__ dk2,
-                                      double2 *__restrict__ f2, double2 *__restrict__ u2) {
+                                      const double *__restrict__ flux, const double *__restrict__ u,
+                                      const double *__restrict__ ivar, int64_t npix, int64_t npair,
+                                      double2 *__restrict__ kl2, float2 *__restrict__ dk2, double2 *__restrict__ f2,
+                                      double2 *__restrict__ u2, double2 *__restrict__ iv2) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= npair) return;
     int64_t pa, pb;
@@ -72,6 +73,7 @@ __global__ void gather_statics_kernel(const double *__restrict__ kgrid, const in
     dk2[e] = make_float2((float)(kgrid[ja + 1] - kgrid[ja]), (float)(kgrid[jb + 1] - kgrid[jb]));
     f2[e] = make_double2(flux[pa], flux[pb]);
     u2[e] = make_double2(u[pa], u[pb]);
+    iv2[e] = make_double2(ivar[pa], ivar[pb]);
 }
 
 // band_tab[node][b] = sum_i w_b[i] * grid[node][i0_b + i];  grid.x = band, grid.y = node

@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--walkers', type=int, default=256)
     ap.add_argument('--block', type=int, default=0)
     ap.add_argument('--npix', type=int, default=4096)
+    ap.add_argument('--mode', default='logpost')
     ap.add_argument('--av0', action='store_true', help='all walkers at A_V = 0: no reddening, the blend loads R only')
     ap.add_argument('--path', default='fused', help='fused | split (split: the stamps are those of the LAST kernel, stage 2)')
     args = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
     s = torch.cuda.current_stream(dev).cuda_stream
     eng.ctx.set_path(_lib.PATH_SPLIT if args.path == 'split' else _lib.PATH_FUSED)
     for _ in range(20):
-        eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), s, _lib.MODE_LOGPOST, args.block)
+        eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), s, {'logpost': _lib.MODE_LOGPOST, 'loglike': _lib.MODE_LOGLIKE}[args.mode], args.block)
     torch.cuda.synchronize()
     out = np.zeros((n, 16), dtype=np.uint64)
     fn = eng.ctx.lib.msx_diag_read_stamps
