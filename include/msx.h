@@ -149,9 +149,15 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
  * never: on MI355X the fused kernel measured faster at every size).  All scratch is sized by
  * msx_stage_problem: no launch allocates or synchronises.  MSX_PATH_SPLIT fails with MSX_ERR_STATE for modes / problems that have no split form
  * (logprior alone, the no-spectrum variant, the optimiser modes, tables beyond the register recipe).                 */
+/* WIDE: two launches for few walkers x long spectra (2..8 segments of 8192 pixels): one workgroup per (walker,
+ * segment) runs recipe + blend + the segment's fit sums / histogram, one workgroup per walker then combines the
+ * segments and runs the median / chi^2 phases -- so that e.g. 128 walkers x 16384 pixels use all 256 CUs.  Same
+ * bits as FUSED (which sums long spectra segment by segment too).  MSX_PATH_AUTO takes it while walkers x segments
+ * <= MSX_WIDE_MAX x #CUs (environment, default 1).                                                              */
 #define MSX_PATH_AUTO 0
 #define MSX_PATH_FUSED 1
 #define MSX_PATH_SPLIT 2
+#define MSX_PATH_WIDE 3
 int msx_set_path(msx_ctx *ctx, int32_t path);
 
 /* ---- f4: the pre-optimiser's chi^2 (fit_spec, mft6.py:856-1137) on the same kernel --------------- */

@@ -68,7 +68,8 @@ struct DevProblem {
     double *opt_med;           // [nchains]
     const int32_t *opt_chain;  // [n] (OPT_STEP launches)
     double *model_scratch;     // [n][npix]: the model vectors of the split path (stages 3 -> 4) and of the GM variants
-    struct WalkerRec *rec;     // [n] split path: what stage 1 (the recipe) leaves for stages 3 and 4
+    struct WalkerRec *rec;     // [n] split / wide path: what the recipe stage leaves for the later ones
+    struct SegPart *segparts;  // [n][segments] wide path: STAGE 3's partials
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;
@@ -116,6 +117,17 @@ struct WalkerDesc {
 };
 
 constexpr int kTileWalkers = 8;     // split path: walkers that share one load of the pair rows
+constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the wide path
+constexpr int kSegBins = 2048;      // (= kLogBins, median.h)
+
+// wide path: what STAGE 3 leaves per (walker, segment) for STAGE 4
+struct alignas(16) SegPart {
+    double q[3];                    // the segment's three fit sums
+    unsigned long long kmin, kmax;  // its value range (order-preserving keys; ~0 / 0 = empty, kmax = ~0: a NaN)
+    unsigned int pad[6];
+    unsigned int hist[kSegBins];    // its share of the median's logarithmic histogram
+};
+static_assert(sizeof(SegPart) == 64 + 4 * kSegBins, "SegPart layout");
 
 // What the recipe leaves behind for stages 3 and 4.
 struct alignas(16) WalkerRec {

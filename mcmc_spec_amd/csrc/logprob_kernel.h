@@ -69,6 +69,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //              value here, like the fused kernel); launched with 256 threads, no dynamic LDS
 //   STAGE = 2  everything after the blend: the model vector comes from P.model_scratch (written by
 //              blend_tiles_kernel), the recipe's scalars from P.rec[wk]
+// and the WIDE path (few walkers, long spectra: one workgroup per walker leaves CUs idle) in two others:
+//   STAGE = 3  one workgroup per (walker, SEGMENT of 8192 pixels): recipe, blend of that segment -> model scratch,
+//              the segment's fit sums / value range / histogram -> P.segparts; segment 0 leaves the recipe's
+//              scalars in P.rec[wk] (and the final value of rejected / failed walkers)
+//   STAGE = 4  one workgroup per walker: model vector scratch -> LDS, the segments' partials combined (the fit
+//              sums serially over the segments, exactly as the fused kernel adds them), then the median / chi^2
+//              phases as ever
 //
 // TABLE LAYOUT.  A CU pulls data from L2 at ~32 B per clock when every lane loads 16 bytes, and no faster per
 // instruction when lanes load less -- so every per-pixel table the blend reads is stored in ELEMENTS of two pixels,
@@ -91,16 +98,21 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
-    const int64_t wk = blockIdx.x;
+    constexpr bool kRecipe = STAGE == 0 || STAGE == 1 || STAGE == 3;  // this stage runs phase 0
+    constexpr bool kBlend = STAGE == 0 || STAGE == 3;                 // ... computes model values from the tables
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
+    const int nsegs = STAGE == 3 ? (ng_mode_fast >> 24) & 0xff : 1;  // STAGE 3: workgroups per walker
+    const int64_t wk = STAGE == 3 ? blockIdx.x / nsegs : blockIdx.x;
+    const int myseg = STAGE == 3 ? (int)(blockIdx.x - wk * nsegs) : 0;
     RecipeRegs RR;
-    if (STAGE != 2 && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, iso_t, iso_g, teff_nodes, logg_nodes, present, niso, nt, ng, threadIdx.x & 63);
+    if (kRecipe && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, iso_t, iso_g, teff_nodes, logg_nodes, present, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
-    if (STAGE == 2 && P.rec[wk].status != MSX_W_OK) return;  // stage 1 wrote this walker's final value (uniform branch)
+    if (!kRecipe && P.rec[wk].status != MSX_W_OK) return;  // an earlier stage wrote this walker's final value (uniform branch)
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
-    const double *__restrict__ model_in = STAGE == 2 ? P.model_scratch + wk * P.npix : nullptr;
+    const double *__restrict__ model_in = (STAGE == 2 || STAGE == 4) ? P.model_scratch + wk * P.npix : nullptr;
+    double *const model_out = STAGE == 3 ? P.model_scratch + wk * P.npix : nullptr;
     const int tid = threadIdx.x;
     constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
     const int lane = tid & 63, wave = tid >> 6;
@@ -151,13 +163,13 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
     const bool early = !GM && fast && !P.no_spectrum &&
                        (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    if (STAGE == 2) {  // the recipe's scalars come from stage 1's record; no phase 0
+    if (!kRecipe) {  // the recipe's scalars come from an earlier stage's record; no phase 0
         if (tid == 0) { D.lp = P.rec[wk].lp; D.chi_extra = P.rec[wk].chi_extra; D.status = MSX_W_OK; }
     }
     // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
     // mode (rejected walkers never read them)
-    if (STAGE != 2 && fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
-    if (STAGE != 2) {
+    if (kRecipe && fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    if (kRecipe) {
         if (fast) {
             if (wave < NS) recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
         } else if (wave == 0) {
@@ -167,15 +179,15 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     }
     __syncthreads();
     int wst = D.status;
-    if (STAGE != 2 && fast) {  // first star that failed decides, like the reference's star-by-star loop
+    if (kRecipe && fast) {  // first star that failed decides, like the reference's star-by-star loop
         wst = D.stat[0];
 #pragma unroll
         for (int k = 1; k < NS; ++k) wst = (wst == MSX_W_OK) ? D.stat[k] : wst;
     }
     if (wst != MSX_W_OK) {
-        if (tid == 0) {
+        if (tid == 0 && myseg == 0) {
             walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
-            if (STAGE == 1) P.rec[wk].status = wst;
+            if (STAGE == 1 || STAGE == 3) P.rec[wk].status = wst;
         }
         return;
     }
@@ -229,13 +241,13 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     float wf[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int64_t off = STAGE == 2 ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
+        const int64_t off = !kBlend ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
         rows_r[c] = P.r2 + off;
         rows_h[c] = P.h2 + off;
-        w[c] = STAGE == 2 ? 0.0 : D.w[c];
+        w[c] = !kBlend ? 0.0 : D.w[c];
         wf[c] = (float)w[c];
     }
-    const double redc = STAGE == 2 ? 0.0 : D.redc;
+    const double redc = !kBlend ? 0.0 : D.redc;
     const bool redden = redc != 0.0;
     // Sums are taken in an order that does not depend on the workgroup size.  Pixel p belongs to SLOT p mod 1024;
     // a slot accumulates its pixels in ascending order in ONE lane's register, the 64 slots of VIRTUAL wave v
@@ -246,28 +258,35 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     //   512 threads: elements tid + 512 j -> pixels (tid >> 8) * 512 + (tid & 255) (+ 256) mod 1024: two slots,
     //                accumulator k = u, virtual wave (wave >> 2) * 8 + 4 u + (wave & 3)
     // so a walker's log-probability has the same bits whatever launch (batch size, shard, rank) evaluates it.
+    // Spectra longer than 8192 pixels are summed SEGMENT by segment (kSegElems elements): each segment's slots are
+    // reduced as above and the segments' sums added serially -- one more level of the same fixed association, and
+    // what lets the wide path give each segment to a workgroup of its own (STAGE 3 / 4).
     constexpr int vk = kMaxWaves / (MAXT / kWave);  // slots per lane: 4 or 2
-    auto virt_wave = [&](int k) { return MAXT == 256 ? 4 * k + wave : (wave >> 2) * 8 + 4 * k + (wave & 3); };
-    double qa[vk][3];
-#pragma unroll
-    for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
     double q[3];
     unsigned long long kmin = ~0ull, kmax = 0ull;
     double vmin = INFINITY, vmax = -INFINITY;  // value range of the model vector; NaNs are flagged apart
     bool seen_nan = false;
     constexpr int SUB = vk / U;  // elements per lane and outer trip: 2 (256 threads) or 1
-    for (int e0 = 0; e0 < ne; e0 += B * SUB) {
+    const int nseg_all = (ne + kSegElems - 1) / kSegElems;
+    const int seg_lo = STAGE == 3 ? myseg : 0, seg_hi = STAGE == 3 ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
+    double qrun = 0.0;  // waves 0..2: their fit sum over the segments so far
+    for (int seg = seg_lo; seg < seg_hi; ++seg) {
+      double qa[vk][3];
+#pragma unroll
+      for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
+      const int e_end = (seg + 1) * kSegElems < ne ? (seg + 1) * kSegElems : ne;
+      for (int e0 = seg * kSegElems; e0 < e_end; e0 += B * SUB) {
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
         const int e = e0 + sub * B + tid;
-        const bool live = e < ne;
-        const int ec = live ? e : ne - 1;
+        const bool live = e < e_end;
+        const int ec = live ? e : e_end - 1;
         const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
         const bool ok[U] = {live && pa < npix, live && pb < npix};
         const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
         double2 kl2 = make_double2(0.0, 0.0), f2, u2, m2;
         float2 dk2 = make_float2(0.f, 0.f);
-        if (STAGE == 2) {
+        if (!kBlend) {
             m2 = make_double2(model_in[pp[0]], model_in[pp[1]]);  // blend_tiles_kernel's output for this walker
         } else {
             // the model values of the two pixels (blend.h; the split path's blend kernel runs the same chain).
@@ -304,7 +323,8 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         for (int u = 0; u < U; ++u) {
             if (ok[u]) {
                 const double m = mm[u];
-                if (!(GM && STAGE == 2)) model[pp[u]] = m;  // (GM stage 2: the scratch row IS the model vector)
+                if (STAGE == 3) model_out[pp[u]] = m;                // the wide path's scratch (read back by STAGE 4)
+                else if (!(GM && STAGE == 2)) model[pp[u]] = m;      // (GM stage 2: the scratch row IS the model vector)
                 const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
                 const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
                 const int slot = sub * U + u;  // static: sub and u are unrolled
@@ -318,22 +338,46 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             }
         }
       }
+      }
+      // this segment's three fit sums: one partial per lane to LDS, one wave per quantity finishes (wave_ops.h)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+          double a[vk];
+#pragma unroll
+          for (int k = 0; k < vk; ++k) a[k] = qa[k][i];
+          red[i][wave][lane] = lane_partial<vk>(a);
+      }
+      __syncthreads();
+      if (wave < 3) qrun += reduce_published<MAXT>(&red[wave][0][0], lane);
+      if (seg + 1 < seg_hi) __syncthreads();  // the next segment rewrites red
     }
     MSX_STAMP(P, wk, 2);
     // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
-    // bound by the CU's L2 port and wave 0's loads are served first, so wave 0 leaves the pixel loop thousands of
-    // cycles before the last wave: it computes the terms in that wait.  (Other modes: inside block_median.)
-    if (STAGE != 2 && early && wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
-    {
-        // the three fit sums: one partial per lane to LDS, one wave per quantity finishes (wave_ops.h); value range:
-        // order-preserving keys, a NaN anywhere counts as above +inf
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double a[vk];
-#pragma unroll
-            for (int k = 0; k < vk; ++k) a[k] = qa[k][i];
-            red[i][wave][lane] = lane_partial<vk>(a);
+    // bound by the CU's memory pipeline and wave 0's loads are served first, so wave 0 leaves the pixel loop
+    // thousands of cycles before the last wave.  (Other modes: inside block_median.)
+    if (kRecipe && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+    if (STAGE == 4) {
+        // the model vector from the scratch into LDS (the median's passes want it there) ...
+        if ((npix & 1) == 0) {
+            const double2 *src = reinterpret_cast<const double2 *>(model_in);
+            double2 *dst = reinterpret_cast<double2 *>(model);
+            for (int i = tid; i < (npix >> 1); i += B) dst[i] = src[i];
+        } else {
+            for (int i = tid; i < npix; i += B) model[i] = model_in[i];
         }
+        // ... and the segments' partials: histogram counts add up, the value range is the union
+        const SegPart *sp = P.segparts + wk * nseg_all;
+        for (int b = tid; b < kLogBins; b += B) {
+            unsigned int cnt = 0;
+            for (int g = 0; g < nseg_all; ++g) cnt += sp[g].hist[b];
+            S.hist[b] = cnt;
+        }
+        if (wave < 3) {  // the fit sums: serially over the segments, like the fused kernel's qrun
+            for (int g = 0; g < nseg_all; ++g) qrun += sp[g].q[wave];
+        }
+    }
+    {
+        // value range: order-preserving keys, a NaN anywhere counts as above +inf
         const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
         const bool wave_nan = __ballot(seen_nan) != 0ull;
         if (lane == 0) {
@@ -341,20 +385,32 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             // (fmin / fmax do not order -0 and +0: a zero bound stands for both)
             S.kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
             S.kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
+            if (wave < 3) S.q[0][wave] = qrun;
         }
-        __syncthreads();
-        if (wave < 3) {
-            const double r = reduce_published<MAXT>(&red[wave][0][0], lane);
-            if (lane == 0) S.q[0][wave] = r;
+        if (STAGE == 4 && tid < nseg_all) {  // (the segments' ranges ride in the slots of waves that have none of their own)
+            S.kmin[nw + tid] = P.segparts[wk * nseg_all + tid].kmin;
+            S.kmax[nw + tid] = P.segparts[wk * nseg_all + tid].kmax;
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) q[i] = S.q[0][i];
         kmin = S.kmin[0]; kmax = S.kmax[0];
-        for (int x = 1; x < nw; ++x) {
+        const int nr = STAGE == 4 ? nw + nseg_all : nw;
+        for (int x = 1; x < nr; ++x) {
             kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
             kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
         }
+    }
+    if (STAGE == 3) {
+        // the segment's partials, and from segment 0 the recipe's scalars, for STAGE 4
+        SegPart *sp = P.segparts + wk * nseg_all + myseg;
+        for (int b = tid; b < kLogBins; b += B) sp->hist[b] = S.hist[b];
+        if (tid == 0) { sp->q[0] = q[0]; sp->q[1] = q[1]; sp->q[2] = q[2]; sp->kmin = kmin; sp->kmax = kmax; }
+        if (myseg == 0 && tid == kWave) {
+            WalkerRec *R = P.rec + wk;
+            R->lp = D.lp; R->chi_extra = D.chi_extra; R->status = MSX_W_OK;
+        }
+        return;
     }
     MSX_STAMP(P, wk, 3);
     // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
@@ -371,7 +427,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
     const double *th_w = th_row;
     auto side = [&]() __attribute__((always_inline)) {
-        if (STAGE != 2 && fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
+        if (kRecipe && fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
     };
     // The spectrum chi^2 factorises: with P(u) = c0 + c1 u + c2 u^2 the raw fit of data/model (from the q
     // sums), the fit of data/(scale*model) is P/scale, data' = scale*data/P and
@@ -385,12 +441,13 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         // elements (base >> 1) + tid and + MAXT (pass_pixel).  u and flux come from LDS with PF, else from the
         // tables; 1/err^2 always from its table.  Global loads run one trip ahead of their use.
         const double2 *u2, *f2, *iv2;
-        int ne;
+        int ne, npix;
         double c0, c1, c2;
         double acc[VK];  // one per slot this lane holds (see phase A and pass_pixel)
         bool on;
         double *red0;    // [MAXT] LDS: the lanes' partials of the chi^2 sum
         double2 nu[2], nf[2], nv[2];  // the NEXT trip's values
+        double tot_run;               // wave 0: the chi^2 sum over the segments finished so far (see phase A)
         __device__ __forceinline__ void prefetch(int base) {
             if (!on) return;
 #pragma unroll
@@ -425,16 +482,27 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
                 const double r = xv[k] - fast_div(f[k], poly);  // (model - data/P); mft6.py:196,120 up to scale^2
                 acc[k & (VK - 1)] += ok[k] ? (r * r) * e[k] : 0.0;
             }
+            // end of a segment of the canonical sum (8192 pixels), more pixels to come: fold it in.  (Uniform: every
+            // thread of the workgroup walks the same trips.)
+            const int next = base + 4 * MAXT;
+            if ((next & (2 * kSegElems - 1)) == 0 && next < npix) {
+                red0[threadIdx.x] = lane_partial<VK>(acc);
+#pragma unroll
+                for (int k = 0; k < VK; ++k) acc[k] = 0.0;
+                __syncthreads();
+                if ((threadIdx.x >> 6) == 0) tot_run += reduce_published<MAXT>(red0, (int)threadIdx.x & 63);
+                __syncthreads();
+            }
         }
         __device__ __forceinline__ void flush(BlockScratch &) {  // one partial per lane; wave 0 finishes at the very end
             if (!on) return;
             red0[threadIdx.x] = lane_partial<VK>(acc);
         }
     };
-    ChiElem chi_elem{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne,
+    ChiElem chi_elem{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix,
                      P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
                      P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
-                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused, &red[0][0][0], {}, {}, {}};
+                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused, &red[0][0][0], {}, {}, {}, 0.0};
     bool chi_done = false;
     double med_model = 0.0;
     bool solved = false;
@@ -524,7 +592,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // the chi^2 sum: wave 0 (whose lane 0 finishes the walker) combines the lanes' partials
     double tot = 0.0;
     if (wave == 0) tot = reduce_published<MAXT>(&red[0][0][0], lane);
-    if (fused) tot = tot * (scale * scale);
+    if (fused) tot = (chi_elem.tot_run + tot) * (scale * scale);
     if (opt_init) {
         dmin = S.kmin[0]; dmax = S.kmax[0];
         for (int x = 1; x < nw; ++x) {

@@ -104,13 +104,16 @@ struct msx_ctx {
     WalkerRec *d_rec = nullptr;
     int32_t *d_perm = nullptr, *d_hdr = nullptr, *d_tmp = nullptr;
     TileHdr *d_tiles = nullptr;
+    SegPart *d_segparts = nullptr;  // wide path: [split_batch][segments]
+    int nseg = 1;                   // segments of the staged spectrum (8192 pixels each)
     int64_t split_batch = 0;        // walkers per sub-batch (0 = split path unavailable for this problem)
     // MSX_PATH_AUTO takes the split path at / above these sizes.  Measured: the fused kernel is bound by
     // VALU issue, not by the L2 port, once a few workgroups share a CU, so sharing row loads buys nothing and the
     // split form's extra round trip through the model scratch costs; the defaults therefore never pick it.
     // MSX_SPLIT_MIN / MSX_SPLIT_MIN_NPIX (environment, read at msx_stage_problem) lower them.
     int64_t split_min_walkers = INT64_MAX, split_min_npix = INT64_MAX;
-    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _SPLIT (msx_set_path)
+    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _SPLIT / _WIDE (msx_set_path)
+    int64_t wide_max_blocks_per_cu = 1;  // MSX_PATH_AUTO takes the wide path while walkers x segments <= this x #CUs (MSX_WIDE_MAX)
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
 };
@@ -188,10 +191,10 @@ void free_problem(msx_ctx *c) {
     if (c->d_opt_med) (void)hipFree(c->d_opt_med);
     c->d_opt_flux = c->d_opt_med = nullptr;
     c->opt_chains = 0;
-    void *sp[] = {c->d_rec, c->d_perm, c->d_hdr, c->d_tmp, c->d_tiles, c->d_model_scratch};
+    void *sp[] = {c->d_rec, c->d_perm, c->d_hdr, c->d_tmp, c->d_tiles, c->d_model_scratch, c->d_segparts};
     for (void *p : sp)
         if (p) (void)hipFree(p);
-    c->d_rec = nullptr; c->d_perm = c->d_hdr = c->d_tmp = nullptr; c->d_tiles = nullptr;
+    c->d_rec = nullptr; c->d_perm = c->d_hdr = c->d_tmp = nullptr; c->d_tiles = nullptr; c->d_segparts = nullptr;
     c->d_model_scratch = nullptr; c->cap_model_scratch = 0; c->split_batch = 0;
 }
 
@@ -288,7 +291,7 @@ DevProblem problem_at(const DevProblem &P0, int64_t off, int mode, int ndim) {
 //   STAGE 1 the recipe alone: 256 threads, no dynamic LDS.
 template <int STAGE>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
-    const dim3 g((unsigned)A.n);
+    const dim3 g((unsigned)(STAGE == 3 ? A.n * c->nseg : A.n));
     const size_t lds = sizeof(double) * (size_t)P.npix;
 #define MSX_LEAD_ARGS A.theta, P.iso_t, P.iso_g, P.teff_nodes, P.logg_nodes, P.present, A.niso_nt, A.ng_mode_fast
 #define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                      \
@@ -298,6 +301,10 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
     if constexpr (STAGE == 1) {
         if (P.nspec == 2) MSX_GO(2, 2, 256, false, false, false, 0); else MSX_GO(3, 2, 256, false, false, false, 0);
+    } else if constexpr (STAGE == 3) {  // (the grid is walkers x segments; the model goes to the scratch: no dynamic LDS)
+        if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, 0); else MSX_GO(3, 2, 512, false, false, false, 0);
+    } else if constexpr (STAGE == 4) {
+        if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
     } else if (c->model_in_global) {
         // spectra longer than the LDS: the model vector lives in the global scratch (STAGE 0 writes it there itself)
         if (P.nspec == 2) MSX_GO(2, 2, 512, true, false, false, 0); else MSX_GO(3, 2, 512, true, false, false, 0);
@@ -350,6 +357,8 @@ int raise_dynamic_lds_limits(msx_ctx *c) {
     if (c->device < 0 || c->device >= 16 || done[c->device]) return MSX_OK;
     HIP_TRY(c, raise_stage<0>());
     HIP_TRY(c, raise_stage<2>());
+    HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 4>));
+    HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 4>));
     HIP_TRY(c, raise_one(broaden_conv_kernel));
     done[c->device] = true;
     return MSX_OK;
@@ -681,11 +690,15 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         HIP_TRY(c, hipMalloc((void **)&c->d_tmp, sizeof(int32_t) * 2 * sb));
         HIP_TRY(c, hipMalloc((void **)&c->d_tiles, sizeof(TileHdr) * sb));
         HIP_TRY(c, hipMalloc((void **)&c->d_hdr, 64));
+        c->nseg = (int)((npair + kSegElems - 1) / kSegElems);
+        HIP_TRY(c, hipMalloc((void **)&c->d_segparts, sizeof(SegPart) * sb * c->nseg));
         c->split_batch = sb;
         P.model_scratch = c->d_model_scratch;
         P.rec = c->d_rec;
+        P.segparts = c->d_segparts;
         if (const char *e = getenv("MSX_SPLIT_MIN")) c->split_min_walkers = std::max<int64_t>(1, atoll(e));
         if (const char *e = getenv("MSX_SPLIT_MIN_NPIX")) c->split_min_npix = std::max<int64_t>(1, atoll(e));
+        if (const char *e = getenv("MSX_WIDE_MAX")) c->wide_max_blocks_per_cu = std::max<int64_t>(0, atoll(e));
     }
 #ifdef MSX_STAMPS
     {   // diagnostic build only: per-walker shader-clock stamps
@@ -715,7 +728,7 @@ int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
 #endif
 
 int msx_set_path(msx_ctx *c, int32_t path) {
-    if (!c || path < MSX_PATH_AUTO || path > MSX_PATH_SPLIT) return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path");
+    if (!c || path < MSX_PATH_AUTO || path > MSX_PATH_WIDE) return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path");
     c->path = path;
     return MSX_OK;
 }
@@ -756,9 +769,19 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         if (!can_split) return fail(c, MSX_ERR_STATE, "msx_set_path(SPLIT): this problem / mode has no split form");
         split = true;
     }
+    // wide (logprob_kernel STAGE 3 / 4): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel
+    // segment) for the blend, so that a launch of <= #CUs / 2 walkers still uses every CU
+    const int64_t cus0 = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    const bool can_wide = can_split && c->nseg >= 2 && c->nseg <= 8 && !c->model_in_global;
+    bool wide = can_wide && !split && n * c->nseg <= c->wide_max_blocks_per_cu * cus0;
+    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_SPLIT) wide = false;
+    if (c->path == MSX_PATH_WIDE) {
+        if (!can_wide) return fail(c, MSX_ERR_STATE, "msx_set_path(WIDE): needs a spectrum of 2..8 segments of 8192 pixels and a mode with a split form");
+        wide = true;
+    }
     // sub-batches: the split path's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
     // hold split_batch walkers
-    const int64_t step = (split || c->model_in_global) ? c->split_batch : n;
+    const int64_t step = (split || wide || c->model_in_global) ? c->split_batch : n;
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min<int64_t>(step, n - off);
@@ -766,6 +789,13 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
         const DevProblem P = problem_at(Pc, off, mode, ndim);
         const int B = block_threads > 0 ? block_threads : pick_block(c, m, Pc.npix);
         int rc;
+        if (wide) {
+            LaunchArgs A3 = A;
+            A3.ng_mode_fast |= c->nseg << 24;
+            if ((rc = launch_logprob<3>(c, P, A3, 512, false))) return rc;
+            if ((rc = launch_logprob<4>(c, P, A, 512, false))) return rc;
+            continue;
+        }
         if (!split) {
             if ((rc = launch_logprob<0>(c, P, A, B, shared512))) return rc;
             continue;

@@ -147,3 +147,68 @@ def test_split_spectrum_longer_than_lds():
     one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
                                    c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
     assert rel_err(s[0], one) < TIGHT
+
+
+def three(eng, fn, *a, **k):
+    from mcmc_spec_amd import _lib
+    out = []
+    for path in (_lib.PATH_FUSED, _lib.PATH_WIDE, _lib.PATH_SPLIT):
+        eng.ctx.set_path(path)
+        out.append(fn(*a, **k))
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    return out
+
+
+@pytest.mark.parametrize('n', [1, 5, 128, 300])
+def test_wide_path_config4_bits(n):
+    """BASELINE config 4's spectrum (16,384 px + photometry): the wide path (one workgroup per walker and 8192-pixel
+    segment, then one per walker) gives the fused kernel's bits for any walker count, also beyond the sizes the
+    automatic choice would take it for; the fused kernel itself sums such a spectrum segment by segment."""
+    import bench
+    from mcmc_spec_amd import synth
+    from mcmc_spec_amd.engine import Engine
+    key = 'wide16k'
+    if key not in common._cache:
+        eng = Engine(0)
+        common._cache[key] = (eng, bench.build_workload(eng, 16384, True))
+    eng, W = common._cache[key]
+    th = synth.draw_walkers(n, seed=40 + n, tmin=W['tmin'], tmax=W['tmax'])
+    if n >= 5:
+        th[1, 1] = 2999.0            # rejected by the prior box: segment 0 of stage 3 alone finishes it
+        th[3, 2] = 0.0               # no reddening
+    f, w, s = three(eng, eng.logposterior, th)
+    assert np.array_equal(f, w) and np.array_equal(f, s)
+    assert np.isfinite(f).sum() >= n - 1
+    f, w, s = three(eng, eng.loglikelihood, th[:1], optimize=True)
+    assert np.array_equal(f, w) and np.array_equal(f, s)
+
+
+def test_wide_path_three_segments_against_the_oracle():
+    """17,000 pixels = two full segments and a short third, unsorted wavelengths: against the oracle and the fused
+    kernel; an error status (Teff outside the isochrone, likelihood mode) comes back through segment 0."""
+    from mcmc_spec_amd import _lib, bands
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    rng = np.random.default_rng(5)
+    wl = rng.uniform(0.56, 0.89, 17000)
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    f, w, s = three(eng, eng.loglikelihood, c.theta[:12])
+    assert np.array_equal(f, w) and np.array_equal(f, s) and np.all(np.isfinite(f))
+    one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(w[0], one) < TIGHT
+    bad = c.theta[:6].copy()
+    bad[2, 0] = 2800.0
+    eng.ctx.set_path(_lib.PATH_WIDE)
+    with pytest.raises(ValueError):
+        eng.loglikelihood(bad)
+    # a one-segment spectrum has no wide form
+    e1 = make_engine(c)
+    e1.ctx.set_path(_lib.PATH_WIDE)
+    with pytest.raises(_lib.MsxError):
+        e1.loglikelihood(c.theta[:4])

@@ -28,7 +28,7 @@ def main():
     from mcmc_spec_amd import _lib, synth
     from mcmc_spec_amd.engine import Engine
     eng = Engine(0)
-    W = build_workload(eng, args.npix, False)
+    W = build_workload(eng, args.npix, args.npix >= 16384)
     dev = torch.device('cuda', 0)
     n = args.walkers
     thn = synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])
