@@ -153,7 +153,8 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
  * segment) runs recipe + blend + the segment's fit sums / histogram, one workgroup per walker then combines the
  * segments and runs the median / chi^2 phases -- so that e.g. 128 walkers x 16384 pixels use all 256 CUs.  Same
  * bits as FUSED (which sums long spectra segment by segment too).  MSX_PATH_AUTO takes it while walkers x segments
- * <= MSX_WIDE_MAX x #CUs (environment, default 1).                                                              */
+ * <= MSX_WIDE_MAX x #CUs (environment; default 0 = never: measured slower than FUSED on MI355X, whose L2 -> CU
+ * fabric, not its CU count, bounds the blend of such launches -- DESIGN.md).                                     */
 #define MSX_PATH_AUTO 0
 #define MSX_PATH_FUSED 1
 #define MSX_PATH_SPLIT 2

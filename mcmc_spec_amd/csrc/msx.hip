@@ -113,7 +113,10 @@ struct msx_ctx {
     // MSX_SPLIT_MIN / MSX_SPLIT_MIN_NPIX (environment, read at msx_stage_problem) lower them.
     int64_t split_min_walkers = INT64_MAX, split_min_npix = INT64_MAX;
     int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _SPLIT / _WIDE (msx_set_path)
-    int64_t wide_max_blocks_per_cu = 1;  // MSX_PATH_AUTO takes the wide path while walkers x segments <= this x #CUs (MSX_WIDE_MAX)
+    // MSX_PATH_AUTO takes the wide path while walkers x segments <= this x #CUs (MSX_WIDE_MAX).  Default 0 = never:
+    // measured, the blend of 128 walkers x 16,384 px already draws ~10 TB/s from the L2s on 128 CUs and
+    // 256 CUs draw 11 -- the L2 -> CU fabric, not the CU count, bounds it, and the second launch costs more than it saves.
+    int64_t wide_max_blocks_per_cu = 0;
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
 };

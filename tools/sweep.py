@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--paths', default='fused,split')
     ap.add_argument('--graph', action='store_true')
+    ap.add_argument('--spread', action='store_true', help='walkers uniform over the whole Teff range: every walker its own grid rows')
     args = ap.parse_args()
     import torch
     from bench import build_workload
@@ -33,7 +34,10 @@ def main():
     stream = torch.cuda.current_stream(dev)
     rows = []
     for n in [int(x) for x in args.walkers.split(',')]:
-        th = torch.from_numpy(synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+        thn = synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])
+        if args.spread:
+            thn[:, 0:2] = np.random.default_rng(1).uniform(W['tmin'] + 1, W['tmax'] - 1, size=(n, 2))
+        th = torch.from_numpy(thn).to(dev)
         lp = torch.empty(n, dtype=torch.float64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
         for path in args.paths.split(','):
