@@ -491,21 +491,22 @@ def main():
     if rank == 0:
         kern_s = kern_ms * 1e-3
         req = eng.ctx.bytes_per_eval()  # bytes one walker's workgroup requests from the memory system (L2-served)
-        kernel_name = ('logprob_kernel<NS=2,U=2,512 threads,PF>' if not block else
-                       ('logprob_kernel<NS=2,U=1,512 threads> (two workgroups per CU)' if block == _lib.BLOCK_512_SHARED
-                        else 'logprob_kernel<NS=2>, %d threads' % block))
-        if args.npix >= 8192:
-            kernel_name = 'logprob_kernel<NS=2,U=1,1024 threads>'
-        elif n > 4 * 256 and not block:
-            kernel_name = 'logprob_kernel<NS=2,U=2,256 threads>'
-        elif n > 256 and not block:
-            kernel_name = 'logprob_kernel<NS=2,U=1,512 threads> (two workgroups per CU)'
+        cus = 256
+        if block == _lib.BLOCK_512_SHARED or (not block and cus < n <= 4 * cus and args.npix < 8192):
+            kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (two workgroups per CU, <= 128 VGPRs)'
+        elif block == 256 or (not block and n > 4 * cus and args.npix < 8192):
+            kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
+        elif args.npix * 8 * 3 > 130 * 1024:
+            kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU)'
+        else:
+            kernel_name = 'logprob_kernel<NS=2, 512 threads, PF> (one workgroup per CU, u / flux kept in LDS)'
         # ---- the roofline that bounds THIS design --------------------------------------------------------------
-        # The kernel never streams the windowed grid from HBM: staging compacts the two samples that bracket each
-        # data pixel into a pixel-major pair table (6.8 MB at config 2) that lives in L2 / Infinity Cache, and a
-        # walker's workgroup pulls its rows through its CU's L2 port.  So the honest bound at this batch size is
-        # L2 -> CU bandwidth (and, from a few workgroups per CU on, FP64 VALU issue: `valu` below).  The contract's
-        # HBM figure is kept, labelled, in `hbm_contract`; it is NOT a bound on this design and may exceed 1.
+        # The kernel never streams the windowed grid from HBM: staging folds the resample into per-node tables of
+        # 12 bytes per pixel (R float64 + H float32, 5.1 MB at config 2) that live in L2 / Infinity Cache, and a
+        # walker's workgroup pulls its eight rows through its CU's memory pipeline.  At this batch size the longest
+        # phase (the blend, ~47 % of the kernel) is bound by the L2 -> CU path; from a few workgroups per CU on the
+        # kernel is bound by FP64 VALU issue instead (`valu`, and the sweep's valu_issue_frac).  The contract's HBM
+        # figure is kept, labelled, in `hbm_contract`; it is NOT a bound on this design and exceeds 1.
         achieved = n * req / kern_s / 1e9
         traffic, traffic_src = None, None
         tj = load_profile('r2_logprob_traffic.json') or load_profile('r1_logprob_traffic.json')
@@ -518,10 +519,13 @@ def main():
             'kernel': kernel_name, 'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples,
             'requested_bytes_per_eval': req, 'requested_bytes_per_launch': n * req,
             'per_cu_GBps': req / kern_s / 1e9 if n <= 256 else None,
-            'per_cu_peak_GBps_guide': [66, 73],
-            'note': 'achieved = bytes the launch requests through the CUs\' L2 ports / kernel time; peak = L2 aggregate '
-                    '(MI355X_MICROARCH.md); one workgroup per CU at <= 256 walkers, so per_cu_GBps is that CU\'s rate '
-                    'averaged over the whole kernel (the blend phase alone runs at the guide\'s 66-73 GB/s per CU)',
+            'guide_l2_row_gather_GBps': {'per_cu': [66, 73], 'chip': [16800, 18800]},
+            'frac_of_guide_measured_gather': achieved / 17800.0,
+            'note': 'achieved = bytes the launch requests from the memory system (L2-served) / kernel time, averaged over '
+                    'the WHOLE kernel (recipe, blend, median, chi^2); peak = the L2 aggregate of MI355X_MICROARCH.md, beside '
+                    'it the same guide\'s measured chip-wide rate for rows gathered from L2 (16.8-18.8 TB/s).  The blend '
+                    'phase alone moves its 442 KB per walker in ~8 us: ~15 TB/s chip-wide with 256 CUs pulling, the '
+                    'most this access pattern drew from the L2s in any experiment of DESIGN.md',
         }
         if not replicas:
             nwin = W['nwin']
@@ -537,8 +541,17 @@ def main():
         copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
         roofline['measured_stream_copy_GBps'] = copy_gbps
         vj = load_profile('r2_valu.json')
+        issue_peak = 1024 * 2.4e9 / 4.0   # FP64 wave-instructions per second: 1024 SIMDs, one per 4 clocks, 2.4 GHz
+        valu_by_regime = {}
         if vj:
-            roofline['valu'] = vj
+            for pt in vj['points']:
+                valu_by_regime[(pt['npix'], pt['walkers'])] = pt['valu_insts_per_eval']
+            v = valu_by_regime.get((args.npix, n))
+            if v:
+                roofline['valu'] = {'insts_per_eval': v, 'wave_insts_per_s': v * n / kern_s, 'issue_peak_per_s': issue_peak,
+                                    'issue_frac': v * n / kern_s / issue_peak,
+                                    'source': 'profiles/r2_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) x this run\'s kernel time; '
+                                              'peak = 1024 SIMDs x 2.4 GHz / 4 clocks per FP64 wave-instruction'}
         workload = ('BASELINE config 5: KOI targets ({} px each after the (0.55, 0.90) um crop), one independent problem per '
                     'GPU, {} walkers per launch, logposterior with 2 contrast terms; {}'.format(
                         args.npix, n, 'ONE GPU rehearsal: 8 staged problems resident, launched round-robin' if world == 1
@@ -580,8 +593,12 @@ def main():
                 th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
                 lp_, st_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
                 us = device_time_us(eng, th, lp_, st_, stream, m, max(5, min(50, 200000 // m)))
-                sweep.append({'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6,
-                              'requested_GBps': m * req / us / 1e3, 'frac_of_l2_peak': m * req / us / 1e3 / L2_PEAK_GBPS})
+                row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6,
+                       'requested_GBps': m * req / us / 1e3, 'frac_of_l2_peak': m * req / us / 1e3 / L2_PEAK_GBPS}
+                vi = valu_by_regime.get((args.npix, 3072)) if m > 1024 else None   # the 256-thread variant's count
+                if vi:
+                    row['valu_issue_frac'] = vi * m / (us * 1e-6) / issue_peak
+                sweep.append(row)
             extra['sweep'] = {'npix': args.npix, 'rows': sweep}
             if args.npix == 4096 and not args.phot:
                 # BASELINE config 4's per-GPU share: 16,384 px + 6-band photometry, 1,024 walkers / 8 GPUs

@@ -1,19 +1,54 @@
 #!/bin/bash
-# The round's profile set (run on the GPU box through gpurun): kernel trace + stats of the default bench, then two
-# separate PMC passes (FETCH_SIZE, WRITE_SIZE -- never combined with trace domains), condensed into profiles/.
-#   gpurun --timeout 900 -- 'tools/profile_round.sh r1'
-set -e
-tag=${1:-r1}
+# The round's profile set (run on the GPU box through gpurun); condensed summaries land in gpurun_out/profiles_<tag>/
+# and are copied into profiles/ (tracked) afterwards.
+#   gpurun --timeout 1100 -- 'tools/profile_round.sh r2'
+# 1. kernel trace + stats of the default bench (config 2: 256 walkers x 4096 px), then two separate PMC passes
+#    (FETCH_SIZE, WRITE_SIZE -- never combined with trace domains) -> <tag>_logprob_kernel_stats.csv, _traffic.json
+# 2. SQ counter passes (counters only) at 256 / 3072 walkers and config 4's share -> <tag>_valu.json, <tag>_sq_*.json
+# 3. kernel stats of the split and wide forms next to the fused one (3072 walkers; 128 walkers x 16384 px)
+tag=${1:-r2}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/prof_$tag
-mkdir -p $out
+dst=$root/gpurun_out/profiles_$tag
+mkdir -p $out $dst
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $root/bench.py --steps 400 --warmup 40 --no-cpu-baseline > $out/bench_kt.json 2> $out/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/w.err
+B="--no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $root/bench.py --steps 400 --warmup 40 $B > $out/bench_kt.json 2> $out/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 $root/bench.py --steps 50 --warmup 5 $B > /dev/null 2> $out/f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 $root/bench.py --steps 50 --warmup 5 $B > /dev/null 2> $out/w.err
 cd $root
 python3 tools/pmc_summary.py --kt $out/kt --fetch $out/pmc_fetch --write $out/pmc_write --kernel logprob_kernel \
-  --out gpurun_out/profiles_$tag/${tag}_logprob \
-  --note "rocprofv3 on: python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline (kernel-trace/stats) and --steps 50 --warmup 5 (two separate --pmc passes: FETCH_SIZE, WRITE_SIZE); config 2: 256 walkers, 4096 px, block auto (512)"
-grep '^{' $out/bench_kt.json > gpurun_out/profiles_$tag/${tag}_bench_under_rocprof.json
-ls -la gpurun_out/profiles_$tag
+  --out $dst/${tag}_logprob \
+  --note "rocprofv3 on: python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-extras (kernel-trace/stats) and --steps 50 --warmup 5 (two separate --pmc passes: FETCH_SIZE, WRITE_SIZE); config 2: 256 walkers, 4096 px, block auto (512 threads, one workgroup per CU)" > /dev/null
+grep '^{' $out/bench_kt.json > $dst/${tag}_bench_under_rocprof.json
+# ---- SQ counters
+for cs in 4096:256 4096:3072 16384:128; do
+  npix=${cs%%:*}; n=${cs##*:}
+  tools/pmc_kernels.sh $tag $npix $n fused > $out/sq_${npix}_${n}.txt 2>&1
+  cp $root/gpurun_out/pmck_${tag}_${npix}_${n}_fused/summary.json $dst/${tag}_sq_${npix}px_${n}walkers.json
+done
+python3 - $dst $tag <<'PY'
+import json, sys
+dst, tag = sys.argv[1], sys.argv[2]
+out = {'source': 'rocprofv3 --pmc (SQ counters only, two passes per point; tools/pmc_kernels.sh) over tools/sweep.py, fused path',
+       'note': 'SQ_INSTS_VALU = vector ALU wave-instructions per launch; SQ_ACTIVE_INST_VALU counts quad-cycles; VALU busy = '
+               '4 x SQ_ACTIVE_INST_VALU / (kernel time x clock x 1024 SIMDs) is derived in DESIGN.md from the kernel times of the same points',
+       'points': []}
+for npix, n in ((4096, 256), (4096, 3072), (16384, 128)):
+    j = json.load(open('%s/%s_sq_%dpx_%dwalkers.json' % (dst, tag, npix, n)))
+    k = [x for x in j if 'logprob_kernel' in x][0]
+    m = j[k]
+    out['points'].append({'npix': npix, 'walkers': n, 'kernel': k, 'valu_insts_per_eval': m['SQ_INSTS_VALU'] / n,
+                          'valu_insts_per_pixel_lane': m['SQ_INSTS_VALU'] / n / (npix / 64.0),
+                          'vmem_read_insts_per_eval': m.get('SQ_INSTS_VMEM_RD', 0) / n, 'lds_insts_per_eval': m.get('SQ_INSTS_LDS', 0) / n,
+                          'wave_cycle_shares': {c: m[c] / m['SQ_WAVE_CYCLES'] for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU') if c in m},
+                          'active_valu_quadcycles_per_eval': m['SQ_ACTIVE_INST_VALU'] / n})
+json.dump(out, open('%s/%s_valu.json' % (dst, tag), 'w'), indent=1)
+print(json.dumps(out['points'], indent=1))
+PY
+# ---- the other forms of the path, per kernel
+PATHS="fused split" tools/prof_split.sh $tag "4096:3072,4096:16384" > $dst/${tag}_forms_4096px.txt 2>&1
+PATHS="fused wide split" tools/prof_split.sh $tag "16384:128" > $dst/${tag}_forms_16384px.txt 2>&1
+python3 tools/sweep.py --blocks 0 --paths fused --walkers 26,128,256,512,1024,2048,4096,16384 > $dst/${tag}_sweep_4096px.jsonl 2>/dev/null
+python3 tools/sweep.py --blocks 0 --paths fused --npix 16384 --phot --walkers 32,128,512 > $dst/${tag}_sweep_16384px.jsonl 2>/dev/null
+ls -la $dst
