@@ -133,7 +133,7 @@ int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n
                       double *logp_out, int32_t *status_out);
 /* same with device pointers on a caller stream; does not synchronise (no launch allocates: every scratch buffer is
  * sized by msx_stage_problem).  block_threads: 0 = auto (512 threads, one workgroup per CU with the pixel statics
- * staged in LDS, up to #CUs walkers and for spectra of >= 8192 pixels; 512 threads two per CU up to 4 x #CUs; 256
+ * staged in LDS, up to #CUs walkers and for spectra of >= 8192 pixels; 512 threads two per CU up to 2 x #CUs; 256
  * threads three per CU beyond), or 256 / 512, or MSX_BLOCK_512_SHARED = 512 threads in the <= 128-VGPR variant that
  * shares its CU with a second workgroup (what a launch wants when another kernel, e.g. a collective, holds CUs at
  * the same time).  The choice affects speed only: every variant produces the same bits.                        */

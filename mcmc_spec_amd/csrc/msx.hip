@@ -250,13 +250,14 @@ int launch_conv(msx_ctx *c, const double *d_in, int64_t in_stride, double *d_tmp
 
 int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
     // Measured at 4096 px: up to one walker per CU, 512 threads owning the CU with the pixel statics in
-    // LDS; up to 4 per CU, 512 threads sharing the CU two by two (<= 128 VGPRs); beyond, 256 threads three per CU.
+    // LDS; up to 2 per CU, 512 threads sharing the CU two by two (<= 128 VGPRs); beyond, 256 threads three per CU
+    // (512 / 1024 / 2048 walkers: 28.3 / 48.2 / 87.8 us shared-512 against 29.2 / 47.2 / 77.6 us with 256 threads).
     // Long spectra (model vector > half the LDS): 512 threads, one workgroup per CU.
     // The choice only affects speed: every variant sums in the same order (see phase A), so a walker's value
     // has the same bits whichever one evaluates it.
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     if (npix >= 8192) return 512;
-    if (n <= 4 * cus) return 512;
+    if (n <= 2 * cus) return 512;
     return 256;
 }
 

@@ -33,7 +33,9 @@ def truthy(val):
 
 def float_list(val):
     """``[2.08,1.3]`` -> floats (mft6.py:3523-3524, 3539); the string ``np.nan`` -> NaN (mft6.py:3530-3536)."""
-    toks = val.strip('[]\n').split(',')
+    toks = val.strip('[] \n').split(',')
+    if toks == ['']:
+        return []   # (an empty list; the reference itself cannot parse one)
     try:
         return [float(p) for p in toks]
     except ValueError:

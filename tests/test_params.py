@@ -78,7 +78,7 @@ def test_parser_quirks(run_dir):
 def test_boolean_and_list_conventions():
     assert params.truthy('True\n') and params.truthy('t') and params.truthy('tRUE') and params.truthy('yes it is')
     assert not params.truthy('False\n') and not params.truthy('f') and not params.truthy('0')
-    assert params.float_list('[2.08,1.3]') == [2.08, 1.3]
+    assert params.float_list('[2.08,1.3]') == [2.08, 1.3] and params.float_list('[]') == [] and list(params.name_list('[]')) == []
     v = params.float_list('[13.8,np.nan,12.3]')       # mft6.py:3530-3536
     assert v[0] == 13.8 and np.isnan(v[1]) and v[2] == 12.3
     with pytest.raises(ValueError):
