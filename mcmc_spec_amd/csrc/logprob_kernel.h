@@ -98,6 +98,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
+    __shared__ double e2tab[kExp2Tab];              // 2^(j/32) for the reddening factor (blend.h)
     constexpr bool kRecipe = STAGE == 0 || STAGE == 1 || STAGE == 3;  // this stage runs phase 0
     constexpr bool kBlend = STAGE == 0 || STAGE == 3;                 // ... computes model values from the tables
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
@@ -158,6 +159,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     }
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
+    if (kBlend) fill_exp2_table(e2tab, tid - (B - kWave));  // the last wave (no recipe work); published by phase 0's barrier
     // Early-histogram path (logbin_median): the median's histogram is filled while phase A computes the model,
     // and the walker's prior terms move to an idle wave of phase 0.  Likelihood / posterior / chi^2 modes with
     // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
@@ -312,8 +314,8 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
                 blend_accumulate<G>(ra, ha, w + c0, wf + c0, redden, sra, sha);
                 blend_accumulate<G>(rb, hb, w + c0, wf + c0, redden, srb, shb);
             }
-            m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, redden);
-            m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, redden);
+            m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, redden, e2tab);
+            m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, redden, e2tab);
         }
         f2 = P.f2[ec];
         u2 = P.u2[ec];

@@ -146,7 +146,9 @@ blend_tiles_kernel(const WalkerRec *__restrict__ rec, const int32_t *__restrict_
     __shared__ __attribute__((aligned(16))) double sW[kTileWalkers][NC];
     __shared__ double sRedc[kTileWalkers];
     __shared__ int sWalker[kTileWalkers];
+    __shared__ double e2tab[kExp2Tab];
     const int tid = threadIdx.x;
+    fill_exp2_table(e2tab, tid);  // (published by the first item's barrier)
     const int ntiles = hdr[0];
     const int nchunk = npair / 256;  // one chunk = 256 elements = 512 pixels
     const long long nitems = (long long)ntiles * nchunk;
@@ -188,8 +190,8 @@ blend_tiles_kernel(const WalkerRec *__restrict__ rec, const int32_t *__restrict_
             const double redc = sRedc[wi];
             const bool redden = redc != 0.0;
             double *out = model + (int64_t)sWalker[wi] * npix;
-            const double ma = blend_pixel_rh<NC>(ra, ha, w, wf, kl.x, (double)dk.x, redc, redden);
-            const double mb = blend_pixel_rh<NC>(rb, hb, w, wf, kl.y, (double)dk.y, redc, redden);
+            const double ma = blend_pixel_rh<NC>(ra, ha, w, wf, kl.x, (double)dk.x, redc, redden, e2tab);
+            const double mb = blend_pixel_rh<NC>(rb, hb, w, wf, kl.y, (double)dk.y, redc, redden, e2tab);
             if (pa < npix) out[pa] = ma;
             if (pb < npix) out[pb] = mb;
         }
