@@ -384,9 +384,11 @@ def main():
     # purpose; the ordering itself is mcmc_spec_amd.benchutil.capture_agreed (tests/test_dist_gloo.py).
     graph, chunk = None, 0
     want_graph = os.environ.get('MSX_BENCH_GRAPH', '1') == '1'
-    period = int(2 * nbatch * nprob // np.gcd(2 * nbatch, nprob))  # a chunk holds whole periods of (problem, batch, buffer)
-    if want_graph and not direct and args.steps >= period:
-        chunk = max(period, min(int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '40')), args.steps) // period * period)
+    # The captured run covers as much of the timed region as possible: one replay costs the host ~10-16 us (the
+    # guide's graph-replay floor), which a 20-step run (what the driver times) would otherwise pay several times.
+    # Step i of a replay uses problem i mod nprob, theta batch i mod nbatch, output buffer i mod 2: any even chunk.
+    if want_graph and not direct and args.steps >= 4:
+        chunk = min(args.steps, int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '200'))) // 2 * 2
         from mcmc_spec_amd.benchutil import capture_agreed
 
         def do_capture():
