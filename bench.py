@@ -494,9 +494,9 @@ def main():
         kern_s = kern_ms * 1e-3
         req = eng.ctx.bytes_per_eval()  # bytes one walker's workgroup requests from the memory system (L2-served)
         cus = 256
-        if block == _lib.BLOCK_512_SHARED or (not block and cus < n <= 2 * cus and args.npix < 8192):
+        if block == _lib.BLOCK_512_SHARED or (not block and cus < n <= 2 * cus and 2048 < args.npix < 8192):
             kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (two workgroups per CU, <= 128 VGPRs)'
-        elif block == 256 or (not block and n > 2 * cus and args.npix < 8192):
+        elif block == 256 or (not block and n > cus and (n > 2 * cus or args.npix <= 2048) and args.npix < 8192):
             kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
         elif args.npix * 8 * 3 > 130 * 1024:
             kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU)'
