@@ -51,34 +51,46 @@ __device__ __forceinline__ void blend_accumulate(const double *r, const float *h
 }
 // 2^x for the reddening factor, x = -0.4 log2(10) A_V k <= 0.  The library exp2 spends 33 vector instructions per
 // call (full-range argument handling, an 11-term polynomial whose coefficients each need a register move); here
-// x = n + j/32 + r with |r| <= 1/64, 2^(j/32) from a 32-entry table in LDS (kExp2Tab, filled once per workgroup by
-// fill_exp2_table) and e^(r ln 2) from six series terms (truncation < 4e-18 relative): about 18 instructions, the
-// result within ~1.5 ulp.  Underflow goes through v_ldexp_f64; a NaN argument gives NaN.
-constexpr int kExp2Tab = 32;
+// x = n + j/64 + z with |z| <= 1/128, 2^(j/64) from a 64-entry table in LDS (kExp2Tab, filled once per workgroup by
+// fill_exp2_table) and 2^z - 1 = sum_{k=1..5} (ln 2)^k z^k / k! (truncation < 4e-17 relative), the coefficients
+// wave-uniform in SGPRs: twelve instructions, the result within ~1.5 ulp.  Underflow goes through v_ldexp_f64; a
+// NaN argument gives NaN.
+constexpr int kExp2Tab = 64;
+constexpr double kLn2Pow1 = 0.6931471805599453, kLn2Pow2 = 0.2402265069591007, kLn2Pow3 = 0.055504108664821576,
+                 kLn2Pow4 = 0.009618129107628477, kLn2Pow5 = 0.0013333558146428441;  // (ln 2)^k / k!
 __device__ __forceinline__ void fill_exp2_table(double *tab, int idx) {  // call with idx = 0 .. kExp2Tab - 1, then barrier
     if ((unsigned)idx < (unsigned)kExp2Tab) tab[idx] = exp2((double)idx * (1.0 / kExp2Tab));
 }
 __device__ __forceinline__ double table_exp2(const double x, const double *__restrict__ tab) {
     const double nf = rint(x * (double)kExp2Tab);
     const int ni = (int)nf;
-    const double y = 0.6931471805599453 * fma(nf, -1.0 / kExp2Tab, x);  // (x - nf / 32) is exact
-    double p = fma(y, 1.0 / 720, 1.0 / 120);
-    p = fma(p, y, 1.0 / 24);
-    p = fma(p, y, 1.0 / 6);
-    p = fma(p, y, 0.5);
-    p = fma(p, y, 1.0);
-    p = p * y;  // e^y - 1
+    const double z = fma(nf, -1.0 / kExp2Tab, x);  // exact
+    double p = fma_sc(z, kLn2Pow5, kLn2Pow4);
+    p = fma_sc(p, z, kLn2Pow3);
+    p = fma_sc(p, z, kLn2Pow2);
+    p = fma_sc(p, z, kLn2Pow1);
+    p = p * z;  // 2^z - 1
     const double t = tab[ni & (kExp2Tab - 1)];
-    return ldexp(fma(t, p, t), ni >> 5);
+    return ldexp(fma(t, p, t), ni >> 6);
 }
+static_assert(kExp2Tab == 64, "table_exp2 shifts by 6");
 
 __device__ __forceinline__ double blend_finish(const double sr, const float sh, const double kl, const double dk,
                                                const double redc, const bool redden, const double *__restrict__ e2tab) {
     if (!redden) return sr;
     const double elo = table_exp2(redc * kl, e2tab);  // 10^(-0.4 A_V k)     mft6.py:62-63
-    const double y = 0.6931471805599453 * (redc * dk);
-    // eps = e^y - 1: four series terms (exact to < 1e-17 for |y| < 1e-3), else the full exp2
-    const double eps = (fabs(y) < 1e-3) ? y * fma(y, fma(y, fma(y, 1.0 / 24, 1.0 / 6), 0.5), 1.0) : exp2(redc * dk) - 1.0;
+    const double s = redc * dk;
+    // eps = 2^s - 1: four series terms (exact to < 1e-14 relative for |s| < 1e-3, and eps only ever scales the
+    // 1e-5-sized H term), else the full exp2
+    double eps;
+    if (fabs(s) < 1e-3) {
+        double p = fma_sc(s, kLn2Pow4, kLn2Pow3);
+        p = fma_sc(p, s, kLn2Pow2);
+        p = fma_sc(p, s, kLn2Pow1);
+        eps = p * s;
+    } else {
+        eps = exp2(s) - 1.0;
+    }
     return elo * fma(eps, (double)sh, sr);
 }
 template <int NC>

@@ -41,6 +41,90 @@ __device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDes
     P.smp_lp_row[s] = acc ? out : D.smp_old;
 }
 
+// The chi^2 terms that ride along the median's pass over the model vector (see phase B in the kernel): u, data flux
+// and 1/err^2 by table ELEMENT (two pixels 256 apart) -- the four pixels of a trip are the elements (base >> 1) + tid
+// and + MAXT (pass_pixel).  u and flux come from LDS with PF, else from the tables; 1/err^2 always from its table.
+// AHEAD = global loads run one trip ahead of their use, into the register set of the other parity (median.h,
+//         pass_trips): the one-workgroup-per-CU variants, which have the registers and few waves to hide a load
+//         behind.  Otherwise a trip's loads are issued at its start, before the trip's LDS reads.
+// ALWAYS = the terms are wanted whatever `on` says (the early-histogram median only runs in the fused modes): no
+//         run-time flag inside the pass, whose merge points would bring register copies back.
+// Holds plain pointers, never a reference to the by-value kernel argument (see DevProblem).
+template <int MAXT, bool PF, bool ALWAYS, bool AHEAD>
+struct ChiElem {
+    static constexpr int VK = kMaxWaves / (MAXT / kWave);
+    static constexpr int NSET = AHEAD ? 2 : 1;
+    const double2 *u2, *f2, *iv2;
+    int ne, npix;
+    double c0, c1, c2;
+    double acc[VK];  // one per slot this lane holds (see phase A and pass_pixel)
+    bool on;
+    double *red0;    // [MAXT] LDS: the lanes' partials of the chi^2 sum
+    double2 nu[NSET][2], nf[NSET][2], nv[NSET][2];  // [register set][element of the trip]
+    double tot_run;  // wave 0: the chi^2 sum over the segments finished so far (see phase A)
+    template <int SET>
+    __device__ __forceinline__ void load_trip(int base) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
+            e = e < ne ? e : ne - 1;
+            const unsigned int o16 = (unsigned int)e << 4;
+            nv[SET][j] = ld_off(iv2, o16);
+            if (!PF) { nu[SET][j] = ld_off(u2, o16); nf[SET][j] = ld_off(f2, o16); }
+        }
+    }
+    __device__ __forceinline__ void prime() {  // before the pass (and before whatever the caller does first)
+        if (!ALWAYS && !on) return;
+        if (AHEAD) load_trip<0>(0);
+    }
+    template <int PAR>
+    __device__ __forceinline__ void begin_trip(int base) {
+        if (!ALWAYS && !on) return;
+        if (!AHEAD) load_trip<0>(base);
+    }
+    // the four pixels of one trip (pass_pixel order)
+    template <int PAR>
+    __device__ __forceinline__ void process4(int base, const int (&p)[4], const double (&xv)[4]) {
+        if (!ALWAYS && !on) return;
+        constexpr int SET = AHEAD ? PAR : 0;
+        double2 cu[2], cf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (PF) {
+                int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
+                e = e < ne ? e : ne - 1;
+                cu[j] = u2[e]; cf[j] = f2[e];  // LDS
+            } else {
+                cu[j] = nu[SET][j]; cf[j] = nf[SET][j];
+            }
+        }
+        if (AHEAD) load_trip<AHEAD ? 1 - PAR : 0>(base + 4 * MAXT);
+        const double u[4] = {cu[0].x, cu[0].y, cu[1].x, cu[1].y}, f[4] = {cf[0].x, cf[0].y, cf[1].x, cf[1].y};
+        const double e[4] = {nv[SET][0].x, nv[SET][0].y, nv[SET][1].x, nv[SET][1].y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double poly = fma(fma(c2, u[k], c1), u[k], c0);
+            const double r = xv[k] - fast_div(f[k], poly);  // (model - data/P); mft6.py:196,120 up to scale^2
+            acc[k & (VK - 1)] += p[k] < npix ? (r * r) * e[k] : 0.0;
+        }
+        // end of a segment of the canonical sum (8192 pixels), more pixels to come: fold it in.  (Uniform: every
+        // thread of the workgroup walks the same trips.)
+        const int next = base + 4 * MAXT;
+        if ((next & (2 * kSegElems - 1)) == 0 && next < npix) {
+            red0[threadIdx.x] = lane_partial<VK>(acc);
+#pragma unroll
+            for (int k = 0; k < VK; ++k) acc[k] = 0.0;
+            __syncthreads();
+            if ((threadIdx.x >> 6) == 0) tot_run += reduce_published<MAXT>(red0, (int)threadIdx.x & 63);
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ void flush(BlockScratch &) {  // one partial per lane; wave 0 finishes at the very end
+        if (!ALWAYS && !on) return;
+        red0[threadIdx.x] = lane_partial<VK>(acc);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // THE HOT KERNEL: one workgroup per walker.
 //   phase 0    one wave per star builds the walker's recipe from register-resident tables (prior gate, A1, A2,
@@ -246,10 +330,10 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         const int64_t off = !kBlend ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
         rows_r[c] = P.r2 + off;
         rows_h[c] = P.h2 + off;
-        w[c] = !kBlend ? 0.0 : D.w[c];
-        wf[c] = (float)w[c];
+        w[c] = !kBlend ? 0.0 : uniform_f64(D.w[c]);
+        wf[c] = uniform_f32((float)w[c]);
     }
-    const double redc = !kBlend ? 0.0 : D.redc;
+    const double redc = !kBlend ? 0.0 : uniform_f64(D.redc);
     const bool redden = redc != 0.0;
     // Sums are taken in an order that does not depend on the workgroup size.  Pixel p belongs to SLOT p mod 1024;
     // a slot accumulates its pixels in ascending order in ONE lane's register, the 64 slots of VIRTUAL wave v
@@ -277,6 +361,11 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
 #pragma unroll
       for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
       const int e_end = (seg + 1) * kSegElems < ne ? (seg + 1) * kSegElems : ne;
+      // The trips of this segment, compiled twice: with the reddening terms (H rows, k, dk, the exp2) and without
+      // (A_V <= 0: R rows only).  `redden` is uniform over the workgroup; as a run-time flag inside the loop it cost a
+      // scalar branch and a zero-fill per H load.
+      auto trips = [&](auto red_c) __attribute__((always_inline)) {
+      constexpr bool RED = decltype(red_c)::value;
       for (int e0 = seg * kSegElems; e0 < e_end; e0 += B * SUB) {
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
@@ -286,8 +375,9 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
         const bool ok[U] = {live && pa < npix, live && pb < npix};
         const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
-        double2 kl2 = make_double2(0.0, 0.0), f2, u2, m2;
-        float2 dk2 = make_float2(0.f, 0.f);
+        // one shared 32-bit byte offset per element width: every table is addressed SGPR base + this (wave_ops.h)
+        const unsigned int o16 = (unsigned int)ec << 4, o8 = (unsigned int)ec << 3;
+        double2 f2, u2, m2;
         if (!kBlend) {
             m2 = make_double2(model_in[pp[0]], model_in[pp[1]]);  // blend_tiles_kernel's output for this walker
         } else {
@@ -295,6 +385,8 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             // All corners' loads are issued together (192 bytes in flight per lane) -- except in the variant that
             // shares its CU (128 VGPRs), which takes the rows one star at a time.
             constexpr int G = SH ? 4 : NC;  // corners per group of loads
+            double2 kl2 = make_double2(0.0, 0.0);
+            float2 dk2 = make_float2(0.f, 0.f);
             double sra = 0.0, srb = 0.0;
             float sha = 0.0f, shb = 0.0f;
 #pragma unroll
@@ -303,22 +395,22 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
                 float2 hh[G];
 #pragma unroll
                 for (int c = 0; c < G; ++c) {
-                    rr[c] = rows_r[c0 + c][ec];
-                    hh[c] = redden ? rows_h[c0 + c][ec] : make_float2(0.f, 0.f);
+                    rr[c] = ld_off(rows_r[c0 + c], o16);
+                    hh[c] = RED ? ld_off(rows_h[c0 + c], o8) : make_float2(0.f, 0.f);
                 }
-                if (c0 == 0 && redden) { kl2 = P.kl2[ec]; dk2 = P.dk2[ec]; }
+                if (c0 == 0 && RED) { kl2 = ld_off(P.kl2, o16); dk2 = ld_off(P.dk2, o8); }
                 double ra[G], rb[G];
                 float ha[G], hb[G];
 #pragma unroll
                 for (int c = 0; c < G; ++c) { ra[c] = rr[c].x; rb[c] = rr[c].y; ha[c] = hh[c].x; hb[c] = hh[c].y; }
-                blend_accumulate<G>(ra, ha, w + c0, wf + c0, redden, sra, sha);
-                blend_accumulate<G>(rb, hb, w + c0, wf + c0, redden, srb, shb);
+                blend_accumulate<G>(ra, ha, w + c0, wf + c0, RED, sra, sha);
+                blend_accumulate<G>(rb, hb, w + c0, wf + c0, RED, srb, shb);
             }
-            m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, redden, e2tab);
-            m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, redden, e2tab);
+            m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, RED, e2tab);
+            m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, RED, e2tab);
         }
-        f2 = P.f2[ec];
-        u2 = P.u2[ec];
+        f2 = ld_off(P.f2, o16);
+        u2 = ld_off(P.u2, o16);
         if (PF && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
         const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
 #pragma unroll
@@ -333,14 +425,16 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
 #pragma unroll
                 for (int k = 0; k < vk; ++k)
                     if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2_; }
-                vmin = fmin(vmin, m);
-                vmax = fmax(vmax, m);
+                vmin = min_nc(vmin, m);
+                vmax = max_nc(vmax, m);
                 seen_nan = seen_nan || (m != m);
                 if (early) atomicAdd(&S.hist[logbin(m)], 1u);
             }
         }
       }
       }
+      };
+      if (redden) trips(std::true_type{}); else trips(std::false_type{});
       // this segment's three fit sums: one partial per lane to LDS, one wave per quantity finishes (wave_ops.h)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -437,80 +531,21 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // so everything but the final scalar multiply is independent of the median and rides along the
     // median's first pass over the model vector (fused modes only; the optimiser modes keep phase C).
     const bool fused = !(mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT);
-    struct ChiElem {  // holds plain pointers, never a reference to the by-value kernel argument (see DevProblem)
-        enum { VK = kMaxWaves / (MAXT / kWave) };  // (a local class cannot have static data members)
-        // u, data flux and 1/err^2 by table ELEMENT (two pixels 256 apart): the four pixels of a trip are the
-        // elements (base >> 1) + tid and + MAXT (pass_pixel).  u and flux come from LDS with PF, else from the
-        // tables; 1/err^2 always from its table.  Global loads run one trip ahead of their use.
-        const double2 *u2, *f2, *iv2;
-        int ne, npix;
-        double c0, c1, c2;
-        double acc[VK];  // one per slot this lane holds (see phase A and pass_pixel)
-        bool on;
-        double *red0;    // [MAXT] LDS: the lanes' partials of the chi^2 sum
-        double2 nu[2], nf[2], nv[2];  // the NEXT trip's values
-        double tot_run;               // wave 0: the chi^2 sum over the segments finished so far (see phase A)
-        __device__ __forceinline__ void prefetch(int base) {
-            if (!on) return;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
-                e = e < ne ? e : ne - 1;
-                nv[j] = iv2[e];
-                if (!PF) { nu[j] = u2[e]; nf[j] = f2[e]; }
-            }
-        }
-        // the four pixels of one trip (pass_pixel order)
-        __device__ __forceinline__ void process4(int base, const int (&)[4], const double (&xv)[4], const bool (&ok)[4]) {
-            if (!on) return;
-            double2 cu[2], cf[2], cv[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                cv[j] = nv[j];
-                if (PF) {
-                    int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
-                    e = e < ne ? e : ne - 1;
-                    cu[j] = u2[e]; cf[j] = f2[e];  // LDS
-                } else {
-                    cu[j] = nu[j]; cf[j] = nf[j];
-                }
-            }
-            prefetch(base + 4 * MAXT);
-            const double u[4] = {cu[0].x, cu[0].y, cu[1].x, cu[1].y}, f[4] = {cf[0].x, cf[0].y, cf[1].x, cf[1].y};
-            const double e[4] = {cv[0].x, cv[0].y, cv[1].x, cv[1].y};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double poly = fma(fma(c2, u[k], c1), u[k], c0);
-                const double r = xv[k] - fast_div(f[k], poly);  // (model - data/P); mft6.py:196,120 up to scale^2
-                acc[k & (VK - 1)] += ok[k] ? (r * r) * e[k] : 0.0;
-            }
-            // end of a segment of the canonical sum (8192 pixels), more pixels to come: fold it in.  (Uniform: every
-            // thread of the workgroup walks the same trips.)
-            const int next = base + 4 * MAXT;
-            if ((next & (2 * kSegElems - 1)) == 0 && next < npix) {
-                red0[threadIdx.x] = lane_partial<VK>(acc);
-#pragma unroll
-                for (int k = 0; k < VK; ++k) acc[k] = 0.0;
-                __syncthreads();
-                if ((threadIdx.x >> 6) == 0) tot_run += reduce_published<MAXT>(red0, (int)threadIdx.x & 63);
-                __syncthreads();
-            }
-        }
-        __device__ __forceinline__ void flush(BlockScratch &) {  // one partial per lane; wave 0 finishes at the very end
-            if (!on) return;
-            red0[threadIdx.x] = lane_partial<VK>(acc);
-        }
-    };
-    ChiElem chi_elem{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix,
-                     P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2],
-                     P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2],
-                     P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2], {}, fused, &red[0][0][0], {}, {}, {}, 0.0};
+    const double pc0 = P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2];
+    const double pc1 = P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2];
+    const double pc2 = P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2];
+    constexpr bool kAhead = MAXT == 512 && !SH;
+    ChiElem<MAXT, PF, false, kAhead> chi_elem{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, fused,
+                                      &red[0][0][0], {}, {}, {}, 0.0};
     bool chi_done = false;
     double med_model = 0.0;
     bool solved = false;
     if (early) {
-        solved = logbin_median<MAXT>(model, npix, kmin, kmax, S, chi_elem, &med_model);
+        ChiElem<MAXT, PF, true, kAhead> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
+                                         &red[0][0][0], {}, {}, {}, 0.0};
+        solved = logbin_median<MAXT>(model, npix, kmin, kmax, S, chi_fast, &med_model);
         chi_done = solved;
+        if (solved) chi_elem.tot_run = chi_fast.tot_run;
         if (!solved) {  // not a positive vector spanning < 8 binades, or > 256 equal-bin candidates: start over
             __syncthreads();  // every wave decided from the counters by itself: none may still be reading them
             for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
@@ -519,20 +554,8 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     }
     if (!solved) med_model = block_median<MAXT>(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
     if (fused && !chi_done) {  // degenerate vectors (all equal): the median took no pass, do it here
-        chi_elem.prefetch(0);
-        for (int base = 0; base < npix; base += 4 * B) {
-            int pp[4];
-            double xv[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = pass_pixel<MAXT>(base, u, tid);
-                ok[u] = p < npix;
-                pp[u] = ok[u] ? p : npix - 1;
-                xv[u] = model[pp[u]];
-            }
-            chi_elem.process4(base, pp, xv, ok);
-        }
+        chi_elem.prime();
+        pass_trips<MAXT>(model, npix, chi_elem, [](const int (&)[4], const double (&)[4]) {});
         chi_elem.flush(S);
         __syncthreads();
     }

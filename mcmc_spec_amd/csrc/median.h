@@ -118,14 +118,41 @@ struct NoSide {
     __device__ __forceinline__ void operator()() const {}
 };
 // Per-element work that can ride along the median's first pass over the vector (it already reads every
-// element): prefetch(0) is called before the pass (the element may start loading what its first trip needs),
-// process4() gets the trip's base and four (index, value, valid) triples, flush() publishes the lanes' partials
-// right before the pass's barrier.
+// element): prime() is called before the pass (the element may start loading what its first trip needs),
+// begin_trip<PAR>() at the top of every trip (before the trip's LDS reads),
+// process4<PAR>() gets the trip's base, its four pixel indices (a pixel p is valid iff p < npix; invalid ones carry
+// the value of pixel npix - 1) and values -- PAR = the trip's parity: an element that loads one trip ahead keeps TWO
+// register sets and alternates, instead of copying "next" to "current" every trip -- and flush() publishes the
+// lanes' partials right before the pass's barrier.
 struct NoElem {
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void process4(int, const int (&)[4], const double (&)[4], const bool (&)[4]) {}
+    __device__ __forceinline__ void prime() {}
+    template <int PAR> __device__ __forceinline__ void begin_trip(int) {}
+    template <int PAR> __device__ __forceinline__ void process4(int, const int (&)[4], const double (&)[4]) {}
     __device__ __forceinline__ void flush(BlockScratch &) {}
 };
+// One pass over the model vector in trips of 4 BT pixels (pass_pixel order): elem.process4, then per(p, xv).
+// (Validity travels as the pixel index, not as a flag: flags handed through arrays get packed into bytes and
+// unpacked again, a dozen instructions per trip; a compare against npix is one.)
+template <int BT, class Elem, class Per>
+__device__ __forceinline__ void pass_trips(const double *model, int npix, Elem &elem, Per per) {
+    const int tid = threadIdx.x;
+    auto one = [&](int base, auto par) __attribute__((always_inline)) {
+        elem.template begin_trip<decltype(par)::value>(base);
+        int p[4];
+        double xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // loads first, then use
+            p[u] = pass_pixel<BT>(base, u, tid);
+            xv[u] = model[p[u] < npix ? p[u] : npix - 1];
+        }
+        elem.template process4<decltype(par)::value>(base, p, xv);
+        per(p, xv);
+    };
+    for (int base = 0; base < npix; base += 8 * BT) {
+        one(base, std::integral_constant<int, 0>{});
+        if (base + 4 * BT < npix) one(base + 4 * BT, std::integral_constant<int, 1>{});  // (uniform)
+    }
+}
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {  // l wave-uniform
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
@@ -153,26 +180,15 @@ __device__ __forceinline__ double block_median(const double *model, int npix, un
         bool solved = false;
         MED_STAMP(0);
         if (lin_ok) {
-            elem.prefetch(0);
-            for (int base = 0; base < npix; base += 4 * B) {  // 4 elements per trip: loads first, then use
-                int pp[4];
-                double xv[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = pass_pixel<BT>(base, u, tid);
-                    ok[u] = p < npix;
-                    pp[u] = ok[u] ? p : npix - 1;
-                    xv[u] = model[pp[u]];
-                }
-                elem.process4(base, pp, xv, ok);
+            elem.prime();
+            pass_trips<BT>(model, npix, elem, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     int bin = (int)((xv[u] - vmin) * scale);
                     bin = bin > kBins - 1 ? kBins - 1 : bin;
-                    if (ok[u]) atomicAdd(&S.hist[bin], 1u);
+                    if (p[u] < npix) atomicAdd(&S.hist[bin], 1u);
                 }
-            }
+            });
             elem.flush(S);
             *elem_done = true;
             __syncthreads();
@@ -332,7 +348,7 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
     if ((hmax - hmin) + (hmin & (unsigned int)(per - 1)) >= (unsigned int)kLogBins) return false;  // the cycle would lap itself
     MED_STAMP(0);
     MED_STAMP(1);
-    elem.prefetch(0);  // the pass's first loads travel while the counters are scanned
+    elem.prime();  // the pass's first loads travel while the counters are scanned
     // ---- per-wave scan: lane l owns the `per` counters from physical bin (a + per*l) mod kLogBins ----------
     const unsigned int phys = (a + (unsigned int)(per * lane)) & (unsigned int)(kLogBins - 1);
     unsigned int own = 0;
@@ -355,37 +371,39 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
     const unsigned int inc2 = wave_scan_u32(c);
     const int J = uni(__ffsll((long long)__ballot(c > 0 && inc2 - c <= t && t < inc2)) - 1);
     const unsigned int kk = t - (unsigned int)__builtin_amdgcn_readlane((int)(inc2 - c), J);
-    const unsigned int cnt = (unsigned int)__builtin_amdgcn_readlane((int)c, J);
-    const unsigned int lsel = (phys_l + (unsigned int)J - a) & (unsigned int)(kLogBins - 1);
-    if (cnt > (unsigned int)kSelectFinish) return false;  // heavy duplication: the general path sorts it out
-    MED_STAMP(2);
-    // ---- one pass: chi^2 terms + candidates of the median's bin + smallest key of the later bins -----------
-    unsigned long long above = ~0ull;
-    double above_v = INFINITY;
-    for (int base = 0; base < npix; base += 4 * B) {
-        int pp[4];
-        double xv[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = pass_pixel<BT>(base, u, tid);
-            ok[u] = p < npix;
-            pp[u] = ok[u] ? p : npix - 1;
-            xv[u] = model[pp[u]];
-        }
-        elem.process4(base, pp, xv, ok);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            // (all values are positive here: the smallest VALUE of the later bins is their smallest key; keys are
-            // only formed for the handful of candidates)
-            const unsigned int lx = (logbin(xv[u]) - a) & (unsigned int)(kLogBins - 1);
-            if (ok[u] && lx == lsel) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
-            else if (ok[u] && lx > lsel) above_v = fmin(above_v, xv[u]);
+    unsigned int cnt = (unsigned int)__builtin_amdgcn_readlane((int)c, J);
+    const unsigned int sel_p = phys_l + (unsigned int)J;  // PHYSICAL bin of rank k1 (< kLogBins: a group does not wrap)
+    // Rank k1 + 1 (even npix) lies in the same bin unless rank k1 is that bin's last value; then it is the smallest
+    // value of the NEXT non-empty bin along the cycle, and that bin's values are gathered too: in the union, ranks
+    // kk and kk + 1 are the two middle values either way.
+    unsigned int nxt_p = sel_p;
+    if (need_two && kk + 1 == cnt) {  // (uniform; ~1 walker in `cnt`)
+        const unsigned long long later = __ballot(c > 0 && lane > J);
+        if (later != 0ull) {
+            const int J2 = uni(__ffsll((long long)later) - 1);
+            nxt_p = phys_l + (unsigned int)J2;
+            cnt += (unsigned int)__builtin_amdgcn_readlane((int)c, J2);
+        } else {
+            // the first non-empty counter of the next lane group that has any (one exists: rank k1 + 1 < npix)
+            const int L2 = uni(__ffsll((long long)(__ballot(own > 0 && lane > L))) - 1);
+            const unsigned int phys_l2 = (unsigned int)__builtin_amdgcn_readlane((int)phys, L2);
+            const unsigned int c2 = lane < per ? S.hist[phys_l2 + lane] : 0u;
+            const int J2 = uni(__ffsll((long long)__ballot(c2 > 0)) - 1);
+            nxt_p = phys_l2 + (unsigned int)J2;
+            cnt += (unsigned int)__builtin_amdgcn_readlane((int)c2, J2);
         }
     }
+    if (cnt > (unsigned int)kSelectFinish) return false;  // heavy duplication: the general path sorts it out
+    MED_STAMP(2);
+    // ---- one pass: chi^2 terms + the candidates (the values of the one or two bins above) ----------------------
+    pass_trips<BT>(model, npix, elem, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int pb = logbin(xv[u]);
+            if (p[u] < npix && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
+        }
+    });
     elem.flush(S);
-    above = wave_min_u64(above_v == INFINITY ? ~0ull : key_of(above_v));
-    if (lane == 0) S.above[wave] = above;
     __syncthreads();
     MED_STAMP(3);
     // ---- rank.  Up to 64 candidates (the usual case): wave 0 alone, in registers, and only wave 0 (whose lane 0
@@ -437,10 +455,7 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
 #ifdef MSX_STAMPS
     if (tid == 0) g_med_stamps[blockIdx.x * 8 + 6] = cnt;
 #endif
-    if (!second) {
-        v2 = S.above[0];
-        for (int x = 1; x < nw; ++x) v2 = S.above[x] < v2 ? S.above[x] : v2;
-    }
+    (void)second;  // (even npix: rank kk + 1 is among the candidates by construction)
     *med_out = need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
     return true;
 }

@@ -42,6 +42,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <string>
 #include <vector>
 

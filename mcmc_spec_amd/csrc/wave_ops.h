@@ -94,15 +94,54 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
 }
 
-// a / b for NORMAL b (model fluxes, continuum polynomials): v_rcp_f64, two Newton steps, one correction of the
-// quotient -- the compiler's own division sequence without its v_div_scale / v_div_fmas / v_div_fixup wrapping
-// (denormal / overflow scaling, special values), four instructions shorter.  b = 0 gives NaN where IEEE gives
-// +-inf: either way the walker's sums stop being finite and its log-probability ends as -inf.
+// ---- instruction-level helpers for the per-pixel loops (these run at the VALU issue limit with large batches: every
+// instruction the compiler adds around an operation is paid 4096 times per walker) ---------------------------------
+// A wave-uniform value, moved to SGPRs: the blend weights, the reddening coefficient.  As scalar operands of the
+// per-pixel FMAs they occupy no vector registers (24 for a binary's eight corners).
+__device__ __forceinline__ double uniform_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+// a * b + c with c a wave-uniform constant held in SGPRs.  The compiler's own choice for `fma(p, y, c)` with a
+// loop-invariant c is v_fmac (destination = addend), i.e. one register-pair COPY of c per use.
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+// min / max as the bare instruction (a quiet-NaN operand is ignored, like fmin / fmax): the compiler brackets
+// fmin / fmax with a canonicalising v_max_f64 x, x per operand -- three instructions for one.  (No signalling NaN
+// reaches these: every operand is the result of arithmetic.)
+__device__ __forceinline__ double min_nc(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_nc(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// base[byte_off / sizeof(T)] with a wave-uniform base and a 32-bit byte offset: selects the SGPR-base + VGPR-offset
+// addressing of global loads, so a lane spends no instruction per load on a 64-bit address (one shared offset
+// register instead of a v_lshl_add_u64 per table row).
+template <class T>
+__device__ __forceinline__ T ld_off(const T *__restrict__ base, unsigned int byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// a / b for NORMAL b (model fluxes, continuum polynomials): v_rcp_f64 (relative error ~2^-24), ONE Newton step
+// (-> 2^-48) and one residual correction of the quotient (q + (a - b q) r: relative error 2^-96 before the final
+// rounding) -- the compiler's own division sequence without its second Newton step and its v_div_scale /
+// v_div_fmas / v_div_fixup wrapping (denormal / overflow scaling, special values), six instructions shorter.
+// b = 0 gives NaN where IEEE gives +-inf: either way the walker's sums stop being finite and its log-probability
+// ends as -inf.
 __device__ __forceinline__ double fast_div(double a, double b) {
     double r = __builtin_amdgcn_rcp(b);
-    double e = fma(-b, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-b, r, 1.0);
+    const double e = fma(-b, r, 1.0);
     r = fma(r, e, r);
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
