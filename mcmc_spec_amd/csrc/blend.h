@@ -81,7 +81,8 @@ __device__ __forceinline__ double blend_finish(const double sr, const float sh, 
     const double elo = table_exp2(redc * kl, e2tab);  // 10^(-0.4 A_V k)     mft6.py:62-63
     const double s = redc * dk;
     // eps = 2^s - 1: four series terms (exact to < 1e-14 relative for |s| < 1e-3, and eps only ever scales the
-    // 1e-5-sized H term), else the full exp2
+    // H term, itself <~ 1e-3 of the pixel), else through the table (the library exp2 would park its eleven
+    // coefficients in vector registers for a branch that real extinction curves never take)
     double eps;
     if (fabs(s) < 1e-3) {
         double p = fma_sc(s, kLn2Pow4, kLn2Pow3);
@@ -89,7 +90,7 @@ __device__ __forceinline__ double blend_finish(const double sr, const float sh, 
         p = fma_sc(p, s, kLn2Pow1);
         eps = p * s;
     } else {
-        eps = exp2(s) - 1.0;
+        eps = table_exp2(s, e2tab) - 1.0;
     }
     return elo * fma(eps, (double)sh, sr);
 }

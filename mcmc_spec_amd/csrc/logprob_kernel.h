@@ -168,9 +168,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // tables hold R = lo + (hi - lo) t (float64) and H = hi t (float32): see blend_pixel_rh (blend.h).
 template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, int STAGE = 0>
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
-// CU <=> k T / 256.  256 threads: three per CU -- two for triples, whose twelve corners do not fit 168 VGPRs;
-// 512 threads sharing a CU: two per CU = four waves per SIMD = 128 VGPRs.)
-__global__ void __launch_bounds__(MAXT, MAXT == 256 ? (NS == 2 ? 3 : 2) : (MAXT == 512 && SH) ? 4 : 1)
+// CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
+// SIMD = 128 VGPRs.)
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && SH) ? 4 : 1)
 logprob_kernel(const double *theta, const double *__restrict__ iso_t, const double *__restrict__ iso_g,
                const double *__restrict__ teff_nodes, const double *__restrict__ logg_nodes,
                const uint8_t *__restrict__ present, int niso_nt, int ng_mode_fast,
@@ -252,12 +252,19 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     if (!kRecipe) {  // the recipe's scalars come from an earlier stage's record; no phase 0
         if (tid == 0) { D.lp = P.rec[wk].lp; D.chi_extra = P.rec[wk].chi_extra; D.status = MSX_W_OK; }
     }
-    // the prior terms (f1) depend on theta alone: an idle wave computes them beside the recipe waves, for every
-    // mode (rejected walkers never read them)
-    if (kRecipe && fast && wave == NS) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    constexpr int NC = NS * 4;
+    const int nseg_all = (ne + kSegElems - 1) / kSegElems;
+    const int seg_lo = STAGE == 3 ? myseg : 0, seg_hi = STAGE == 3 ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
+    // The prior terms (f1) depend on theta alone and only the walker's last lines read them: an idle wave computes
+    // them beside the recipe waves -- or, where phase A follows (`early` modes of the blending stages), wave 1 at the
+    // end of phase A, while it would otherwise wait for the slowest wave (rejected walkers never read them).
+    const bool prior_late = kBlend && early;
+    if (kRecipe && fast && wave == NS && !prior_late) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
     if (kRecipe) {
         if (fast) {
-            if (wave < NS) recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
+            if (wave < NS) {
+                recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
+            }
         } else if (wave == 0) {
             const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
             build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
@@ -320,7 +327,6 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     MSX_STAMP(P, wk, 1);
 
     // ---- phase A ------------------------------------------------------------------------------------
-    constexpr int NC = NS * 4;
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
     const float2 *rows_h[NC];   // H = hi t
     double w[NC];
@@ -353,33 +359,58 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     double vmin = INFINITY, vmax = -INFINITY;  // value range of the model vector; NaNs are flagged apart
     bool seen_nan = false;
     constexpr int SUB = vk / U;  // elements per lane and outer trip: 2 (256 threads) or 1
-    const int nseg_all = (ne + kSegElems - 1) / kSegElems;
-    const int seg_lo = STAGE == 3 ? myseg : 0, seg_hi = STAGE == 3 ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
     double qrun = 0.0;  // waves 0..2: their fit sum over the segments so far
     for (int seg = seg_lo; seg < seg_hi; ++seg) {
       double qa[vk][3];
 #pragma unroll
       for (int k = 0; k < vk; ++k) qa[k][0] = qa[k][1] = qa[k][2] = 0.0;
       const int e_end = (seg + 1) * kSegElems < ne ? (seg + 1) * kSegElems : ne;
+      // What follows a pixel pair's model values: the model vector, the fit sums, the value range, the histogram.
+      auto finish_elem = [&](const double2 m2, const double2 f2, const double2 u2, const int ec, const bool live,
+                             auto sub_c) __attribute__((always_inline)) {
+        constexpr int sub = decltype(sub_c)::value;
+        const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
+        const bool ok[U] = {live && pa < npix, live && pb < npix};
+        const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
+        if (PF && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
+        const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+                const double m = mm[u];
+                if (STAGE == 3) model_out[pp[u]] = m;                // the wide path's scratch (read back by STAGE 4)
+                else if (!(GM && STAGE == 2)) model[pp[u]] = m;      // (GM stage 2: the scratch row IS the model vector)
+                const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
+                const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
+                constexpr int slot = sub * U;  // (+ u: both unrolled)
+#pragma unroll
+                for (int k = 0; k < vk; ++k)
+                    if (slot + u == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2_; }
+                vmin = min_nc(vmin, m);
+                vmax = max_nc(vmax, m);
+                seen_nan = seen_nan || (m != m);
+                if (early) atomicAdd(&S.hist[logbin(m)], 1u);
+            }
+        }
+      };
       // The trips of this segment, compiled twice: with the reddening terms (H rows, k, dk, the exp2) and without
       // (A_V <= 0: R rows only).  `redden` is uniform over the workgroup; as a run-time flag inside the loop it cost a
       // scalar branch and a zero-fill per H load.
       auto trips = [&](auto red_c) __attribute__((always_inline)) {
       constexpr bool RED = decltype(red_c)::value;
+      {
       for (int e0 = seg * kSegElems; e0 < e_end; e0 += B * SUB) {
-#pragma unroll
-      for (int sub = 0; sub < SUB; ++sub) {
+        auto one = [&](auto sub_c) __attribute__((always_inline)) {
+        constexpr int sub = decltype(sub_c)::value;
         const int e = e0 + sub * B + tid;
         const bool live = e < e_end;
         const int ec = live ? e : e_end - 1;
-        const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
-        const bool ok[U] = {live && pa < npix, live && pb < npix};
-        const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
-        // one shared 32-bit byte offset per element width: every table is addressed SGPR base + this (wave_ops.h)
         const unsigned int o16 = (unsigned int)ec << 4, o8 = (unsigned int)ec << 3;
-        double2 f2, u2, m2;
+        double2 m2;
         if (!kBlend) {
-            m2 = make_double2(model_in[pp[0]], model_in[pp[1]]);  // blend_tiles_kernel's output for this walker
+            const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
+            // blend_tiles_kernel's output for this walker
+            m2 = make_double2(model_in[pa < npix ? pa : npix - 1], model_in[pb < npix ? pb : npix - 1]);
         } else {
             // the model values of the two pixels (blend.h; the split path's blend kernel runs the same chain).
             // All corners' loads are issued together (192 bytes in flight per lane) -- except in the variant that
@@ -409,28 +440,10 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
             m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, RED, e2tab);
             m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, RED, e2tab);
         }
-        f2 = ld_off(P.f2, o16);
-        u2 = ld_off(P.u2, o16);
-        if (PF && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
-        const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (ok[u]) {
-                const double m = mm[u];
-                if (STAGE == 3) model_out[pp[u]] = m;                // the wide path's scratch (read back by STAGE 4)
-                else if (!(GM && STAGE == 2)) model[pp[u]] = m;      // (GM stage 2: the scratch row IS the model vector)
-                const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
-                const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
-                const int slot = sub * U + u;  // static: sub and u are unrolled
-#pragma unroll
-                for (int k = 0; k < vk; ++k)
-                    if (slot == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2_; }
-                vmin = min_nc(vmin, m);
-                vmax = max_nc(vmax, m);
-                seen_nan = seen_nan || (m != m);
-                if (early) atomicAdd(&S.hist[logbin(m)], 1u);
-            }
-        }
+        finish_elem(m2, ld_off(P.f2, o16), ld_off(P.u2, o16), ec, live, sub_c);
+        };
+        one(std::integral_constant<int, 0>{});
+        if constexpr (SUB == 2) one(std::integral_constant<int, 1>{});
       }
       }
       };
@@ -452,6 +465,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     // bound by the CU's memory pipeline and wave 0's loads are served first, so wave 0 leaves the pixel loop
     // thousands of cycles before the last wave.  (Other modes: inside block_median.)
     if (kRecipe && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+    if (kRecipe && fast && prior_late && wave == 1 && myseg == 0) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
     if (STAGE == 4) {
         // the model vector from the scratch into LDS (the median's passes want it there) ...
         if ((npix & 1) == 0) {

@@ -417,63 +417,97 @@ __device__ __forceinline__ void load_recipe_regs(RecipeRegs &R, const double *__
 // (preloaded pointers), so it runs while the rest of the kernel-argument segment -- which the gates read -- is
 // still in flight.  It is safe for any theta (no memory access depends on it; NaNs fail the range test), and the
 // gates still take precedence in the reported status, like logprior before loglikelihood in the reference.
+// In two halves, so that a kernel variant can publish the NODES (which rows phase A will read) before the weights
+// exist and have every wave request its first table elements while the recipe finishes:
+//   recipe_nodes_regs    A1 + A2 + presence: D.node (canonical order; zeros if the star failed), D.redc
+//   recipe_weights_regs  A4 + gates: D.w, D.stat
 template <int NS>
-__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const RecipeRegs &R, int niso, int nt, int ng, int mode,
-                                  const double *__restrict__ th, WalkerDesc &D, int lane, int64_t wk, const int star) {
-    double t[2 * NS + 2];
+struct RecipeMid {
+    double t[2 * NS + 2];  // (only ever indexed by constants: a run-time index would park the struct in scratch)
+    double ts, rs;         // this wave's star: Teff, and its radius (R1, or R1 times its ratio)
+    double lg, te1, te2, ge1, ge2;
+    int t1, t2, g1, g2, st;
+    int node[4];  // nearest-first order (the order the weights are formed in)
+};
+template <int NS>
+__device__ __forceinline__ void recipe_nodes_regs(const DevProblem &P, const RecipeRegs &R, int niso, int nt, int ng, int mode,
+                                                  const double *__restrict__ th, WalkerDesc &D, int lane, int64_t wk,
+                                                  const int star, RecipeMid<NS> &M) {
 #pragma unroll
-    for (int k = 0; k < 2 * NS + 2; ++k) t[k] = th[k];
+    for (int k = 0; k < 2 * NS + 2; ++k) M.t[k] = th[k];
+    M.ts = M.t[0];
+    M.rs = M.t[NS + 1];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) {
+        M.ts = (star == k) ? M.t[k] : M.ts;
+        M.rs = (star == k) ? M.t[NS + 1] * M.t[NS + 1 + k] : M.rs;
+    }
     MSX_STAMP(P, wk, 9);
-    const double a_v = t[NS];
-    const double plx = t[2 * NS + 1];
-    const double *rad = &t[NS + 1];
-    // ---- A1 + A2 + A4 -----------------------------------------------------------------------------------
+    // ---- A1 + A2 ---------------------------------------------------------------------------------------------
     const double iso_lo = pick4(R.isot, 0), iso_hi = pick4(R.isot, niso - 1);
     int st = MSX_W_OK;
-    int node[4] = {0, 0, 0, 0};
-    double w[4] = {0.0, 0.0, 0.0, 0.0};
-    const double di = 1.0 / plx;  // mft6.py:690
+    M.node[0] = M.node[1] = M.node[2] = M.node[3] = 0;
+    M.lg = 0.0; M.te1 = M.te2 = M.ge1 = M.ge2 = 0.0;
+    M.t1 = M.t2 = M.g1 = M.g2 = 0;
     {
-        const int s = star;
         do {
-            if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; break; }
-            const double lg = iso_interp_regs(R.isot, R.isog, niso, t[s]);  // mft6.py:1149
+            if (!(M.ts >= iso_lo) || !(M.ts <= iso_hi)) { st = MSX_W_VALUEERROR; break; }
+            M.lg = iso_interp_regs(R.isot, R.isog, niso, M.ts);  // mft6.py:1149
             MSX_STAMP(P, wk, 12);
-            int t1, t2, g1, g2;
-            double te1, te2, ge1, ge2;
-            st = bracket_regs(R.tn, nt, t[s], &t1, &t2, &te1, &te2);
-            if (st == MSX_W_OK) st = bracket_regs(R.gn, ng, lg, &g1, &g2, &ge1, &ge2);
+            st = bracket_regs(R.tn, nt, M.ts, &M.t1, &M.t2, &M.te1, &M.te2);
+            if (st == MSX_W_OK) st = bracket_regs(R.gn, ng, M.lg, &M.g1, &M.g2, &M.ge1, &M.ge2);
             if (st != MSX_W_OK) break;
             MSX_STAMP(P, wk, 13);
-            const int n11 = t1 * ng + g1, n12 = t1 * ng + g2, n21 = t2 * ng + g1, n22 = t2 * ng + g2;
+            const int four[4] = {M.t1 * ng + M.g1, M.t1 * ng + M.g2, M.t2 * ng + M.g1, M.t2 * ng + M.g2};
             bool have = true;
-            const int four[4] = {n11, n12, n21, n22};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int nd = uni(four[c]);
                 have = have && (__builtin_amdgcn_readlane(nd < kWave ? R.pres0 : R.pres1, nd & 63) != 0);
             }
             if (!have) { st = MSX_W_KEYERROR; break; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) M.node[c] = four[c];
             MSX_STAMP(P, wk, 14);
-            const double a = (g1 == g2) ? 0.0 : (lg - ge1) / (ge2 - ge1);
-            const double b = (t1 == t2) ? 0.0 : (t[s] - te1) / (te2 - te1);
-            const double r = (s == 0) ? rad[0] : rad[0] * rad[s];
-            const double q = r * kRsunCm / (di * kPcCm);  // mft6.py:691,700
-            const double sc = q * q;
-            node[0] = n11; w[0] = (1.0 - b) * (1.0 - a) * sc;
-            node[1] = n12; w[1] = (1.0 - b) * a * sc;
-            node[2] = n21; w[2] = b * (1.0 - a) * sc;
-            node[3] = n22; w[3] = b * a * sc;
-            sort4_by_node(node, w);  // canonical corner order (blend.h): a function of the grid cell alone
         } while (false);
+    }
+    M.st = st;
+    if (lane == 0) {
+        int sorted[4];
+        double order[4] = {0.0, 1.0, 2.0, 3.0};  // (the weights take the same exchanges in recipe_weights_regs)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sorted[c] = M.node[c];
+        sort4_by_node(sorted, order);  // canonical corner order (blend.h): a function of the grid cell alone
+#pragma unroll
+        for (int c = 0; c < 4; ++c) D.node[4 * star + c] = sorted[c];
+        if (star == 0) D.redc = redden_rule(mode, P.use_av, M.t[NS]) ? -0.4 * kLog2Of10 * M.t[NS] : 0.0;
+    }
+}
+template <int NS>
+__device__ __forceinline__ void recipe_weights_regs(const DevProblem &P, int mode, WalkerDesc &D, int lane, int64_t wk,
+                                                    const int star, RecipeMid<NS> &M) {
+    const double plx = M.t[2 * NS + 1];
+    const int st = M.st;
+    double w[4] = {0.0, 0.0, 0.0, 0.0};
+    if (st == MSX_W_OK) {  // ---- A4 ---------------------------------------------------------------------------
+        const double di = 1.0 / plx;  // mft6.py:690
+        const double a = (M.g1 == M.g2) ? 0.0 : (M.lg - M.ge1) / (M.ge2 - M.ge1);
+        const double b = (M.t1 == M.t2) ? 0.0 : (M.ts - M.te1) / (M.te2 - M.te1);
+        const double q = M.rs * kRsunCm / (di * kPcCm);  // mft6.py:691,700
+        const double sc = q * q;
+        w[0] = (1.0 - b) * (1.0 - a) * sc;
+        w[1] = (1.0 - b) * a * sc;
+        w[2] = b * (1.0 - a) * sc;
+        w[3] = b * a * sc;
+        sort4_by_node(M.node, w);
     }
     MSX_STAMP(P, wk, 10);
     // ---- the hard gates of the prior (mft6.py:1227-1230 binary, :1347-1350 triple) -----------------------
     bool alive = true;
 #pragma unroll
-    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(t[k]);  // emcee refuses non-finite coords
+    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(M.t[k]);  // emcee refuses non-finite coords
     if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
-        alive = alive && prior_gates<NS>(P, t);
+        alive = alive && prior_gates<NS>(P, M.t);
     }
     if (!alive) {
         if (lane == 0) D.stat[star] = MSX_W_REJECT;
@@ -486,12 +520,19 @@ __device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const Rec
     if (lane == 0) {
         if (st == MSX_W_OK) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { D.node[4 * star + c] = node[c]; D.w[4 * star + c] = w[c]; }
-            if (star == 0) D.redc = redden_rule(mode, P.use_av, a_v) ? -0.4 * kLog2Of10 * a_v : 0.0;
+            for (int c = 0; c < 4; ++c) D.w[4 * star + c] = w[c];
         }
         D.stat[star] = st;
     }
     MSX_STAMP(P, wk, 11);
+}
+// (both halves back to back: the variants that do not separate them)
+template <int NS>
+__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const RecipeRegs &R, int niso, int nt, int ng, int mode,
+                                  const double *__restrict__ th, WalkerDesc &D, int lane, int64_t wk, const int star) {
+    RecipeMid<NS> M;
+    recipe_nodes_regs<NS>(P, R, niso, nt, ng, mode, th, D, lane, wk, star, M);
+    recipe_weights_regs<NS>(P, mode, D, lane, wk, star, M);
 }
 
 // Part 2 (off the critical path): the Gaussian prior terms (f1) and the contrast / photometry chi^2

@@ -65,25 +65,24 @@ def main():
         print('  first start -> last end: {} cycles'.format(int(o[:, 7].max() - o[:, 0].min())))
         return
     d = np.diff(out[:, :8].astype(np.int64), axis=1)
-    names = ['phase0 recipe', 'phaseA blend', 'reduce q/minmax', 'radix select', 'second rank', 'phaseC chi2', 'reduce chi2']
+    names = ['phase0 recipe', 'phaseA blend', 'fit sums + range (barriers)', 'median + chi2 pass', '-', 'tail', 'final reduce']
     tot = (out[:, 7] - out[:, 0]).astype(np.int64)
     print('walkers {} block {}: median total {} cycles'.format(n, args.block or 'auto', int(np.median(tot))))
     for i, nm in enumerate(names):
         print('  {:18s} median {:8d} cycles  ({:5.1f} %)'.format(nm, int(np.median(d[:, i])), 100 * np.median(d[:, i]) / np.median(tot)))
-    e = out[:, [0, 8, 9, 10, 11, 12, 13, 1]].astype(np.int64)
+    # wave 0's chain through phase 0, in time order (recipe.h: stamps 9, 12, 13, 14, 10, 11)
+    e = out[:, [0, 8, 9, 12, 13, 14, 10, 11, 1]].astype(np.int64)
     de = np.diff(e, axis=1)
-    for i, nm in enumerate(['stage tables+barrier', 'theta load', 'prior', 'iso+bracket', 'band loads+log10', 'chi combine', 'barrier']):
+    for i, nm in enumerate(['(entry)', 'theta load', 'iso interp', 'two brackets', 'presence mask', 'weights', 'gates + LDS store',
+                            'barrier (other waves)']):
         print('    phase0/{:22s} median {:8d} cycles'.format(nm, int(np.median(de[:, i]))))
-    e2 = out[:, [10, 12, 13, 14, 11]].astype(np.int64)
-    for i, nm in enumerate(['iso interp', 'two brackets', 'presence mask', 'weights + LDS store']):
-        print('    recipe/{:24s} median {:8d} cycles'.format(nm, int(np.median(np.diff(e2, axis=1)[:, i]))))
     med = np.zeros((n, 8), dtype=np.uint64)
     fm = eng.ctx.lib.msx_diag_read_med_stamps
     fm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     fm.restype = C.c_int
     assert fm(eng.ctx.h, n, med.ctypes.data) == 0
     dm = np.diff(med[:, :5].astype(np.int64), axis=1)
-    for i, nm in enumerate(['hist fill+barrier', 'bin scan (2 barriers)', 'gather+barrier', 'all-pairs rank+barrier']):
+    for i, nm in enumerate(['(entry)', 'bin scan', 'chi2 + gather pass + barrier', 'rank']):
         print('    median/{:24s} median {:8d} cycles'.format(nm, int(np.median(dm[:, i]))))
     print('    median/candidates: median {} max {}'.format(int(np.median(med[:, 6])), int(med[:, 6].max())))
     span = int(out[:, 7].max() - out[:, 0].min())
