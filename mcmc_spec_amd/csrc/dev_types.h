@@ -116,6 +116,10 @@ struct WalkerDesc {
     int64_t smp_nacc;                     // its acceptance count so far
 };
 
+// The recipe's small tables, gathered into ONE block so that a single preloaded pointer reaches them all (fixed
+// offsets: the register-resident recipe takes at most 256 isochrone points, 64 Teff x 32 logg nodes; the presence
+// mask is one uint32 per Teff node, bit g = node (t, g) is in the grid).
+constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPresent = 5120, kRecipeBlockBytes = 5376;
 constexpr int kTileWalkers = 8;     // split path: walkers that share one load of the pair rows
 constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the wide path
 constexpr int kSegBins = 2048;      // (= kLogBins, median.h)

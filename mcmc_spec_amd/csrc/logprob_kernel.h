@@ -171,14 +171,21 @@ template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = f
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && SH) ? 4 : 1)
-logprob_kernel(const double *theta, const double *__restrict__ iso_t, const double *__restrict__ iso_g,
-               const double *__restrict__ teff_nodes, const double *__restrict__ logg_nodes,
-               const uint8_t *__restrict__ present, int niso_nt, int ng_mode_fast,
-               DevProblem P, int64_t n, int ndim, double *__restrict__ logp, int32_t *__restrict__ status) {
-    // The leading arguments (14 dwords) are compiled for KERNARG PRELOAD (-mllvm -amdgpu-kernarg-preload-count):
-    // the command processor delivers them in SGPRs at wave start, so theta and the recipe's small tables can be
-    // requested in the first instructions, ~1.5 us before the 1.2 KB DevProblem (fetched from the kernel-argument
-    // segment like any argument) is available.  They duplicate P.iso_t, ... and pack niso|nt<<16, ng|mode<<8|fast<<16.
+logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
+               double gate_tmin, double gate_tmax, DevProblem P, double *__restrict__ logp, int32_t *__restrict__ status) {
+    // The leading arguments (12 dwords; the preload takes 14) are compiled for KERNARG PRELOAD (-mllvm
+    // -amdgpu-kernarg-preload-count): the command processor delivers them in SGPRs at wave start, so theta and the
+    // recipe's small tables are requested in the first instructions, while the 1.2 KB DevProblem (fetched from the
+    // kernel-argument segment like any argument: a memory round trip, then a scalar-cache access per field) is
+    // still on its way.  Everything the walker's critical chain needs up to its weights is among them:
+    //   rblk            the recipe's tables in one block (dev_types.h: isochrone Teff / logg, the grid's node lists and
+    //                   per-Teff-node presence bits at fixed offsets; from P.iso_t, P.iso_g, P.teff_nodes, ...)
+    //   niso_nt         niso | nt << 16
+    //   ng_mode_fast    ng | mode << 8 | fast << 16 | sampler << 17 | dist_fit << 18 | use_av << 19 | segments << 24
+    //   n               the batch size (ndim is 2 NS + 2, checked by the host)
+    //   gate_tmin/tmax  the Teff box of the prior's hard gates (= P.tmin, P.tmax)
+    const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
+    constexpr int ndim = 2 * NS + 2;
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
@@ -188,12 +195,20 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
+    const bool smp_on = (ng_mode_fast >> 17) & 1;  // device-resident sampler: theta is a proposal built here (= P.smp_on)
     const int nsegs = STAGE == 3 ? (ng_mode_fast >> 24) & 0xff : 1;  // STAGE 3: workgroups per walker
     const int64_t wk = STAGE == 3 ? blockIdx.x / nsegs : blockIdx.x;
     const int myseg = STAGE == 3 ? (int)(blockIdx.x - wk * nsegs) : 0;
     RecipeRegs RR;
-    if (kRecipe && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, iso_t, iso_g, teff_nodes, logg_nodes, present, niso, nt, ng, threadIdx.x & 63);
+    if (kRecipe && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
+    // theta, requested before anything that waits for the kernel-argument segment (the recipe waves; the sampler
+    // builds its proposal below instead)
+    // (one VECTOR load, lane k takes coordinate k: a scalar load would share its counter with the kernel-argument
+    // fetches below and be waited for together with them)
+    double theta_lane = 0.0;
+    if (kRecipe && fast && !smp_on && (threadIdx.x >> 6) < NS && (threadIdx.x & 63) < ndim)
+        theta_lane = theta[wk * ndim + (threadIdx.x & 63)];
     if (!kRecipe && P.rec[wk].status != MSX_W_OK) return;  // an earlier stage wrote this walker's final value (uniform branch)
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
     const double *__restrict__ model_in = (STAGE == 2 || STAGE == 4) ? P.model_scratch + wk * P.npix : nullptr;
@@ -212,7 +227,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
     const double *th_row = theta + wk * ndim;
-    if (P.smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
+    if (smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
         // two dependent levels only: {own index, complement index, z} -> the two coordinate rows.  The proposal
         // goes to LDS (the recipe waves read it there, no round trip through memory); wave 1 meanwhile fetches
         // what the accept step will need at the very end.
@@ -240,6 +255,7 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
         }
         __syncthreads();
         th_row = D.theta;
+        if (kRecipe && fast && wave < NS && lane < ndim) theta_lane = D.theta[lane];
     }
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
@@ -263,7 +279,10 @@ logprob_kernel(const double *theta, const double *__restrict__ iso_t, const doub
     if (kRecipe) {
         if (fast) {
             if (wave < NS) {
-                recipe_part1_regs<NS>(P, RR, niso, nt, ng, mode, th_row, D, lane, wk, wave);
+                double tv[ndim];
+#pragma unroll
+                for (int k = 0; k < ndim; ++k) tv[k] = readlane_f64(theta_lane, k);
+                recipe_part1_regs<NS>(P, gates, RR, niso, nt, ng, mode, theta_lane, tv, D, lane, wk, wave);
             }
         } else if (wave == 0) {
             const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};

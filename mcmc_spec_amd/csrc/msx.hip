@@ -119,6 +119,7 @@ struct msx_ctx {
     // 256 CUs draw 11 -- the L2 -> CU fabric, not the CU count, bounds it, and the second launch costs more than it saves.
     int64_t wide_max_blocks_per_cu = 0;
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
+    unsigned char *d_recipe_block = nullptr;  // ... and its tables in one block (dev_types.h), freed with the problem
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
 };
 static void sampler_free(msx_ctx *c);
@@ -300,10 +301,10 @@ template <int STAGE>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
     const dim3 g((unsigned)(STAGE == 3 ? A.n * c->nseg : A.n));
     const size_t lds = sizeof(double) * (size_t)P.npix;
-#define MSX_LEAD_ARGS A.theta, P.iso_t, P.iso_g, P.teff_nodes, P.logg_nodes, P.present, A.niso_nt, A.ng_mode_fast
+#define MSX_LEAD_ARGS A.theta, (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax
 #define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                      \
     hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, STAGE>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
-                       A.n, A.ndim, A.logp, A.status)
+                       A.logp, A.status)
     // dynamic LDS: the model vector; PF adds u and the data flux in the tables' pair layout
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
     if constexpr (STAGE == 1) {
@@ -680,7 +681,30 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     c->model_in_global = model_in_global;
     c->pf_ok = !model_in_global && need_lds + 16 + 32 * npair <= 147 * 1024;  // model + u2 + f2, + ~12 KB static <= 160 KB
     if ((rc = raise_dynamic_lds_limits(c))) return rc;
-    c->recipe_fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= kWave && P.nt * P.ng <= 2 * kWave && P.nav + 1 <= 2 * kWave;
+    c->recipe_fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= 32 && P.nav + 1 <= 2 * kWave;
+    c->d_recipe_block = nullptr;
+    if (c->recipe_fast) {  // the recipe's tables behind one (preloaded) pointer
+        void *blk = nullptr;
+        HIP_TRY(c, hipMalloc(&blk, kRecipeBlockBytes));
+        tr.push_back(blk);
+        c->d_recipe_block = (unsigned char *)blk;
+        HIP_TRY(c, hipMemsetAsync(blk, 0, kRecipeBlockBytes, c->stream));
+        const hipMemcpyKind dd = hipMemcpyDeviceToDevice;
+        HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbIsoT, P.iso_t, sizeof(double) * P.niso, dd, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbIsoG, P.iso_g, sizeof(double) * P.niso, dd, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbTeff, P.teff_nodes, sizeof(double) * P.nt, dd, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbLogg, P.logg_nodes, sizeof(double) * P.ng, dd, c->stream));
+        std::vector<uint8_t> pres((size_t)(P.nt * P.ng));
+        HIP_TRY(c, hipMemcpyAsync(pres.data(), P.present, pres.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> pmask((size_t)P.nt, 0u);
+        for (int64_t t = 0; t < P.nt; ++t)
+            for (int64_t g = 0; g < P.ng; ++g)
+                if (pres[(size_t)(t * P.ng + g)]) pmask[(size_t)t] |= 1u << g;
+        HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbPresent, pmask.data(), sizeof(uint32_t) * pmask.size(),
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     // Scratch of the split path, sized once here so that no launch ever allocates or synchronises: a batch is
     // cut into sub-batches whose model vectors (walkers x npix doubles) stay inside the Infinity Cache between the
     // blend kernel that writes them and the median / chi^2 kernel that reads them back.
@@ -763,7 +787,8 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     LaunchArgs A;
     A.ndim = ndim; A.mode = mode; A.s = s;
     A.niso_nt = (int)(std::min<int64_t>(Pc.niso, 0xffff) | ((int64_t)std::min<int64_t>(Pc.nt, 0x7fff) << 16));
-    A.ng_mode_fast = (int)std::min<int64_t>(Pc.ng, 0xff) | (mode << 8) | ((fast ? 1 : 0) << 16);
+    A.ng_mode_fast = (int)std::min<int64_t>(Pc.ng, 0xff) | (mode << 8) | ((fast ? 1 : 0) << 16) | ((Pc.smp_on ? 1 : 0) << 17) |
+                     ((Pc.dist_fit ? 1 : 0) << 18) | ((Pc.use_av ? 1 : 0) << 19);
 
     // ---- which form of the path -------------------------------------------------------------------------
     // split (split_kernels.h): many walkers (shared row loads) or long spectra (pixels over all CUs).  Only the

@@ -100,8 +100,15 @@ __device__ void build_desc(const DevProblem &P, const double *teff, const double
 //   no dist_fit, binary: T box, both radius entries >= 0.05                                    mft6.py:1286
 //   no dist_fit, triple: T box, the two RATIOS >= 0.05 (R1 is not tested), plx >= 0            mft6.py:1411
 //   and A_V >= 0 whenever extinction is fitted                                                 mft6.py:1229
+// what the gates read besides theta.  The fast recipe gets these from PRELOADED kernel arguments (logprob_kernel):
+// fetched from the DevProblem they would each cost a scalar-cache round trip in the walker's critical chain.
+struct GateArgs {
+    double tmin, tmax;
+    bool dist_fit, use_av;
+};
+__device__ __forceinline__ GateArgs gates_of(const DevProblem &P) { return GateArgs{P.tmin, P.tmax, P.dist_fit != 0, P.use_av != 0}; }
 template <int NS>
-__device__ __forceinline__ bool prior_gates(const DevProblem &P, const double *t) {
+__device__ __forceinline__ bool prior_gates(const GateArgs &P, const double *t) {
     const double a_v = t[NS], plx = t[2 * NS + 1];
     const double *rad = t + NS + 1;
     bool ok = true;
@@ -197,7 +204,7 @@ __device__ __forceinline__ void build_recipe_wave(const DevProblem &P, const Rec
     int st = MSX_W_OK;
     double lp = 0.0;
     if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) {
-        alive = alive && prior_gates<NS>(P, t);
+        alive = alive && prior_gates<NS>(gates_of(P), t);
         if (alive && P.use_av) {
             if (P.nav > 0) {
                 const double d = 1.0 / plx;  // pc, mft6.py:1233
@@ -348,7 +355,7 @@ __device__ __forceinline__ double pick2(const double (&r)[2], int idx) {  // idx
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// np.interp on the register-resident isochrone; caller checked the range
+// np.interp on a register-resident table (search by count; the radius prior's luminosity lookup); caller checked the range
 __device__ __forceinline__ double iso_interp_regs(const double (&xs)[4], const double (&ys)[4], int n, double x) {
     int cnt = 0;
 #pragma unroll
@@ -361,7 +368,100 @@ __device__ __forceinline__ double iso_interp_regs(const double (&xs)[4], const d
     return slope * (x - x0) + y0;
 }
 
-// sorted-node bracket on a register-resident node list (lane i holds nodes[i], pads +inf)
+// ------------------------------------------------------------------------------------------------
+// The register-resident recipe (the usual case: <= 256 isochrone points, <= 64 Teff and <= 32 logg nodes).
+// One wave per star.  The tables are loaded in the kernel's very first instructions from a pointer that arrives
+// PRELOADED in SGPRs (see logprob_kernel), one table entry per lane TOGETHER WITH ITS RIGHT NEIGHBOUR, and
+// everything that does not depend on theta (the isochrone's slopes) is computed while theta is still in flight.
+// When theta arrives every lane evaluates "its" interval speculatively -- lane l: is x in [x_l, x_l+1), and if so
+// what is the interpolated value / the nearest node / the bracket -- and a ballot picks the one lane that is right:
+// a handful of dependent instructions where a search by count + readlane took dozens (the chain from theta to the
+// walker's weights is the kernel's start-up latency: nothing else can begin before it ends).
+// ------------------------------------------------------------------------------------------------
+struct RecipeRegs {
+    double isot[4], isot_n[4], isog[4], slope[4];  // isochrone element i = lane + 64 k: x_i, x_i+1 (+inf past the end),
+                                                   // y_i, (y_i+1 - y_i) / (x_i+1 - x_i) (0 for the last element)
+    double tn, tn_n, gn, gn_n;                     // Teff / logg node l and l + 1 (+inf pads)
+    unsigned int m0, m1;                           // presence bits (bit g: node (l, g) is in the grid) of Teff node l, l + 1
+    double iso_lo, iso_hi;                         // (uniform) the isochrone's Teff range
+    double t_first, t_last, g_first, g_last;       // (uniform) first / last node
+    unsigned int m_first, m_last;                  // (uniform) presence bits of the first / last Teff node
+};
+__device__ __forceinline__ void load_recipe_regs(RecipeRegs &R, const unsigned char *__restrict__ rblk, int niso, int nt, int ng,
+                                                 int lane) {
+    const double *__restrict__ iso_t = reinterpret_cast<const double *>(rblk + kRbIsoT);
+    const double *__restrict__ iso_g = reinterpret_cast<const double *>(rblk + kRbIsoG);
+    const double *__restrict__ teff_nodes = reinterpret_cast<const double *>(rblk + kRbTeff);
+    const double *__restrict__ logg_nodes = reinterpret_cast<const double *>(rblk + kRbLogg);
+    const unsigned int *__restrict__ pmask = reinterpret_cast<const unsigned int *>(rblk + kRbPresent);
+    double yn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + kWave * k;
+        R.isot[k] = i < niso ? iso_t[i] : INFINITY;
+        R.isog[k] = i < niso ? iso_g[i] : 0.0;
+        R.isot_n[k] = i + 1 < niso ? iso_t[i + 1] : INFINITY;
+        yn[k] = i + 1 < niso ? iso_g[i + 1] : 0.0;
+    }
+    R.tn = lane < nt ? teff_nodes[lane] : INFINITY;
+    R.tn_n = lane + 1 < nt ? teff_nodes[lane + 1] : INFINITY;
+    R.gn = lane < ng ? logg_nodes[lane] : INFINITY;
+    R.gn_n = lane + 1 < ng ? logg_nodes[lane + 1] : INFINITY;
+    R.m0 = lane < nt ? pmask[lane] : 0u;
+    R.m1 = lane + 1 < nt ? pmask[lane + 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + kWave * k;
+        R.slope[k] = i + 1 < niso ? (yn[k] - R.isog[k]) / (R.isot_n[k] - R.isot[k]) : 0.0;  // np.interp's slope
+    }
+    R.iso_lo = pick4(R.isot, 0);
+    R.iso_hi = pick4(R.isot, niso - 1);
+    R.t_first = readlane_f64(R.tn, 0);
+    R.t_last = readlane_f64(R.tn, nt - 1);
+    R.g_first = readlane_f64(R.gn, 0);
+    R.g_last = readlane_f64(R.gn, ng - 1);
+    R.m_first = (unsigned int)__builtin_amdgcn_readlane((int)R.m0, 0);
+    R.m_last = (unsigned int)__builtin_amdgcn_readlane((int)R.m0, nt - 1);
+}
+
+// np.interp on the register-resident isochrone for lo <= x <= hi (the caller checked the range).  Exactly one
+// (register, lane) holds the interval [x_i, x_i+1) that contains x -- the LAST i with x_i <= x, like the
+// search-by-count (duplicated abscissae: their zero-length intervals are never hit).  x on a node gives y_i exactly.
+__device__ __forceinline__ double iso_interp_lanes(const RecipeRegs &R, double x) {
+    double v = 0.0;
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool h = R.isot[k] <= x && x < R.isot_n[k];
+        const double val = R.slope[k] * (x - R.isot[k]) + R.isog[k];
+        v = h ? val : v;
+        hit = hit || h;
+    }
+    const int L = uni(__ffsll((long long)__ballot(hit)) - 1);
+    return readlane_f64(v, L & 63);  // (no lane: x is NaN -- the range check sent it away already)
+}
+
+// The reference's bracket of v in a sorted node list (mft6.py:439-477: nearest node first, ties to the lower, the
+// other side next; on a node both are that node; below the first node the "other" index -1 wraps to the LAST node;
+// beyond the last there is no other node -> IndexError), evaluated by the lane whose interval [n_l, n_l+1) holds v.
+struct LaneBracket {
+    int i1, i2, st;
+    double e1, e2;
+    bool own;
+};
+__device__ __forceinline__ LaneBracket lane_bracket(double nl, double nn, int l, int n, double v) {
+    LaneBracket B;
+    B.own = nl <= v && v < nn;                      // (pads are +inf: never for l >= n)
+    const bool up = fabs(nn - v) < fabs(nl - v);   // the upper node is strictly nearer
+    const bool eq = nl == v;
+    B.i1 = up ? l + 1 : l;
+    B.i2 = (up || eq) ? l : l + 1;
+    B.e1 = up ? nn : nl;
+    B.e2 = (up || eq) ? nl : nn;
+    B.st = (!up && !eq && l + 1 >= n) ? MSX_W_INDEXERROR : MSX_W_OK;
+    return B;
+}
+// the same bracket by count + readlane (uniform result): v is NaN, or some other case no lane owns
 __device__ __forceinline__ int bracket_regs(double nodes, int n, double v, int *i1, int *i2, double *e1, double *e2) {
     const int j = uni(__popcll(__ballot(nodes <= v))) - 1;
     int best;
@@ -375,164 +475,131 @@ __device__ __forceinline__ int bracket_regs(double nodes, int n, double v, int *
     else if (nb > v) other = best - 1;
     else other = best + 1;
     if (other == -1) other = n - 1;
+    *i1 = best;
+    *i2 = best;
+    *e1 = nb;
+    *e2 = nb;
     if (other >= n) return MSX_W_INDEXERROR;
     other = uni(other);
-    *i1 = best;
     *i2 = other;
-    *e1 = nb;
     *e2 = readlane_f64(nodes, other);
     return MSX_W_OK;
 }
 
-// The small tables of the register-resident recipe: loaded by the recipe waves in the kernel's very first
-// instructions, from pointers that arrive PRELOADED in SGPRs (the leading kernel arguments, see logprob_kernel),
-// so these loads do not wait for the 1.5 us fetch of the kernel-argument segment.
-struct RecipeRegs {
-    double isot[4], isog[4];  // isochrone Teff / logg, element i in lane i % 64 of register i / 64 (pads +inf / 0)
-    double tn, gn;            // Teff / logg node lists, one node per lane (pads +inf)
-    int pres0, pres1;         // presence mask of nodes 0..63 / 64..127
-};
-__device__ __forceinline__ void load_recipe_regs(RecipeRegs &R, const double *__restrict__ iso_t,
-                                                 const double *__restrict__ iso_g, const double *__restrict__ teff_nodes,
-                                                 const double *__restrict__ logg_nodes, const uint8_t *__restrict__ present,
-                                                 int niso, int nt, int ng, int lane) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + kWave * k;
-        const bool ok = i < niso;
-        R.isot[k] = ok ? iso_t[i] : INFINITY;
-        R.isog[k] = ok ? iso_g[i] : 0.0;
+// Part 1 (gates phase A): the gates, A1 logg, A2 brackets + presence, A4 weights.  Writes D.node, D.w, D.redc (star
+// 0's wave), D.stat.  `theta_lane`: lane k < 2 NS + 2 holds coordinate k (the kernel's first load); tv: the same
+// values, uniform.  The gates of the prior (mft6.py:1227-1230 binary, :1347-1350 triple; emcee refuses non-finite
+// coordinates) are ONE compare per lane against that lane's bounds -- off the chain altogether; they still take
+// precedence in the reported status, like logprior before loglikelihood in the reference.  The chain itself is safe
+// for any theta: no memory access depends on it.
+template <int NS>
+__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const GateArgs &G, const RecipeRegs &R, int niso, int nt,
+                                                  int ng, int mode, const double theta_lane, const double (&tv)[2 * NS + 2],
+                                                  WalkerDesc &D, int lane, int64_t wk, const int star) {
+    constexpr int ND = 2 * NS + 2;
+    MSX_STAMP(P, wk, 9);
+    // ---- the gates: lane k tests coordinate k ------------------------------------------------------------------
+    bool alive;
+    {
+        double lo = -INFINITY, hi = INFINITY;
+        if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
+            if (lane < NS) { lo = G.tmin; hi = G.tmax; }
+            if (lane == NS && G.use_av) lo = 0.0;
+            if (G.dist_fit) {
+                if (lane > NS && lane <= 2 * NS) lo = 0.05;
+                if (NS == 2 && lane == NS + 1) hi = 1.5;
+                if (lane == 2 * NS + 1) { lo = NS == 2 ? 1.0 / 3000 : 1.0 / 1000; hi = 1.0 / 4; }
+            } else if (NS == 2) {
+                if (lane > NS && lane <= 2 * NS) lo = 0.05;
+            } else {
+                if (lane > NS + 1 && lane <= 2 * NS) lo = 0.05;
+                if (lane == 2 * NS + 1) lo = 0.0;
+            }
+        }
+        const bool ok = lane >= ND || (isfinite(theta_lane) && !(theta_lane < lo) && !(theta_lane > hi));
+        alive = __ballot(ok) == ~0ull;
     }
-    R.tn = lane < nt ? teff_nodes[lane] : INFINITY;
-    R.gn = lane < ng ? logg_nodes[lane] : INFINITY;
-    const int nn = nt * ng;
-    R.pres0 = lane < nn ? (int)present[lane] : 0;
-    R.pres1 = lane + kWave < nn ? (int)present[lane + kWave] : 0;
-}
-
-// Part 1 (gates phase A): A1 logg, A2 brackets, A4 weights, then the finite + box check.  One wave per star
-// (wave `star` of the block): the two or three dependent lookup chains run side by side; every wave evaluates the
-// (cheap) gates itself and reports through D.stat[star].  Writes D.node, D.w, D.redc, D.stat.
-// Order matters for latency, not for the result: everything up to the weights needs only theta and the tables
-// (preloaded pointers), so it runs while the rest of the kernel-argument segment -- which the gates read -- is
-// still in flight.  It is safe for any theta (no memory access depends on it; NaNs fail the range test), and the
-// gates still take precedence in the reported status, like logprior before loglikelihood in the reference.
-// In two halves, so that a kernel variant can publish the NODES (which rows phase A will read) before the weights
-// exist and have every wave request its first table elements while the recipe finishes:
-//   recipe_nodes_regs    A1 + A2 + presence: D.node (canonical order; zeros if the star failed), D.redc
-//   recipe_weights_regs  A4 + gates: D.w, D.stat
-template <int NS>
-struct RecipeMid {
-    double t[2 * NS + 2];  // (only ever indexed by constants: a run-time index would park the struct in scratch)
-    double ts, rs;         // this wave's star: Teff, and its radius (R1, or R1 times its ratio)
-    double lg, te1, te2, ge1, ge2;
-    int t1, t2, g1, g2, st;
-    int node[4];  // nearest-first order (the order the weights are formed in)
-};
-template <int NS>
-__device__ __forceinline__ void recipe_nodes_regs(const DevProblem &P, const RecipeRegs &R, int niso, int nt, int ng, int mode,
-                                                  const double *__restrict__ th, WalkerDesc &D, int lane, int64_t wk,
-                                                  const int star, RecipeMid<NS> &M) {
-#pragma unroll
-    for (int k = 0; k < 2 * NS + 2; ++k) M.t[k] = th[k];
-    M.ts = M.t[0];
-    M.rs = M.t[NS + 1];
+    // this wave's star: Teff, and its radius (R1, or R1 times its ratio)
+    double ts = tv[0], rs = tv[NS + 1];
 #pragma unroll
     for (int k = 1; k < NS; ++k) {
-        M.ts = (star == k) ? M.t[k] : M.ts;
-        M.rs = (star == k) ? M.t[NS + 1] * M.t[NS + 1 + k] : M.rs;
+        ts = (star == k) ? tv[k] : ts;
+        rs = (star == k) ? tv[NS + 1] * tv[NS + 1 + k] : rs;
     }
-    MSX_STAMP(P, wk, 9);
-    // ---- A1 + A2 ---------------------------------------------------------------------------------------------
-    const double iso_lo = pick4(R.isot, 0), iso_hi = pick4(R.isot, niso - 1);
-    int st = MSX_W_OK;
-    M.node[0] = M.node[1] = M.node[2] = M.node[3] = 0;
-    M.lg = 0.0; M.te1 = M.te2 = M.ge1 = M.ge2 = 0.0;
-    M.t1 = M.t2 = M.g1 = M.g2 = 0;
-    {
-        do {
-            if (!(M.ts >= iso_lo) || !(M.ts <= iso_hi)) { st = MSX_W_VALUEERROR; break; }
-            M.lg = iso_interp_regs(R.isot, R.isog, niso, M.ts);  // mft6.py:1149
-            MSX_STAMP(P, wk, 12);
-            st = bracket_regs(R.tn, nt, M.ts, &M.t1, &M.t2, &M.te1, &M.te2);
-            if (st == MSX_W_OK) st = bracket_regs(R.gn, ng, M.lg, &M.g1, &M.g2, &M.ge1, &M.ge2);
-            if (st != MSX_W_OK) break;
-            MSX_STAMP(P, wk, 13);
-            const int four[4] = {M.t1 * ng + M.g1, M.t1 * ng + M.g2, M.t2 * ng + M.g1, M.t2 * ng + M.g2};
-            bool have = true;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int nd = uni(four[c]);
-                have = have && (__builtin_amdgcn_readlane(nd < kWave ? R.pres0 : R.pres1, nd & 63) != 0);
-            }
-            if (!have) { st = MSX_W_KEYERROR; break; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) M.node[c] = four[c];
-            MSX_STAMP(P, wk, 14);
-        } while (false);
-    }
-    M.st = st;
-    if (lane == 0) {
-        int sorted[4];
-        double order[4] = {0.0, 1.0, 2.0, 3.0};  // (the weights take the same exchanges in recipe_weights_regs)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sorted[c] = M.node[c];
-        sort4_by_node(sorted, order);  // canonical corner order (blend.h): a function of the grid cell alone
-#pragma unroll
-        for (int c = 0; c < 4; ++c) D.node[4 * star + c] = sorted[c];
-        if (star == 0) D.redc = redden_rule(mode, P.use_av, M.t[NS]) ? -0.4 * kLog2Of10 * M.t[NS] : 0.0;
-    }
-}
-template <int NS>
-__device__ __forceinline__ void recipe_weights_regs(const DevProblem &P, int mode, WalkerDesc &D, int lane, int64_t wk,
-                                                    const int star, RecipeMid<NS> &M) {
-    const double plx = M.t[2 * NS + 1];
-    const int st = M.st;
-    double w[4] = {0.0, 0.0, 0.0, 0.0};
-    if (st == MSX_W_OK) {  // ---- A4 ---------------------------------------------------------------------------
-        const double di = 1.0 / plx;  // mft6.py:690
-        const double a = (M.g1 == M.g2) ? 0.0 : (M.lg - M.ge1) / (M.ge2 - M.ge1);
-        const double b = (M.t1 == M.t2) ? 0.0 : (M.ts - M.te1) / (M.te2 - M.te1);
-        const double q = M.rs * kRsunCm / (di * kPcCm);  // mft6.py:691,700
-        const double sc = q * q;
-        w[0] = (1.0 - b) * (1.0 - a) * sc;
-        w[1] = (1.0 - b) * a * sc;
-        w[2] = b * (1.0 - a) * sc;
-        w[3] = b * a * sc;
-        sort4_by_node(M.node, w);
-    }
-    MSX_STAMP(P, wk, 10);
-    // ---- the hard gates of the prior (mft6.py:1227-1230 binary, :1347-1350 triple) -----------------------
-    bool alive = true;
-#pragma unroll
-    for (int k = 0; k < 2 * NS + 2; ++k) alive = alive && isfinite(M.t[k]);  // emcee refuses non-finite coords
-    if (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR) {
-        alive = alive && prior_gates<NS>(P, M.t);
-    }
-    if (!alive) {
-        if (lane == 0) D.stat[star] = MSX_W_REJECT;
-        return;
-    }
-    if (mode == MSX_MODE_LOGPRIOR) {  // no spectrum pass: the prior terms finish the job
-        if (lane == 0) D.stat[star] = MSX_W_OK;
-        return;
-    }
-    if (lane == 0) {
-        if (st == MSX_W_OK) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) D.w[4 * star + c] = w[c];
+    const double plx = tv[2 * NS + 1];
+    const double q = fast_div(rs * kRsunCm, fast_div(1.0, plx) * kPcCm);  // mft6.py:690-691,700
+    const double sc = q * q;
+    // ---- A2, Teff: needs theta alone -----------------------------------------------------------------------------
+    LaneBracket T = lane_bracket(R.tn, R.tn_n, lane, nt, ts);
+    unsigned int mA = T.i1 == lane ? R.m0 : R.m1, mB = T.i2 == lane ? R.m0 : R.m1;  // presence bits of nodes i1, i2
+    int LT = uni(__ffsll((long long)__ballot(T.own)) - 1);
+    int st_t = MSX_W_OK;
+    if (LT < 0) {  // (uniform) no lane owns Teff: below the first node, or not a number
+        LT = 0;
+        if (ts < R.t_first) {
+            T.i1 = 0; T.i2 = nt - 1; T.e1 = R.t_first; T.e2 = R.t_last; mA = R.m_first; mB = R.m_last;
+        } else {
+            st_t = bracket_regs(R.tn, nt, ts, &T.i1, &T.i2, &T.e1, &T.e2);
+            mA = (unsigned int)__builtin_amdgcn_readlane((int)R.m0, T.i1 & 63);
+            mB = (unsigned int)__builtin_amdgcn_readlane((int)R.m0, T.i2 & 63);
         }
-        D.stat[star] = st;
+    } else {
+        st_t = __builtin_amdgcn_readlane(T.st, LT);
+    }
+    const double bw = (T.i1 == T.i2) ? 0.0 : fast_div(ts - T.e1, T.e2 - T.e1);
+    // ---- A1 logg, then its bracket -----------------------------------------------------------------------------
+    int st = MSX_W_OK;
+    const bool in_iso = (ts >= R.iso_lo) && (ts <= R.iso_hi);
+    if (!in_iso) st = MSX_W_VALUEERROR;
+    const double lg = iso_interp_lanes(R, ts);  // mft6.py:1149
+    MSX_STAMP(P, wk, 12);
+    int g1, g2, st_g = MSX_W_OK;
+    double a;
+    {
+        const LaneBracket Gb = lane_bracket(R.gn, R.gn_n, lane, ng, lg);
+        const double al = (Gb.i1 == Gb.i2) ? 0.0 : fast_div(lg - Gb.e1, Gb.e2 - Gb.e1);
+        const int LG = uni(__ffsll((long long)__ballot(Gb.own)) - 1);
+        if (LG >= 0) {
+            g1 = __builtin_amdgcn_readlane(Gb.i1, LG);
+            g2 = __builtin_amdgcn_readlane(Gb.i2, LG);
+            st_g = __builtin_amdgcn_readlane(Gb.st, LG);
+            a = readlane_f64(al, LG);
+        } else if (lg < R.g_first) {
+            g1 = 0; g2 = ng - 1;
+            a = (g1 == g2) ? 0.0 : fast_div(lg - R.g_first, R.g_last - R.g_first);
+        } else {
+            double ge1, ge2;
+            st_g = bracket_regs(R.gn, ng, lg, &g1, &g2, &ge1, &ge2);
+            a = (g1 == g2) ? 0.0 : fast_div(lg - ge1, ge2 - ge1);
+        }
+    }
+    MSX_STAMP(P, wk, 13);
+    if (st == MSX_W_OK) st = st_t;
+    if (st == MSX_W_OK) st = st_g;
+    // ---- presence, A4: in every lane; lane LT holds the walker's --------------------------------------------------
+    const bool have = (((mA >> g1) & (mA >> g2) & (mB >> g1) & (mB >> g2)) & 1u) != 0u;
+    const bool have_u = __builtin_amdgcn_readlane((int)have, LT) != 0;
+    if (st == MSX_W_OK && !have_u) st = MSX_W_KEYERROR;
+    MSX_STAMP(P, wk, 14);
+    int node[4] = {T.i1 * ng + g1, T.i1 * ng + g2, T.i2 * ng + g1, T.i2 * ng + g2};
+    double w[4] = {(1.0 - bw) * (1.0 - a) * sc, (1.0 - bw) * a * sc, bw * (1.0 - a) * sc, bw * a * sc};
+    sort4_by_node(node, w);  // canonical corner order (blend.h): a function of the grid cell alone
+    MSX_STAMP(P, wk, 10);
+    if (lane == LT) {
+        if (!alive) {
+            D.stat[star] = MSX_W_REJECT;
+        } else if (mode == MSX_MODE_LOGPRIOR) {  // no spectrum pass: the prior terms finish the job
+            D.stat[star] = MSX_W_OK;
+        } else {
+            if (st == MSX_W_OK) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { D.node[4 * star + c] = node[c]; D.w[4 * star + c] = w[c]; }
+                if (star == 0) D.redc = redden_rule(mode, G.use_av, tv[NS]) ? -0.4 * kLog2Of10 * tv[NS] : 0.0;
+            }
+            D.stat[star] = st;
+        }
     }
     MSX_STAMP(P, wk, 11);
-}
-// (both halves back to back: the variants that do not separate them)
-template <int NS>
-__device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const RecipeRegs &R, int niso, int nt, int ng, int mode,
-                                  const double *__restrict__ th, WalkerDesc &D, int lane, int64_t wk, const int star) {
-    RecipeMid<NS> M;
-    recipe_nodes_regs<NS>(P, R, niso, nt, ng, mode, th, D, lane, wk, star, M);
-    recipe_weights_regs<NS>(P, mode, D, lane, wk, star, M);
 }
 
 // Part 2 (off the critical path): the Gaussian prior terms (f1) and the contrast / photometry chi^2
