@@ -483,8 +483,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
     // bound by the CU's memory pipeline and wave 0's loads are served first, so wave 0 leaves the pixel loop
     // thousands of cycles before the last wave.  (Other modes: inside block_median.)
-    if (kRecipe && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
-    if (kRecipe && fast && prior_late && wave == 1 && myseg == 0) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    // (fused kernel: both run in waves 1 and 2 while wave 0 ranks the median's candidates, see phase B)
+    const bool late_side = STAGE == 0 && kRecipe && early;
+    if (STAGE != 0 && kRecipe && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+    if (STAGE != 0 && kRecipe && fast && prior_late && wave == 1 && myseg == 0) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
     if (STAGE == 4) {
         // the model vector from the scratch into LDS (the median's passes want it there) ...
         if ((npix & 1) == 0) {
@@ -504,7 +506,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         if (wave < 3) {  // the fit sums: serially over the segments, like the fused kernel's qrun
             for (int g = 0; g < nseg_all; ++g) qrun += sp[g].q[wave];
         }
+        if (early) __syncthreads();  // the counters are complete: running totals next
     }
+    // the early histogram is complete (the segment loop's barrier): its running totals, published by the barrier below
+    if (early && STAGE != 3) hist_prefix_inplace<MAXT>(S);
     {
         // value range: order-preserving keys, a NaN anywhere counts as above +inf
         const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
@@ -578,6 +583,13 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                                          &red[0][0][0], {}, {}, {}, 0.0};
         solved = logbin_median<MAXT>(model, npix, kmin, kmax, S, chi_fast, &med_model);
         chi_done = solved;
+        // Only wave 0 is busy from here (it ranks the candidates; the others left logbin_median after its barrier):
+        // waves 1 and 2 compute what only the walker's last line reads -- the contrast / photometry terms (A5/A6, which
+        // start with a round trip to the band table) and the Gaussian prior terms (f1).  One closing barrier below.
+        if (late_side) {
+            if (wave == 1) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+            if (wave == 2 && prior_late) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+        }
         if (solved) chi_elem.tot_run = chi_fast.tot_run;
         if (!solved) {  // not a positive vector spanning < 8 binades, or > 256 equal-bin candidates: start over
             __syncthreads();  // every wave decided from the counters by itself: none may still be reading them
@@ -663,6 +675,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const double md = bad ? NAN : block_median<MAXT>(model, npix, dmin, dmax, S, NoSide(), no_elem, &unused);  // np.median(flux), :1011
         if (tid == 0) P.opt_med[wk] = md;
     }
+    if (late_side) __syncthreads();  // D.chi_extra, D.lp (waves 1 and 2)
     if (tid == 0) {
         double iic = tot / (double)npix;  // mft6.py:1179
         if (opt_step || opt_init) iic = iic * 3;  // mft6.py:893,1015

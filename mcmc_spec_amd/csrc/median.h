@@ -332,6 +332,35 @@ __device__ __forceinline__ unsigned int logbin(double x) {
     return ((unsigned int)__double2hiint(x) >> 12) & (unsigned int)(kLogBins - 1);
 }
 
+// The early histogram's counters, turned IN PLACE into running totals: thread t owns counters [t PT, (t + 1) PT) and
+// leaves in each the number of values in its wave's block of bins up to and including that bin; S.wave_tot[w] gets
+// the block's total.  Every thread of the workgroup calls it once the counters are complete (a barrier has passed);
+// one more barrier publishes the result.  logbin_median then finds a rank with three dependent LDS reads (the wave
+// totals, one running total per lane, one thread's counters) instead of summing all 2048 counters in every wave.
+template <int BT>
+__device__ __forceinline__ void hist_prefix_inplace(BlockScratch &S) {
+    constexpr int PT = kLogBins / BT;  // counters per thread: 4 (512 threads) or 8 (256)
+    static_assert(PT == 4 || PT == 8, "256 or 512 threads");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint4 *h = reinterpret_cast<uint4 *>(&S.hist[tid * PT]);
+    uint4 a = h[0], b = make_uint4(0u, 0u, 0u, 0u);
+    a.y += a.x; a.z += a.y; a.w += a.z;
+    unsigned int tot = a.w;
+    if (PT == 8) {
+        b = h[1];
+        b.x += a.w; b.y += b.x; b.z += b.y; b.w += b.z;
+        tot = b.w;
+    }
+    const unsigned int inc = wave_scan_u32(tot), ex = inc - tot;
+    a.x += ex; a.y += ex; a.z += ex; a.w += ex;
+    h[0] = a;
+    if (PT == 8) {
+        b.x += ex; b.y += ex; b.z += ex; b.w += ex;
+        h[1] = b;
+    }
+    if (lane == kWave - 1) S.wave_tot[wave] = inc;
+}
+
 template <int BT, class Elem>
 __device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
                                               BlockScratch &S, Elem &elem, double *med_out) {
@@ -342,55 +371,77 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
     if (!(kmin > key_of(0.0)) || kmin == kmax) return false;
     const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
     const unsigned int hmax = (unsigned int)__double2hiint(val_of(kmax)) >> 12;
-    constexpr int per = kLogBins / kWave;  // counters per lane in the scan
-    // scan origin: min's bin rounded down to a lane's group, so no group straddles the end of the array
-    const unsigned int a = (hmin & (unsigned int)(kLogBins - 1)) & ~(unsigned int)(per - 1);
-    if ((hmax - hmin) + (hmin & (unsigned int)(per - 1)) >= (unsigned int)kLogBins) return false;  // the cycle would lap itself
+    // the cycle of bins starts at min's bin; it must not lap itself
+    const unsigned int a = hmin & (unsigned int)(kLogBins - 1);
+    if (hmax - hmin >= (unsigned int)kLogBins) return false;
     MED_STAMP(0);
     MED_STAMP(1);
-    elem.prime();  // the pass's first loads travel while the counters are scanned
-    // ---- per-wave scan: lane l owns the `per` counters from physical bin (a + per*l) mod kLogBins ----------
-    const unsigned int phys = (a + (unsigned int)(per * lane)) & (unsigned int)(kLogBins - 1);
-    unsigned int own = 0;
-    {
-        const uint4 *h4 = reinterpret_cast<const uint4 *>(&S.hist[phys]);
+    elem.prime();  // the pass's first loads travel while the rank is located
+    // ---- locate rank k1 along the cycle from the running totals (hist_prefix_inplace) ---------------------------
+    constexpr int PT = kLogBins / BT, blk = kWave * PT;  // counters per thread; bins per wave block
+    unsigned int woff[nw + 1];  // values before wave block w
+    woff[0] = 0u;
 #pragma unroll
-        for (int i = 0; i < per / 4; ++i) {
-            const uint4 h = h4[i];
-            own += h.x + h.y + h.z + h.w;
+    for (int w = 0; w < nw; ++w) woff[w + 1] = woff[w] + S.wave_tot[w];
+    // values in the physical bins before the cycle's origin come LAST along the cycle
+    unsigned int base = 0u;
+    if (a != 0u) {
+        const unsigned int am = a - 1u;
+        unsigned int wo = 0u;
+#pragma unroll
+        for (int w = 1; w < nw; ++w) wo = (am >= (unsigned int)(w * blk)) ? woff[w] : wo;
+        base = wo + S.hist[am];
+    }
+    const unsigned int n_hi = (unsigned int)npix - base;
+    const unsigned int r = k1 < n_hi ? base + k1 : k1 - n_hi;  // rank k1 in PHYSICAL bin order
+    int W = 0;
+#pragma unroll
+    for (int w = 1; w < nw; ++w) W = (r >= woff[w]) ? w : W;
+    unsigned int wsel = 0u;
+#pragma unroll
+    for (int w = 1; w < nw; ++w) wsel = (W == w) ? woff[w] : wsel;
+    const unsigned int rp = r - wsel;  // ... within wave block W
+    const unsigned int T = S.hist[W * blk + lane * PT + PT - 1];  // running total at the end of lane's counters
+    const int L = uni(__ffsll((long long)__ballot(T > rp)) - 1) & 63;
+    const unsigned int prevT = L > 0 ? (unsigned int)__builtin_amdgcn_readlane((int)T, L - 1) : 0u;
+    unsigned int cv[PT];
+    {
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(&S.hist[W * blk + L * PT]);  // (uniform address: a broadcast)
+        const uint4 x = q4[0];
+        cv[0] = x.x; cv[1] = x.y; cv[2] = x.z; cv[3] = x.w;
+        if (PT == 8) {
+            const uint4 y = q4[1];
+            cv[PT - 4] = y.x; cv[PT - 3] = y.y; cv[PT - 2] = y.z; cv[PT - 1] = y.w;
         }
     }
-    const unsigned int inc = wave_scan_u32(own);
-    const unsigned int excl = inc - own;
-    const bool mine_it = own > 0 && excl <= k1 && k1 < excl + own;      // exactly one lane (total = npix > k1)
-    const int L = uni(__ffsll((long long)__ballot(mine_it)) - 1);
-    // second level, again on the whole wave: lane j < per takes counter j of lane L's group
-    const unsigned int phys_l = (unsigned int)__builtin_amdgcn_readlane((int)phys, L);
-    const unsigned int t = k1 - (unsigned int)__builtin_amdgcn_readlane((int)excl, L);
-    const unsigned int c = lane < per ? S.hist[phys_l + lane] : 0u;
-    const unsigned int inc2 = wave_scan_u32(c);
-    const int J = uni(__ffsll((long long)__ballot(c > 0 && inc2 - c <= t && t < inc2)) - 1);
-    const unsigned int kk = t - (unsigned int)__builtin_amdgcn_readlane((int)(inc2 - c), J);
-    unsigned int cnt = (unsigned int)__builtin_amdgcn_readlane((int)c, J);
-    const unsigned int sel_p = phys_l + (unsigned int)J;  // PHYSICAL bin of rank k1 (< kLogBins: a group does not wrap)
+    int isel = 0;
+    unsigned int below = prevT, upto = cv[0];  // running totals before / through the selected bin
+#pragma unroll
+    for (int i = 0; i + 1 < PT; ++i) {
+        const bool past = cv[i] <= rp;  // (monotone: true for a prefix of the counters)
+        isel = past ? i + 1 : isel;
+        below = past ? cv[i] : below;
+        upto = past ? cv[i + 1] : upto;
+    }
+    const unsigned int kk = rp - below;
+    unsigned int cnt = upto - below;
+    const unsigned int sel_p = (unsigned int)(W * blk + L * PT + isel);  // PHYSICAL bin of rank k1
     // Rank k1 + 1 (even npix) lies in the same bin unless rank k1 is that bin's last value; then it is the smallest
     // value of the NEXT non-empty bin along the cycle, and that bin's values are gathered too: in the union, ranks
     // kk and kk + 1 are the two middle values either way.
     unsigned int nxt_p = sel_p;
     if (need_two && kk + 1 == cnt) {  // (uniform; ~1 walker in `cnt`)
-        const unsigned long long later = __ballot(c > 0 && lane > J);
-        if (later != 0ull) {
-            const int J2 = uni(__ffsll((long long)later) - 1);
-            nxt_p = phys_l + (unsigned int)J2;
-            cnt += (unsigned int)__builtin_amdgcn_readlane((int)c, J2);
-        } else {
-            // the first non-empty counter of the next lane group that has any (one exists: rank k1 + 1 < npix)
-            const int L2 = uni(__ffsll((long long)(__ballot(own > 0 && lane > L))) - 1);
-            const unsigned int phys_l2 = (unsigned int)__builtin_amdgcn_readlane((int)phys, L2);
-            const unsigned int c2 = lane < per ? S.hist[phys_l2 + lane] : 0u;
-            const int J2 = uni(__ffsll((long long)__ballot(c2 > 0)) - 1);
-            nxt_p = phys_l2 + (unsigned int)J2;
-            cnt += (unsigned int)__builtin_amdgcn_readlane((int)c2, J2);
+        unsigned int p0 = sel_p + 1u;
+        for (int it = 0; it < kLogBins / kWave; ++it, p0 += (unsigned int)kWave) {  // (one exists: rank k1 + 1 < npix)
+            const unsigned int bb = (p0 + (unsigned int)lane) & (unsigned int)(kLogBins - 1);
+            const unsigned int hb = S.hist[bb], hp = (bb & (unsigned int)(blk - 1)) ? S.hist[bb - 1u] : 0u;
+            const unsigned long long nz = __ballot(hb != hp);
+            if (nz != 0ull) {
+                const int J = uni(__ffsll((long long)nz) - 1);
+                nxt_p = (p0 + (unsigned int)J) & (unsigned int)(kLogBins - 1);
+                cnt += (unsigned int)__builtin_amdgcn_readlane((int)(hb - hp), J);
+                break;
+            }
         }
     }
     if (cnt > (unsigned int)kSelectFinish) return false;  // heavy duplication: the general path sorts it out
