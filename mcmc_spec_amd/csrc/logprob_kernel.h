@@ -616,11 +616,13 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     const int64_t chain = opt_step ? (int64_t)P.opt_chain[wk] : wk;
     const double *__restrict__ dflux = opt_step ? P.opt_flux + chain * npix : P.pix_flux;
     const double med_data = opt_step ? P.opt_med[chain] : P.median_flux;
-    const double scale = med_data / med_model;  // mft6.py:1173 / :1011
-    double coef[3];
+    const double scale = fast_div(med_data, med_model);  // mft6.py:1173 / :1011
+    double coef[3] = {0.0, 0.0, 0.0};
+    if (!fused) {  // (the fused modes' chi^2 terms rode along the median's pass)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
+        for (int i = 0; i < 3; ++i)
+            coef[i] = (P.minv[3 * i] * q[0] + P.minv[3 * i + 1] * q[1] + P.minv[3 * i + 2] * q[2]) / scale;
+    }
     double chia[vk];  // per virtual wave, like phase A
 #pragma unroll
     for (int k = 0; k < vk; ++k) chia[k] = 0.0;
@@ -677,13 +679,14 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     }
     if (late_side) __syncthreads();  // D.chi_extra, D.lp (waves 1 and 2)
     if (tid == 0) {
-        double iic = tot / (double)npix;  // mft6.py:1179
+        double iic = fast_div(tot, (double)npix);  // mft6.py:1179
         if (opt_step || opt_init) iic = iic * 3;  // mft6.py:893,1015
         const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191 / :904 / :1028
         double out;
         if (mode == MSX_MODE_CHISQ || opt_step || opt_init) out = total;  // mft6.py:1198-1199
         else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
         walker_done(P, D, wk, ndim, out, MSX_W_OK, logp, status);
+        MSX_STAMP(P, wk, 15);
     }
 }
 

@@ -85,7 +85,9 @@ def main():
     for i, nm in enumerate(['(entry)', 'bin scan', 'chi2 + gather pass + barrier', 'rank']):
         print('    median/{:24s} median {:8d} cycles'.format(nm, int(np.median(dm[:, i]))))
     print('    median/candidates: median {} max {}'.format(int(np.median(med[:, 6])), int(med[:, 6].max())))
-    span = int(out[:, 7].max() - out[:, 0].min())
+    fin = (out[:, 15] - out[:, 7]).astype(np.int64)
+    print('  closing barrier + combine + store: median {} cycles  (walker total {})'.format(int(np.median(fin)), int(np.median(fin + tot))))
+    span = int(out[:, 15].max() - out[:, 0].min())
     print('  first start -> last end: {} cycles'.format(span))
 
 
