@@ -23,6 +23,10 @@ constexpr double kLog2Of10 = 3.3219280948873623478703194294893901758648313930245
 // ScratchSize 0 for logprob_kernel; tests/test_abi.py checks it.  (Reading the struct through a pointer to a
 // device copy instead was tried: no scratch hazard, but 61 instead of 16 spilled SGPRs and +10 % kernel time
 // for 256-thread workgroups, so by-value + forced inlining stays.)
+struct SmpRec {  // the stretch move of one walker of a half-step
+    int32_t si, ci;  // ensemble index of the walker and of its partner in the complementary half
+    double zz;       // the stretch factor
+};
 struct DevProblem {
     // grid (A0)
     const double *grid;   // [nt*ng][nwl]
@@ -80,6 +84,8 @@ struct DevProblem {
     const int32_t *smp_sidx, *smp_cidx, *smp_partner;  // [ns]; smp_partner holds cidx[partner]: the ensemble
                                                        // index of the complementary walker (resolved on the host)
     const double *smp_zz, *smp_zfac, *smp_logu;        // [ns]
+    const SmpRec *smp_rec;                  // [ns] {sidx, cidx[partner], zz} again, one record per walker: what the
+                                            // proposal needs, behind ONE pointer that reaches the kernel preloaded
     int64_t *smp_naccept;                   // [nw]
     double *smp_chain_row, *smp_lp_row;     // chain[step] [nw][ndim], logp chain[step] [nw]
     int32_t *smp_worst;

@@ -172,8 +172,9 @@ template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = f
 // SIMD = 128 VGPRs.)
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && SH) ? 4 : 1)
 logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
-               double gate_tmin, double gate_tmax, DevProblem P, double *__restrict__ logp, int32_t *__restrict__ status) {
-    // The leading arguments (12 dwords; the preload takes 14) are compiled for KERNARG PRELOAD (-mllvm
+               double gate_tmin, double gate_tmax, const SmpRec *__restrict__ smp_rec, DevProblem P,
+               double *__restrict__ logp, int32_t *__restrict__ status) {
+    // The leading arguments (14 dwords: all the preload takes) are compiled for KERNARG PRELOAD (-mllvm
     // -amdgpu-kernarg-preload-count): the command processor delivers them in SGPRs at wave start, so theta and the
     // recipe's small tables are requested in the first instructions, while the 1.2 KB DevProblem (fetched from the
     // kernel-argument segment like any argument: a memory round trip, then a scalar-cache access per field) is
@@ -184,6 +185,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     //   ng_mode_fast    ng | mode << 8 | fast << 16 | sampler << 17 | dist_fit << 18 | use_av << 19 | segments << 24
     //   n               the batch size (ndim is 2 NS + 2, checked by the host)
     //   gate_tmin/tmax  the Teff box of the prior's hard gates (= P.tmin, P.tmax)
+    //   theta, smp_rec  device-resident sampler: `theta` is the resident ensemble (= P.smp_coords) and smp_rec the
+    //                   half-step's records (= P.smp_rec): the proposal is two dependent loads away from wave start
     const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
     constexpr int ndim = 2 * NS + 2;
     __shared__ WalkerDesc D;
@@ -227,54 +230,59 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
     const double *th_row = theta + wk * ndim;
+    // Early-histogram path (logbin_median): the median's histogram is filled while phase A computes the model,
+    // and the walker's prior terms move off phase 0.  Likelihood / posterior / chi^2 modes with the register-resident
+    // recipe and the model vector in LDS; everything else keeps block_median.
+    const bool early = !GM && fast && !P.no_spectrum &&
+                       (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    // The prior terms (f1) depend on theta alone and only the walker's last lines read them: an idle wave computes
+    // them beside the recipe waves -- or, where phase A follows (`early` modes of the blending stages), a wave that
+    // idles while wave 0 ranks the median's candidates (rejected walkers never read them).
+    const bool prior_late = kBlend && early;
     if (smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
-        // two dependent levels only: {own index, complement index, z} -> the two coordinate rows.  The proposal
-        // goes to LDS (the recipe waves read it there, no round trip through memory); wave 1 meanwhile fetches
-        // what the accept step will need at the very end.
-        if (tid < ndim) {
+        // two dependent levels from wave start: the walker's record {own index, partner's index, z} (a preloaded
+        // pointer) -> the two coordinate rows of the resident ensemble (the `theta` argument).  Every recipe wave
+        // forms the proposal itself, lane k coordinate k, straight into the register the recipe reads: no LDS round
+        // trip, no barrier.  Wave 0 also leaves it in LDS for the phases after phase 0; a non-recipe wave meanwhile
+        // fetches what the accept step will need at the very end.
+        const SmpRec rc = smp_rec[wk];
+        if (wave < NS && lane < ndim) {
 #pragma clang fp contract(off)
             // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
             // the device-resident and the host-driven sampler stay in lock-step
-            const int64_t si = P.smp_sidx[wk], ci = P.smp_partner[wk];
-            const double zz = P.smp_zz[wk];
-            const double sv = P.smp_coords[si * ndim + tid];
-            const double cv = P.smp_coords[ci * ndim + tid];
+            const double sv = theta[(int64_t)rc.si * ndim + lane];
+            const double cv = theta[(int64_t)rc.ci * ndim + lane];
             const double diff = cv - sv;
-            const double prod = diff * zz;
+            const double prod = diff * rc.zz;
             const double qv = cv - prod;
-            D.theta[tid] = qv;
-            D.smp_sv[tid] = sv;
-            P.smp_q[wk * ndim + tid] = qv;  // (kept for inspection; nothing reads it back)
-        } else if (tid == kWave) {
-            const int64_t si = P.smp_sidx[wk];
+            theta_lane = qv;
+            if (wave == 0) {
+                D.theta[lane] = qv;
+                D.smp_sv[lane] = sv;
+                P.smp_q[wk * ndim + lane] = qv;  // (kept for inspection; nothing reads it back)
+            }
+        } else if (tid == NS * kWave) {
+            const int64_t si = rc.si;
             D.smp_s = si;
             D.smp_old = P.smp_logp[si];
             D.smp_nacc = P.smp_naccept[si];
             D.smp_zfac = P.smp_zfac[wk];
             D.smp_logu = P.smp_logu[wk];
         }
-        __syncthreads();
+        // (readers of D.theta before phase 0's barrier: the prior terms' wave where they are not late, and the
+        // general recipe -- which runs in wave 0, the writer)
+        if (!prior_late) __syncthreads();
         th_row = D.theta;
-        if (kRecipe && fast && wave < NS && lane < ndim) theta_lane = D.theta[lane];
     }
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
     if (kBlend) fill_exp2_table(e2tab, tid - (B - kWave));  // the last wave (no recipe work); published by phase 0's barrier
-    // Early-histogram path (logbin_median): the median's histogram is filled while phase A computes the model,
-    // and the walker's prior terms move to an idle wave of phase 0.  Likelihood / posterior / chi^2 modes with
-    // the register-resident recipe and the model vector in LDS; everything else keeps block_median.
-    const bool early = !GM && fast && !P.no_spectrum &&
-                       (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
     if (!kRecipe) {  // the recipe's scalars come from an earlier stage's record; no phase 0
         if (tid == 0) { D.lp = P.rec[wk].lp; D.chi_extra = P.rec[wk].chi_extra; D.status = MSX_W_OK; }
     }
     constexpr int NC = NS * 4;
     const int nseg_all = (ne + kSegElems - 1) / kSegElems;
     const int seg_lo = STAGE == 3 ? myseg : 0, seg_hi = STAGE == 3 ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
-    // The prior terms (f1) depend on theta alone and only the walker's last lines read them: an idle wave computes
-    // them beside the recipe waves -- or, where phase A follows (`early` modes of the blending stages), wave 1 at the
-    // end of phase A, while it would otherwise wait for the slowest wave (rejected walkers never read them).
-    const bool prior_late = kBlend && early;
     if (kRecipe && fast && wave == NS && !prior_late) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
     if (kRecipe) {
         if (fast) {

@@ -288,7 +288,7 @@ DevProblem problem_at(const DevProblem &P0, int64_t off, int mode, int ndim) {
     if (mode == MSX_MODE_OPT_INIT) { P.opt_flux += off * P.npix; P.opt_med += off; }
     if (P.smp_on) {
         P.smp_sidx += off; P.smp_cidx += off; P.smp_partner += off;
-        P.smp_zz += off; P.smp_zfac += off; P.smp_logu += off;
+        P.smp_zz += off; P.smp_zfac += off; P.smp_logu += off; P.smp_rec += off;
         P.smp_q += off * ndim;
     }
     return P;
@@ -301,7 +301,8 @@ template <int STAGE>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
     const dim3 g((unsigned)(STAGE == 3 ? A.n * c->nseg : A.n));
     const size_t lds = sizeof(double) * (size_t)P.npix;
-#define MSX_LEAD_ARGS A.theta, (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax
+#define MSX_LEAD_ARGS (P.smp_on ? (const double *)P.smp_coords : A.theta), (const unsigned char *)c->d_recipe_block, A.niso_nt, \
+                      A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, P.smp_rec
 #define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                      \
     hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, STAGE>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
                        A.logp, A.status)
@@ -973,7 +974,9 @@ struct SamplerRun {
         int64_t nsteps = 0;
         bool busy = false;
     } slot[2];
-    size_t in_bytes(int64_t st) const { return (size_t)(st * 2 * ns) * (3 * sizeof(double) + 3 * sizeof(int32_t)); }
+    size_t in_bytes(int64_t st) const {  // [zz | zfac | logu | sidx | cidx | partner | records]
+        return (size_t)(st * 2 * ns) * (3 * sizeof(double) + 3 * sizeof(int32_t) + sizeof(SmpRec));
+    }
     size_t out_bytes(int64_t st) const {
         return sizeof(double) * (size_t)(st * nw * ndim + st * nw) + sizeof(int64_t) * (size_t)nw + 16;
     }
@@ -1097,11 +1100,15 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
     // resolve partner -> ensemble index of the complementary walker here, so that the kernel's proposal needs
     // two dependent loads (index, coordinates) instead of three
     for (int64_t i = 0; i < nh; ++i) hi[2 * nh + i] = hi[nh + (i / ns) * ns + hi[2 * nh + i]];
+    // ... and the proposal's inputs once more as one record per walker (the kernel's first load)
+    SmpRec *hr = (SmpRec *)(hi + 3 * nh);
+    for (int64_t i = 0; i < nh; ++i) { hr[i].si = hi[i]; hr[i].ci = hi[2 * nh + i]; hr[i].zz = hz[i]; }
     HIP_TRY(c, hipMemcpyAsync(sl.d_in, sl.h_in, r->in_bytes(nsteps), hipMemcpyHostToDevice, r->up));
     HIP_TRY(c, hipEventRecord(sl.in_ready, r->up));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.in_ready, 0));
     double *d_zz = (double *)sl.d_in, *d_zfac = d_zz + nh, *d_logu = d_zfac + nh;
     int32_t *d_sidx = (int32_t *)(d_logu + nh), *d_cidx = d_sidx + nh, *d_partner = d_cidx + nh;
+    const SmpRec *d_rec = (const SmpRec *)(d_partner + nh);
     double *d_chain = (double *)sl.d_out, *d_lpchain = d_chain + nsteps * nw * ndim;
     int64_t *d_nacc_snap = (int64_t *)(d_lpchain + nsteps * nw);
     int32_t *d_worst = (int32_t *)(d_nacc_snap + nw);
@@ -1114,7 +1121,7 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
         for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
             const int64_t off = (st * 2 + half) * ns;
             P.smp_sidx = d_sidx + off; P.smp_cidx = d_cidx + off; P.smp_partner = d_partner + off;
-            P.smp_zz = d_zz + off; P.smp_zfac = d_zfac + off; P.smp_logu = d_logu + off;
+            P.smp_zz = d_zz + off; P.smp_zfac = d_zfac + off; P.smp_logu = d_logu + off; P.smp_rec = d_rec + off;
             P.smp_chain_row = d_chain + st * nw * ndim; P.smp_lp_row = d_lpchain + st * nw;
             if (!r->sharded) {
                 rc = msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
@@ -1127,6 +1134,7 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
             if (hi > lo) {
                 P.smp_defer = 1;
                 P.smp_sidx += lo; P.smp_cidx += lo; P.smp_partner += lo; P.smp_zz += lo; P.smp_zfac += lo; P.smp_logu += lo;
+                P.smp_rec += lo;
                 P.smp_q = r->d_q + lo * ndim;
                 rc = msx_logprob_batch_dev(c, r->mode, r->d_q + lo * ndim, hi - lo, ndim, r->d_newlp_all + lo, r->d_wst + lo,
                                            c->stream, 0);

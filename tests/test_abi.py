@@ -64,7 +64,7 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
     src = os.path.join(ROOT, 'mcmc_spec_amd', 'csrc', 'msx.hip')
     with tempfile.TemporaryDirectory() as d:
         out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-                              '-mllvm', '-amdgpu-kernarg-preload-count=7',
+                              '-mllvm', '-amdgpu-kernarg-preload-count=8',
                               '-Rpass-analysis=kernel-resource-usage', '-o', os.path.join(d, 't.so'), src],
                              capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]

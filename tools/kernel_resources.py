@@ -22,7 +22,7 @@ def demangle(names):
 
 def main():
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-mllvm',
-           '-amdgpu-kernarg-preload-count=7', '-Rpass-analysis=kernel-resource-usage', '-o', '/tmp/msx_res.o',
+           '-amdgpu-kernarg-preload-count=8', '-Rpass-analysis=kernel-resource-usage', '-o', '/tmp/msx_res.o',
            os.path.join(ROOT, 'mcmc_spec_amd', 'csrc', 'msx.hip')] + sys.argv[1:]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None

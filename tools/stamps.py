@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-clock shares of the hot kernel (build with -DMSX_STAMPS, never shipped).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=7 -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=8 -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
     MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 256 --block 1024
 """
 import argparse
