@@ -284,11 +284,9 @@ def main():
     # the launch is a plain C call with pre-built arguments (no per-step Python marshalling)
     import ctypes as C
     fn = eng.ctx.lib.msx_logprob_batch_dev
-    # With a collective in flight RCCL's kernel holds a CU or two.  The N = 1 variant (512 threads + 136 KB of LDS:
-    # one workgroup per CU, all 256 CUs needed at once) would run a second round for the displaced walkers, so
-    # N > 1 launches the 512-thread variant that fits two workgroups per CU (<= 128 VGPRs, 44 KB of LDS;
-    # MSX_BLOCK_512_SHARED): 20.2 us alone against 19.1 us, and 23.5 us for 256-thread workgroups.  Same bits.
-    block = args.block if args.block else (_lib.BLOCK_512_SHARED if use_gather and args.npix < 8192 else 0)
+    # (binaries below 8192 px run the <= 128-VGPR, 44 KB-of-LDS variant at every batch size up to two walkers per CU:
+    # two of its workgroups fit a CU, so a CU or two held by RCCL's kernel at N > 1 costs no second round)
+    block = args.block
 
     def calls_for(sp):
         # step i: problem i mod nprob (config 5 rehearsal), theta batch i mod nbatch, output buffer i mod 2
@@ -494,10 +492,19 @@ def main():
         kern_s = kern_ms * 1e-3
         req = eng.ctx.bytes_per_eval()  # bytes one walker's workgroup requests from the memory system (L2-served)
         cus = 256
-        if block == _lib.BLOCK_512_SHARED or (not block and cus < n <= 2 * cus and 2048 < args.npix < 8192):
-            kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (two workgroups per CU, <= 128 VGPRs)'
-        elif block == 256 or (not block and n > cus and (n > 2 * cus or args.npix <= 2048) and args.npix < 8192):
+        # (mirrors pick_block / launch_logprob of csrc/msx.hip)
+        if block in (256, 512):
+            bt = block
+        elif block == _lib.BLOCK_512_SHARED or args.npix >= 8192 or n <= cus:
+            bt = 512
+        elif args.npix <= 2048:
+            bt = 256
+        else:
+            bt = 512 if n <= 2 * cus else 256
+        if bt == 256:
             kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
+        elif args.npix * 8 <= 70 * 1024:
+            kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (<= 128 VGPRs: two workgroups fit a CU; rows one star at a time)'
         elif args.npix * 8 * 3 > 130 * 1024:
             kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU)'
         else:

@@ -320,8 +320,12 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     } else {
         // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
         const bool own_cu = A.n <= c->prop.multiProcessorCount || lds > 70 * 1024;  // (long spectra: one per CU anyway)
-        const bool pf = B == 512 && !shared512 && own_cu && c->pf_ok && c->use_pf;
-        const bool sh = B == 512 && !pf && (shared512 || !own_cu);
+        // binaries: the <= 128-VGPR variant (rows taken one star at a time, u / flux re-read by the chi^2 pass) whenever two
+        // workgroups fit a CU -- since the vector-instruction diet of round 2 it is also the fastest with a CU to itself
+        // (256 walkers x 4096 px: 17.6 us against 17.9 staged in LDS, 18.0 plain)
+        const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024;
+        const bool pf = B == 512 && !shared512 && !sh2 && own_cu && c->pf_ok && c->use_pf;
+        const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
         if (P.nspec == 2) {
             if (B == 256) MSX_GO(2, 2, 256, false, false, false, lds);
             else if (pf) MSX_GO(2, 2, 512, false, false, true, lds_pf);
