@@ -512,10 +512,11 @@ def main():
         # ---- the roofline that bounds THIS design --------------------------------------------------------------
         # The kernel never streams the windowed grid from HBM: staging folds the resample into per-node tables of
         # 12 bytes per pixel (R float64 + H float32, 5.1 MB at config 2) that live in L2 / Infinity Cache, and a
-        # walker's workgroup pulls its eight rows through its CU's memory pipeline.  At this batch size the longest
-        # phase (the blend, ~47 % of the kernel) is bound by the L2 -> CU path; from a few workgroups per CU on the
-        # kernel is bound by FP64 VALU issue instead (`valu`, and the sweep's valu_issue_frac).  The contract's HBM
-        # figure is kept, labelled, in `hbm_contract`; it is NOT a bound on this design and exceeds 1.
+        # walker's workgroup pulls its eight rows through its CU's memory pipeline.  The bound is the L2 -> CU path: at
+        # 256 walkers one phase of the kernel (the blend, ~45 % of it) runs at that limit and the rest is a latency
+        # chain; at large batches the WHOLE kernel averages 0.6 of the L2 aggregate (the sweep's last rows: above the
+        # guide's own measured gather rate) with the vector ALUs half busy (`valu`, the sweep's valu_issue_frac).  The
+        # contract's HBM figure is kept, labelled, in `hbm_contract`; it is NOT a bound on this design and exceeds 1.
         achieved = n * req / kern_s / 1e9
         traffic, traffic_src = None, None
         tj = load_profile('r2_logprob_traffic.json') or load_profile('r1_logprob_traffic.json')
@@ -533,8 +534,9 @@ def main():
             'note': 'achieved = bytes the launch requests from the memory system (L2-served) / kernel time, averaged over '
                     'the WHOLE kernel (recipe, blend, median, chi^2); peak = the L2 aggregate of MI355X_MICROARCH.md, beside '
                     'it the same guide\'s measured chip-wide rate for rows gathered from L2 (16.8-18.8 TB/s).  The blend '
-                    'phase alone moves its 442 KB per walker in ~8 us: ~15 TB/s chip-wide with 256 CUs pulling, the '
-                    'most this access pattern drew from the L2s in any experiment of DESIGN.md',
+                    'phase alone moves its ~500 KB per walker in ~6.5 us: ~20 TB/s chip-wide with 256 CUs pulling, 78 GB/s '
+                    'per CU (the guide measures 66-73); the rest of the kernel is the walker\'s dependent chain (recipe, '
+                    'median, chi^2) and moves little.  Large batches reach 21.6 TB/s over the whole kernel (extra.sweep)',
         }
         if not replicas:
             nwin = W['nwin']

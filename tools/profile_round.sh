@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3
 cd $root
 python3 tools/pmc_summary.py --kt $out/kt --fetch $out/pmc_fetch --write $out/pmc_write --kernel logprob_kernel \
   --out $dst/${tag}_logprob \
-  --note "rocprofv3 on: python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-extras (kernel-trace/stats) and --steps 50 --warmup 5 (two separate --pmc passes: FETCH_SIZE, WRITE_SIZE); config 2: 256 walkers, 4096 px, block auto (512 threads, one workgroup per CU)" > /dev/null
+  --note "rocprofv3 on: python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-extras (kernel-trace/stats) and --steps 50 --warmup 5 (two separate --pmc passes: FETCH_SIZE, WRITE_SIZE); config 2: 256 walkers, 4096 px, block auto (512 threads, the <= 128-VGPR variant)" > /dev/null
 grep '^{' $out/bench_kt.json > $dst/${tag}_bench_under_rocprof.json
 # ---- SQ counters
 for cs in 4096:256 4096:3072 16384:128; do
