@@ -897,3 +897,68 @@ def test_fuzzed_problems_against_the_oracle():
         worst = max(worst, float(e))
         assert e < TIGHT, (case, npix, phot, rad_prior, with_prior, e)
     print('fuzz: worst relative deviation from the oracle', worst)
+
+
+def test_brackets_at_and_beyond_the_edges_of_the_node_lists():
+    """The lane-parallel brackets of the recipe (csrc/recipe.h) in the corners no interval owns: a value below the
+    first node (the reference's unchecked index -1 wraps to the LAST node, mft6.py:467-477), exactly on the first /
+    last node, beyond the last node (IndexError) -- for Teff and for logg, against the oracle."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    from oracle import mft6_oracle as orc
+    c = golden_case('B')
+    bl = bands.make_bands(c.tables, *c.vega)
+
+    def engine_for(keep):
+        specs = {k: v for k, v in c.specs.items() if k == 'wl' or keep(*[float(x) for x in k.split(',')])}
+        eng = Engine(0)
+        eng.stage_specs(specs)
+        eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2, bands=bl,
+                          av_table=common.av_table_exact(), tmin=c.tmin, tmax=c.tmax, prior=c.prior)
+        return eng, specs
+
+    def want(specs, t):
+        return orc.loglikelihood(list(t), c.fr, 2, c.data, c.err, c.r, specs, c.ctm, c.ptm, c.tmi, c.tma, c.matrix,
+                                 bandlib=c.bandlib)
+
+    base = c.theta[0].copy()
+    # ---- Teff nodes 3200 .. 4000 only (the isochrone and the prior box still span 3000 .. 4200)
+    eng, specs = engine_for(lambda t, g: 3200.0 <= t <= 4000.0)
+    cases = []
+    for t1, t2 in [(3150.0, 3650.0), (3650.0, 3150.0), (3199.999, 3200.0), (3200.0, 4000.0), (4000.0, 3999.5), (3100.0, 3120.0)]:
+        th = base.copy()
+        th[0], th[1] = t1, t2
+        cases.append(th)
+    th = np.array(cases)
+    got = eng.loglikelihood(th)
+    exp = np.array([want(specs, t) for t in th])
+    assert np.all(np.isfinite(exp)) and rel_err(got, exp).max() < TIGHT, (got, exp)
+    for t1, t2 in [(4000.5, 3650.0), (3650.0, 4199.0)]:
+        bad = base.copy()
+        bad[0], bad[1] = t1, t2
+        with pytest.raises(IndexError):
+            want(specs, bad)
+        with pytest.raises(IndexError):
+            eng.loglikelihood(bad)
+    # ---- logg nodes 5.0, 5.5 only: the isochrone's logg drops below 5.0 above ~4030 K (wrap), lies inside below
+    eng, specs = engine_for(lambda t, g: g >= 5.0)
+    cases = []
+    for t1, t2 in [(4100.0, 3500.0), (3500.0, 4150.0), (4180.0, 4060.0), (3850.0, 3325.0)]:
+        th = base.copy()
+        th[0], th[1] = t1, t2
+        cases.append(th)
+    th = np.array(cases)
+    got = eng.loglikelihood(th)
+    exp = np.array([want(specs, t) for t in th])
+    assert np.all(np.isfinite(exp)) and rel_err(got, exp).max() < TIGHT, (got, exp)
+    # ---- one logg node: every bracket degenerates to it
+    eng, specs = engine_for(lambda t, g: g == 5.5)
+    got = eng.loglikelihood(c.theta[:6])
+    exp = np.array([want(specs, t) for t in c.theta[:6]])
+    assert rel_err(got, exp).max() < TIGHT
+    # ---- logg nodes 4.0, 4.5 only: logg ~ 5.1 lies beyond the last node -> IndexError
+    eng, specs = engine_for(lambda t, g: g <= 4.5)
+    with pytest.raises(IndexError):
+        want(specs, base)
+    with pytest.raises(IndexError):
+        eng.loglikelihood(base)
