@@ -433,6 +433,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const bool live = e < e_end;
         const int ec = live ? e : e_end - 1;
         const unsigned int o16 = (unsigned int)ec << 4, o8 = (unsigned int)ec << 3;
+        // data flux and u: requested with the rows by the 256-thread variant (one wait per trip instead of two:
+        // 16,384 walkers 458 -> 438 us), after the blend by the 512-thread ones (17.45 against 17.57 us at 256 walkers)
+        constexpr bool kEarlyFU = MAXT == 256;
+        double2 f2v = make_double2(0.0, 0.0), u2v = make_double2(0.0, 0.0);
+        if (kEarlyFU) { f2v = ld_off(P.f2, o16); u2v = ld_off(P.u2, o16); }
         double2 m2;
         if (!kBlend) {
             const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
@@ -467,7 +472,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             m2.x = blend_finish(sra, sha, kl2.x, (double)dk2.x, redc, RED, e2tab);
             m2.y = blend_finish(srb, shb, kl2.y, (double)dk2.y, redc, RED, e2tab);
         }
-        finish_elem(m2, ld_off(P.f2, o16), ld_off(P.u2, o16), ec, live, sub_c);
+        if (!kEarlyFU) { f2v = ld_off(P.f2, o16); u2v = ld_off(P.u2, o16); }
+        finish_elem(m2, f2v, u2v, ec, live, sub_c);
         };
         one(std::integral_constant<int, 0>{});
         if constexpr (SUB == 2) one(std::integral_constant<int, 1>{});
