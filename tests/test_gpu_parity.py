@@ -962,3 +962,61 @@ def test_brackets_at_and_beyond_the_edges_of_the_node_lists():
         want(specs, base)
     with pytest.raises(IndexError):
         eng.loglikelihood(base)
+
+
+def test_register_recipe_on_a_dense_grid_with_holes():
+    """40 Teff x 20 logg nodes (the register-resident recipe's presence BITS beyond the first few, Teff lanes up to
+    39; round 1's byte table stopped at 128 nodes) with a few nodes missing: log-posterior against the oracle, and
+    KeyError exactly where the oracle raises it."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands, synth
+    from oracle import mft6_oracle as orc
+    c = golden_case('B')
+    teffs = np.arange(3000, 4200, 30)
+    loggs = 4.0 + 0.075 * np.arange(20)
+    wl = np.arange(5300.0, 9700.0, 0.5)
+    flux = synth.make_grid(teffs, loggs, wl, nlines=150, seed=5)
+    specs = synth.grid_to_specs(teffs, loggs, wl, flux)
+    holes = [(3630, loggs[14]), (3660, loggs[15]), (3300, loggs[13])]
+    for t, g in holes:
+        del specs['{}, {}'.format(int(t), float(g))]
+    rng = np.random.default_rng(12)
+    npix = 900
+    dwl = np.sort(rng.uniform(0.58, 0.88, npix))
+    data = [dwl, 1.0 + 0.05 * rng.normal(size=npix)]
+    err = rng.uniform(0.01, 0.05, size=npix)
+    r = [dwl.min(), dwl.max()]
+    ctm = [[list(np.linspace(6000.0, 9500.0, 60))], [list(0.9 * np.ones(60))], [0], [7750.0]]
+    ptm = [[], [], [], []]
+    fr = [[2.4], [0.05], np.array(['x']), np.zeros(0), [], np.array([])]
+    tmi, tma = 6000.0, 9500.0
+    eng = Engine(0)
+    eng.stage_specs(specs)
+    eng.stage_problem(data, err, fr, r, ctm, ptm, tmi, tma, c.matrix, nspec=2, bands=bands.make_bands(c.tables, *c.vega),
+                      av_table=common.av_table_exact(), tmin=3000.0, tmax=4170.0, prior=c.prior)
+    n = 48
+    th = np.column_stack([rng.uniform(3005, 4165, n), rng.uniform(3005, 4165, n), rng.uniform(0, 0.6, n),
+                          rng.uniform(0.1, 1.2, n), rng.uniform(0.1, 1.0, n), rng.uniform(1 / 2000, 1 / 50, n)])
+    th[:6, 0] = teffs[[0, 5, 17, 30, 38, 39]]           # on nodes, including the first and the last
+    th[6:10, 1] = teffs[[3, 11, 21, 35]] + 15.0          # ties
+    th[10, 0], th[11, 1], th[12, 0] = 3640.0, 3650.0, 3310.0   # cells that touch the holes
+    got_vals, want_vals, bad = [], [], 0
+    for t in th:
+        try:
+            w = orc.logposterior(list(t), fr, 2, data, err, r, specs, ctm, ptm, tmi, tma, 3000.0, 4170.0, c.matrix,
+                                 common.av_prior, prior=c.prior, bandlib=c.bandlib)
+        except KeyError:
+            bad += 1
+            with pytest.raises(KeyError):
+                eng.logposterior(t)
+            continue
+        got_vals.append(eng.logposterior(t))
+        want_vals.append(w)
+    got_vals, want_vals = np.array(got_vals), np.array(want_vals)
+    assert bad >= 2 and len(got_vals) >= 30
+    assert np.array_equal(np.isinf(got_vals), np.isinf(want_vals))
+    assert rel_err(got_vals, want_vals).max() < TIGHT
+    # the same walkers in one launch: the good ones keep their values whatever their neighbours raise
+    good = np.array([t for t in th if True])
+    st = eng.ctx.logprob_batch(good, __import__('mcmc_spec_amd._lib', fromlist=['x']).MODE_LOGPOST)[1]
+    assert int((st == 0).sum() + (st == 1).sum()) == len(got_vals)
