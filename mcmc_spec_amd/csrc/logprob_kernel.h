@@ -299,10 +299,14 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     }
     __syncthreads();
     int wst = D.status;
-    if (kRecipe && fast) {  // first star that failed decides, like the reference's star-by-star loop
+    if (kRecipe && fast) {  // first star that failed decides, like the reference's star-by-star loop ...
         wst = D.stat[0];
 #pragma unroll
         for (int k = 1; k < NS; ++k) wst = (wst == MSX_W_OK) ? D.stat[k] : wst;
+        // ... except that every star's logg is interpolated before the first star's spectrum is built (mft6.py:1149):
+        // a Teff outside the isochrone on a later star raises before an earlier star's bracket can
+#pragma unroll
+        for (int k = 1; k < NS; ++k) wst = (wst != MSX_W_REJECT && D.stat[k] == MSX_W_VALUEERROR) ? MSX_W_VALUEERROR : wst;
     }
     if (wst != MSX_W_OK) {
         if (tid == 0 && myseg == 0) {

@@ -252,12 +252,19 @@ __device__ __forceinline__ void build_recipe_wave(const DevProblem &P, const Rec
         if (lane == 0) { D.lp = lp; D.status = MSX_W_OK; }
         return;
     }
-    // A1 + A2 + A4
+    // A1 + A2 + A4.  The reference interpolates every star's logg before it builds the first star's spectrum
+    // (mft6.py:1149): a Teff outside the isochrone, on ANY star, raises before any bracket can
     int node[NS * 4];
     double w[NS * 4];
 #pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (!(t[s] >= T.iso_t[0]) || !(t[s] <= T.iso_t[P.niso - 1])) st = MSX_W_VALUEERROR;
+    if (st != MSX_W_OK) {
+        if (lane == 0) D.status = st;
+        return;
+    }
+#pragma unroll
     for (int s = 0; s < NS; ++s) {
-        if (!(t[s] >= T.iso_t[0]) || !(t[s] <= T.iso_t[P.niso - 1])) { st = MSX_W_VALUEERROR; break; }
         const int cnt = wave_count_le(T.iso_t, P.niso, t[s], lane);
         const double lg = interp_from_count(T.iso_t, T.iso_g, P.niso, t[s], cnt);  // mft6.py:1149
         int t1, t2, g1, g2;

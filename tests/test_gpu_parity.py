@@ -113,6 +113,18 @@ def test_error_conventions():
         eng.loglikelihood(bad)
     # ... but the posterior rejects it in the prior box first (mft6.py:1227) -> -inf, no exception
     assert eng.logposterior(bad) == -np.inf
+    # two different failures on the two stars: every star's logg is interpolated before the first star's spectrum is
+    # built (mft6.py:1149), so the secondary's ValueError wins over the primary's IndexError (beyond the last node)
+    both = c.theta[0].copy()
+    both[0], both[1] = 4325.0, 2874.0
+    from oracle import mft6_oracle as orc
+    with pytest.raises(ValueError):
+        orc.loglikelihood(list(both), c.fr, 2, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    with pytest.raises(ValueError):
+        eng.loglikelihood(both)
+    both[1] = 3500.0
+    with pytest.raises(IndexError):
+        eng.loglikelihood(both)
     # wrong length
     with pytest.raises(ValueError):
         eng.loglikelihood(np.zeros(5))
