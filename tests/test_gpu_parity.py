@@ -1032,3 +1032,44 @@ def test_register_recipe_on_a_dense_grid_with_holes():
     good = np.array([t for t in th if True])
     st = eng.ctx.logprob_batch(good, __import__('mcmc_spec_amd._lib', fromlist=['x']).MODE_LOGPOST)[1]
     assert int((st == 0).sum() + (st == 1).sum()) == len(got_vals)
+
+
+@pytest.mark.parametrize('which', ['B', 'C'])
+def test_statuses_and_values_beyond_the_box(which):
+    """loglikelihood over a box LARGER than the grid and the isochrone (binaries and triples): the exception class of
+    every walker (Teff outside the isochrone -> ValueError on any star first, beyond the last node -> IndexError,
+    missing node -> KeyError) and the values of the rest against the oracle.  Walkers below the grid's first node are
+    compared loosely: the reference's wrapped bracket (index -1) extrapolates between the first and the last node, the
+    model crosses zero near 2907 K and the likelihood is singular there (observed: <= 6e-6 relative on values of 1e10)."""
+    from oracle import mft6_oracle as orc
+    from mcmc_spec_amd import _lib
+    c = golden_case(which)
+    ns = c.nspec
+    eng = make_engine(c, rad_prior=(which == 'C'))
+    rng = np.random.default_rng(31 + ns)
+    n = 500
+    cols = [rng.uniform(2850, 4350, n) for _ in range(ns)] + [rng.uniform(0.0, 1.2, n)] + \
+           [rng.uniform(0.03, 1.6, n) for _ in range(ns)] + [rng.uniform(1 / 3200, 1 / 3.5, n)]
+    th = np.column_stack(cols)
+    th[:8, 0], th[:8, 1] = 4325.0, 2874.0            # IndexError on the primary, ValueError on the secondary: ValueError
+    exp_st = np.zeros(n, dtype=np.int32)
+    want = np.full(n, np.nan)
+    for i, t in enumerate(th):
+        try:
+            want[i] = orc.loglikelihood(list(t), c.fr, ns, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, c.matrix,
+                                        bandlib=c.bandlib)
+        except KeyError:
+            exp_st[i] = _lib.W_KEYERROR
+        except IndexError:
+            exp_st[i] = _lib.W_INDEXERROR
+        except ValueError:
+            exp_st[i] = _lib.W_VALUEERROR
+    got, st = eng.ctx.logprob_batch(th, _lib.MODE_LOGLIKE)
+    assert np.array_equal(st, exp_st), {int(k): int((st == k).sum()) for k in np.unique(st)}
+    assert (exp_st == _lib.W_VALUEERROR).sum() >= 8 and (exp_st == _lib.W_INDEXERROR).sum() >= 20
+    ok = exp_st == 0
+    inside = ok & np.all(th[:, :ns] >= 3000.0, axis=1)
+    assert inside.sum() >= 100 and rel_err(got[inside], want[inside]).max() < TIGHT
+    wrapped = ok & ~inside
+    if wrapped.any():
+        assert rel_err(got[wrapped], want[wrapped]).max() < 1e-4
