@@ -364,7 +364,7 @@ __device__ __forceinline__ void hist_prefix_inplace(BlockScratch &S) {
 template <int BT, class Elem>
 __device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
                                               BlockScratch &S, Elem &elem, double *med_out) {
-    constexpr int B = BT, nw = BT >> 6;  // the workgroup size is a compile-time constant of every kernel variant
+    constexpr int nw = BT >> 6;  // the workgroup size is a compile-time constant of every kernel variant
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
     const bool need_two = (npix & 1) == 0;
