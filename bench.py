@@ -284,9 +284,10 @@ def main():
     # the launch is a plain C call with pre-built arguments (no per-step Python marshalling)
     import ctypes as C
     fn = eng.ctx.lib.msx_logprob_batch_dev
-    # (binaries below 8192 px run the <= 128-VGPR, 44 KB-of-LDS variant at every batch size up to two walkers per CU:
-    # two of its workgroups fit a CU, so a CU or two held by RCCL's kernel at N > 1 costs no second round)
-    block = args.block
+    # With a collective in flight RCCL's kernel holds a CU or two.  The N = 1 variant (512 threads + 136 KB of LDS: one
+    # workgroup per CU, all 256 CUs needed at once) would run a second round for the displaced walkers, so N > 1
+    # launches the <= 128-VGPR variant, two of whose workgroups fit a CU (MSX_BLOCK_512_SHARED).  Same bits.
+    block = args.block if args.block else (_lib.BLOCK_512_SHARED if use_gather and args.npix < 8192 else 0)
 
     def calls_for(sp):
         # step i: problem i mod nprob (config 5 rehearsal), theta batch i mod nbatch, output buffer i mod 2
@@ -519,12 +520,12 @@ def main():
             bt = 512 if n <= 2 * cus else 256
         if bt == 256:
             kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
-        elif args.npix * 8 <= 70 * 1024:
+        elif args.npix * 8 <= 70 * 1024 and (n > cus or block == _lib.BLOCK_512_SHARED):
             kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (<= 128 VGPRs: two workgroups fit a CU; rows one star at a time)'
         elif args.npix * 8 * 3 > 130 * 1024:
-            kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU)'
+            kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU, four pixels per lane and trip)'
         else:
-            kernel_name = 'logprob_kernel<NS=2, 512 threads, PF> (one workgroup per CU, u / flux kept in LDS)'
+            kernel_name = 'logprob_kernel<NS=2, 512 threads, PF> (one workgroup per CU, u / flux kept in LDS, four pixels per lane and trip)'
         # ---- the roofline that bounds THIS design --------------------------------------------------------------
         # The kernel never streams the windowed grid from HBM: staging folds the resample into per-node tables of
         # 12 bytes per pixel (R float64 + H float32, 5.1 MB at config 2) that live in L2 / Infinity Cache, and a

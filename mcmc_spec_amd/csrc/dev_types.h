@@ -45,6 +45,10 @@ struct DevProblem {
     const float2 *dk2;     // [npair]         k[lo+1] - k[lo]
     const double2 *f2, *u2, *iv2;  // [npair] data flux, mapped wavelength u, 1/err^2 (element copies of pix_flux, pix_u, pix_ivar)
     int64_t npair;
+    // ... and the float32 ones in quads (staging_kernels.h::gather_quads_kernel): quad q = elements {1024 (q >> 9) + (q & 511), + 512}
+    const float4 *h4;      // [nt*ng][nquad]
+    const float4 *dk4;     // [nquad]
+    int64_t nquad;         // ceil(npair / 1024) * 512
     const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
     int64_t npix;
     double median_flux;

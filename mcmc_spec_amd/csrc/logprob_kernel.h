@@ -358,8 +358,12 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     MSX_STAMP(P, wk, 1);
 
     // ---- phase A ------------------------------------------------------------------------------------
+    // kQuad: the 512-thread fused variants walk the tables a QUAD (two elements, four pixels) per lane and trip and
+    // take the float32 values from the quad tables: one 16-byte load where two elements need two 8-byte ones
+    constexpr bool kQuad = kBlend && STAGE == 0 && MAXT == 512 && !GM && !SH;  // (the <= 128-VGPR variant has no room for a quad's rows)
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
     const float2 *rows_h[NC];   // H = hi t
+    const float4 *rows_h4[NC];  // ... by quad
     double w[NC];
     float wf[NC];
 #pragma unroll
@@ -367,6 +371,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const int64_t off = !kBlend ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
         rows_r[c] = P.r2 + off;
         rows_h[c] = P.h2 + off;
+        rows_h4[c] = P.h4 + (!kQuad ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * P.nquad);
         w[c] = !kBlend ? 0.0 : uniform_f64(D.w[c]);
         wf[c] = uniform_f32((float)w[c]);
     }
@@ -429,7 +434,51 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
       // scalar branch and a zero-fill per H load.
       auto trips = [&](auto red_c) __attribute__((always_inline)) {
       constexpr bool RED = decltype(red_c)::value;
-      {
+      if constexpr (kQuad) {
+      for (int e0 = seg * kSegElems; e0 < e_end; e0 += 2 * B) {  // (segments are whole numbers of quad trips)
+        const int eA = e0 + tid, eB = eA + B;
+        const bool liveA = eA < e_end, liveB = eB < e_end;
+        const int ecA = liveA ? eA : e_end - 1, ecB = liveB ? eB : e_end - 1;
+        const unsigned int oA = (unsigned int)ecA << 4, oB = (unsigned int)ecB << 4;
+        const unsigned int oq = (unsigned int)((e0 >> 1) + tid) << 4;  // quad (e0 / 1024) * 512 + tid, 16 bytes each
+        constexpr int G = SH ? 4 : NC;  // corners per group of loads
+        double sr[4] = {0.0, 0.0, 0.0, 0.0};
+        float sh[4] = {0.f, 0.f, 0.f, 0.f};
+        double2 klA = make_double2(0.0, 0.0), klB = klA;
+        float4 dk = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c0 = 0; c0 < NC; c0 += G) {
+            double2 rA[G], rB[G];
+            float4 hq[G];
+#pragma unroll
+            for (int c = 0; c < G; ++c) {
+                rA[c] = ld_off(rows_r[c0 + c], oA);
+                rB[c] = ld_off(rows_r[c0 + c], oB);
+                hq[c] = RED ? ld_off(rows_h4[c0 + c], oq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (c0 == 0 && RED) { klA = ld_off(P.kl2, oA); klB = ld_off(P.kl2, oB); dk = ld_off(P.dk4, oq); }
+            double r0[G], r1[G], r2[G], r3[G];
+            float h0[G], h1[G], h2[G], h3[G];
+#pragma unroll
+            for (int c = 0; c < G; ++c) {
+                r0[c] = rA[c].x; r1[c] = rA[c].y; r2[c] = rB[c].x; r3[c] = rB[c].y;
+                h0[c] = hq[c].x; h1[c] = hq[c].y; h2[c] = hq[c].z; h3[c] = hq[c].w;
+            }
+            blend_accumulate<G>(r0, h0, w + c0, wf + c0, RED, sr[0], sh[0]);
+            blend_accumulate<G>(r1, h1, w + c0, wf + c0, RED, sr[1], sh[1]);
+            blend_accumulate<G>(r2, h2, w + c0, wf + c0, RED, sr[2], sh[2]);
+            blend_accumulate<G>(r3, h3, w + c0, wf + c0, RED, sr[3], sh[3]);
+        }
+        double2 mA, mB;
+        mA.x = blend_finish(sr[0], sh[0], klA.x, (double)dk.x, redc, RED, e2tab);
+        mA.y = blend_finish(sr[1], sh[1], klA.y, (double)dk.y, redc, RED, e2tab);
+        mB.x = blend_finish(sr[2], sh[2], klB.x, (double)dk.z, redc, RED, e2tab);
+        mB.y = blend_finish(sr[3], sh[3], klB.y, (double)dk.w, redc, RED, e2tab);
+        const double2 fA = ld_off(P.f2, oA), uA = ld_off(P.u2, oA), fB = ld_off(P.f2, oB), uB = ld_off(P.u2, oB);
+        finish_elem(mA, fA, uA, ecA, liveA, std::integral_constant<int, 0>{});
+        finish_elem(mB, fB, uB, ecB, liveB, std::integral_constant<int, 0>{});
+      }
+      } else {
       for (int e0 = seg * kSegElems; e0 < e_end; e0 += B * SUB) {
         auto one = [&](auto sub_c) __attribute__((always_inline)) {
         constexpr int sub = decltype(sub_c)::value;

@@ -91,6 +91,7 @@ struct msx_ctx {
     int max_dyn_lds = 0;
     bool pf_ok = false;   // the LDS-staged-statics variants fit (msx_stage_problem)
     bool use_pf = true;   // MSX_NO_PF=1 in the environment turns them off (A/B measurements)
+    bool force_sh2 = false;  // MSX_NO_SH2=0: binaries take the <= 128-VGPR variant even with a CU to themselves (A/B measurements)
     bool zero_copy = true;   // host-pointer entry point without copy commands; MSX_ZERO_COPY=0 restores them
     bool model_in_global = false;
     // RCCL all-gather of log-probabilities: communicator + its own stream + per-slot events
@@ -320,10 +321,10 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     } else {
         // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
         const bool own_cu = A.n <= c->prop.multiProcessorCount || lds > 70 * 1024;  // (long spectra: one per CU anyway)
-        // binaries: the <= 128-VGPR variant (rows taken one star at a time, u / flux re-read by the chi^2 pass) whenever two
-        // workgroups fit a CU -- since the vector-instruction diet of round 2 it is also the fastest with a CU to itself
-        // (256 walkers x 4096 px: 17.6 us against 17.9 staged in LDS, 18.0 plain)
-        const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024;
+        // binaries between one and two walkers per CU: the <= 128-VGPR variant, two workgroups per CU.  With a CU to
+        // itself a workgroup takes the quad-walking variants (pixel statics staged in LDS when they fit): 256 walkers x
+        // 4096 px 16.7-16.9 us against 17.0-17.1 for the <= 128-VGPR variant; MSX_NO_SH2=0 in the environment forces the latter
+        const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024 && c->force_sh2;
         const bool pf = B == 512 && !shared512 && !sh2 && own_cu && c->pf_ok && c->use_pf;
         const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
         if (P.nspec == 2) {
@@ -388,6 +389,7 @@ int msx_create(int device, msx_ctx **out) {
     c->device = device;
     memset(&c->P, 0, sizeof(c->P));
     if (const char *e = getenv("MSX_NO_PF")) c->use_pf = !(e[0] == '1');
+    if (const char *e = getenv("MSX_NO_SH2")) c->force_sh2 = e[0] == '0';
     if (const char *e = getenv("MSX_ZERO_COPY")) c->zero_copy = !(e[0] == '0');
     *out = c;  // returned even on failure so the caller can read msx_last_error
     HIP_TRY(c, hipSetDevice(device));
@@ -663,6 +665,17 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
                        P.pix_ivar, p->npix, npair, d_kl2, d_dk2, d_f2, d_u2, d_iv2);
     HIP_TRY(c, hipGetLastError());
     P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.iv2 = d_iv2; P.npair = npair;
+    {   // the float32 tables in quads, for the 512-thread variants
+        const int64_t nquad = (npair + 1023) / 1024 * 512;
+        float4 *d_h4 = nullptr, *d_dk4 = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&d_h4, sizeof(float4) * nn * nquad)); tr.push_back(d_h4);
+        HIP_TRY(c, hipMalloc((void **)&d_dk4, sizeof(float4) * nquad)); tr.push_back(d_dk4);
+        const unsigned gq = (unsigned)((nquad + 255) / 256);
+        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, (unsigned)nn), dim3(256), 0, c->stream, d_h2, npair, nquad, d_h4);
+        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, 1), dim3(256), 0, c->stream, d_dk2, npair, nquad, d_dk4);
+        HIP_TRY(c, hipGetLastError());
+        P.h4 = d_h4; P.dk4 = d_dk4; P.nquad = nquad;
+    }
     // band integrals
     double *d_tab = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_tab, sizeof(double) * std::max<int64_t>(1, nn * nb))); tr.push_back(d_tab);

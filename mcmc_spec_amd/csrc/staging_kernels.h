@@ -76,6 +76,19 @@ __global__ void gather_statics_kernel(const double *__restrict__ kgrid, const in
     iv2[e] = make_double2(ivar[pa], ivar[pb]);
 }
 
+// The float32 tables once more in QUADS of four pixels: quad q = 512 J + t holds the elements eA = 1024 J + t and
+// eB = eA + 512 (pixels {x, x + 256, x + 1024, x + 1280}), so that a lane of a 512-thread workgroup fetches the H
+// (and dk) values of the two elements it takes per quad trip with ONE 16-byte load instead of two 8-byte ones.
+// src has `rows` rows of npair float2 (H: one row per grid node; dk: one row); dst rows of nquad float4.
+__global__ void gather_quads_kernel(const float2 *__restrict__ src, int64_t npair, int64_t nquad, float4 *__restrict__ dst) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nquad) return;
+    const int64_t eA = (q >> 9) * 1024 + (q & 511), eB = eA + 512;
+    const float2 *row = src + (int64_t)blockIdx.y * npair;
+    const float2 a = eA < npair ? row[eA] : make_float2(0.f, 0.f), b = eB < npair ? row[eB] : make_float2(0.f, 0.f);
+    dst[(int64_t)blockIdx.y * nquad + q] = make_float4(a.x, a.y, b.x, b.y);
+}
+
 // band_tab[node][b] = sum_i w_b[i] * grid[node][i0_b + i];  grid.x = band, grid.y = node
 __global__ void band_integral_kernel(const double *__restrict__ grid, int64_t nwl, const double *__restrict__ w,
                                      const int64_t *__restrict__ woff, const int64_t *__restrict__ i0,
