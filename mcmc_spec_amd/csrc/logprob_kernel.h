@@ -360,7 +360,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // ---- phase A ------------------------------------------------------------------------------------
     // kQuad: the 512-thread fused variants walk the tables a QUAD (two elements, four pixels) per lane and trip and
     // take the float32 values from the quad tables: one 16-byte load where two elements need two 8-byte ones
-    constexpr bool kQuad = kBlend && STAGE == 0 && MAXT == 512 && !SH;  // (the <= 128-VGPR variant has no room for a quad's rows)
+    constexpr bool kQuad = kBlend && MAXT == 512 && !SH;  // (the <= 128-VGPR variant has no room for a quad's rows)
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
     const float2 *rows_h[NC];   // H = hi t
     const float4 *rows_h4[NC];  // ... by quad
