@@ -132,11 +132,12 @@ int msx_stage_problem(msx_ctx *ctx, const msx_problem *p);
 int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n, int32_t ndim,
                       double *logp_out, int32_t *status_out);
 /* same with device pointers on a caller stream; does not synchronise (no launch allocates: every scratch buffer is
- * sized by msx_stage_problem).  block_threads: 0 = auto (binaries below 8192 pixels: 512 threads in the <= 128-VGPR
- * variant, two of which fit a CU, up to 2 x #CUs walkers -- up to #CUs for spectra of <= 2048 pixels -- and 256
- * threads three per CU beyond; spectra of >= 8192 pixels and triples: 512 threads, one workgroup per CU), or 256 /
- * 512, or MSX_BLOCK_512_SHARED = 512 threads in the <= 128-VGPR variant whatever the batch size.  The choice affects
- * speed only: every variant produces the same bits.                                                              */
+ * sized by msx_stage_problem).  block_threads: 0 = auto (up to #CUs walkers, spectra of >= 8192 pixels, triples: 512
+ * threads, one workgroup per CU; binaries below 8192 pixels between #CUs and 2 x #CUs walkers: 512 threads in the
+ * <= 128-VGPR variant, two of which fit a CU; beyond, and from #CUs walkers on for spectra of <= 2048 pixels: 256
+ * threads, three per CU), or 256 / 512, or MSX_BLOCK_512_SHARED = 512 threads in the <= 128-VGPR variant whatever
+ * the batch size (what a launch wants when another kernel, e.g. a collective, holds CUs at the same time).  The
+ * choice affects speed only: every variant produces the same bits.                                               */
 #define MSX_BLOCK_512_SHARED 1512
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
