@@ -518,7 +518,9 @@ def main():
             bt = 256
         else:
             bt = 512 if n <= 2 * cus else 256
-        if bt == 256:
+        if bt == 256 and n <= 2 * cus:
+            kernel_name = 'logprob_kernel<NS=2, 256 threads, two per CU> (four pixels per lane and trip)'
+        elif bt == 256:
             kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
         elif args.npix * 8 <= 70 * 1024 and (n > cus or block == _lib.BLOCK_512_SHARED):
             kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (<= 128 VGPRs: two workgroups fit a CU; rows one star at a time)'

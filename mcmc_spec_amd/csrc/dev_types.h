@@ -46,8 +46,10 @@ struct DevProblem {
     const double2 *f2, *u2, *iv2;  // [npair] data flux, mapped wavelength u, 1/err^2 (element copies of pix_flux, pix_u, pix_ivar)
     int64_t npair;
     // ... and the float32 ones in quads (staging_kernels.h::gather_quads_kernel): quad q = elements {1024 (q >> 9) + (q & 511), + 512}
-    const float4 *h4;      // [nt*ng][nquad]
+    const float4 *h4;      // [nt*ng][nquad]   512-thread workgroups: eB = eA + 512
     const float4 *dk4;     // [nquad]
+    const float4 *h4b;     // [nt*ng][nquad]   256-thread workgroups: eB = eA + 256
+    const float4 *dk4b;    // [nquad]
     int64_t nquad;         // ceil(npair / 1024) * 512
     const double *pix_t, *pix_u, *pix_flux, *pix_ivar;  // pix_ivar = 1/err^2 (chisq squares sigma, mft6.py:120)
     int64_t npix;

@@ -170,7 +170,7 @@ template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = f
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
-__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 3 : (MAXT == 512 && SH) ? 4 : 1)
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? (SH ? 2 : 3) : (MAXT == 512 && SH) ? 4 : 1)
 logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
                double gate_tmin, double gate_tmax, const SmpRec *__restrict__ smp_rec, DevProblem P,
                double *__restrict__ logp, int32_t *__restrict__ status) {
@@ -360,7 +360,9 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // ---- phase A ------------------------------------------------------------------------------------
     // kQuad: the 512-thread fused variants walk the tables a QUAD (two elements, four pixels) per lane and trip and
     // take the float32 values from the quad tables: one 16-byte load where two elements need two 8-byte ones
-    constexpr bool kQuad = kBlend && MAXT == 512 && !SH;  // (the <= 128-VGPR variant has no room for a quad's rows)
+    // (512 threads: not the <= 128-VGPR variant, which has no room for a quad's rows; 256 threads: only the variant
+    // that runs two per CU instead of three -- SH there -- and so has 256 VGPRs)
+    constexpr bool kQuad = kBlend && ((MAXT == 512 && !SH) || (MAXT == 256 && SH));
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
     const float2 *rows_h[NC];   // H = hi t
     const float4 *rows_h4[NC];  // ... by quad
@@ -371,7 +373,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const int64_t off = !kBlend ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
         rows_r[c] = P.r2 + off;
         rows_h[c] = P.h2 + off;
-        rows_h4[c] = P.h4 + (!kQuad ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * P.nquad);
+        rows_h4[c] = (MAXT == 512 ? P.h4 : P.h4b) + (!kQuad ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * P.nquad);
         w[c] = !kBlend ? 0.0 : uniform_f64(D.w[c]);
         wf[c] = uniform_f32((float)w[c]);
     }
@@ -441,7 +443,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const int ecA = liveA ? eA : e_end - 1, ecB = liveB ? eB : e_end - 1;
         const unsigned int oA = (unsigned int)ecA << 4, oB = (unsigned int)ecB << 4;
         const unsigned int oq = (unsigned int)((e0 >> 1) + tid) << 4;  // quad (e0 / 1024) * 512 + tid, 16 bytes each
-        constexpr int G = SH ? 4 : NC;  // corners per group of loads
+        constexpr int G = NC;  // corners per group of loads: all (the quad variants have the registers)
         double sr[4] = {0.0, 0.0, 0.0, 0.0};
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         double2 klA = make_double2(0.0, 0.0), klB = klA;
@@ -456,7 +458,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 rB[c] = ld_off(rows_r[c0 + c], oB);
                 hq[c] = RED ? ld_off(rows_h4[c0 + c], oq) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (c0 == 0 && RED) { klA = ld_off(P.kl2, oA); klB = ld_off(P.kl2, oB); dk = ld_off(P.dk4, oq); }
+            if (c0 == 0 && RED) { klA = ld_off(P.kl2, oA); klB = ld_off(P.kl2, oB); dk = ld_off(MAXT == 512 ? P.dk4 : P.dk4b, oq); }
             double r0[G], r1[G], r2[G], r3[G];
             float h0[G], h1[G], h2[G], h3[G];
 #pragma unroll
@@ -476,7 +478,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         mB.y = blend_finish(sr[3], sh[3], klB.y, (double)dk.w, redc, RED, e2tab);
         const double2 fA = ld_off(P.f2, oA), uA = ld_off(P.u2, oA), fB = ld_off(P.f2, oB), uB = ld_off(P.u2, oB);
         finish_elem(mA, fA, uA, ecA, liveA, std::integral_constant<int, 0>{});
-        finish_elem(mB, fB, uB, ecB, liveB, std::integral_constant<int, 0>{});
+        finish_elem(mB, fB, uB, ecB, liveB, std::integral_constant<int, SUB - 1>{});  // (256 threads: the trip's second element)
       }
       } else {
       for (int e0 = seg * kSegElems; e0 < e_end; e0 += B * SUB) {

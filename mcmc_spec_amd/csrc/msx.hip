@@ -91,6 +91,7 @@ struct msx_ctx {
     int max_dyn_lds = 0;
     bool pf_ok = false;   // the LDS-staged-statics variants fit (msx_stage_problem)
     bool use_pf = true;   // MSX_NO_PF=1 in the environment turns them off (A/B measurements)
+    int q256 = -1;           // 256-thread launches: the two-per-CU quad-trip variant always (1) / never (0) / up to two walkers per CU (-1); MSX_Q256
     bool force_sh2 = false;  // MSX_NO_SH2=0: binaries take the <= 128-VGPR variant even with a CU to themselves (A/B measurements)
     bool zero_copy = true;   // host-pointer entry point without copy commands; MSX_ZERO_COPY=0 restores them
     bool model_in_global = false;
@@ -328,7 +329,11 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
         const bool pf = B == 512 && !shared512 && !sh2 && own_cu && c->pf_ok && c->use_pf;
         const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
         if (P.nspec == 2) {
-            if (B == 256) MSX_GO(2, 2, 256, false, false, false, lds);
+            // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
+            // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
+            const bool q256 = c->q256 > 0 || (c->q256 < 0 && A.n <= 2 * (int64_t)c->prop.multiProcessorCount);
+            if (B == 256 && q256) MSX_GO(2, 2, 256, false, true, false, lds);
+            else if (B == 256) MSX_GO(2, 2, 256, false, false, false, lds);
             else if (pf) MSX_GO(2, 2, 512, false, false, true, lds_pf);
             else if (sh) MSX_GO(2, 2, 512, false, true, false, lds);   // two workgroups per CU
             else MSX_GO(2, 2, 512, false, false, false, lds);
@@ -360,6 +365,7 @@ hipError_t raise_stage() {
     hipError_t e = hipSuccess;
 #define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__, STAGE>)
     MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 512, false, false, false); MSX_R(2, 2, 512, false, true, false);
+    if (STAGE == 0) MSX_R(2, 2, 256, false, true, false);
     MSX_R(2, 2, 512, false, false, true);
     MSX_R(3, 2, 256, false, false, false); MSX_R(3, 2, 512, false, false, false);
     MSX_R(3, 2, 512, false, false, true);
@@ -390,6 +396,7 @@ int msx_create(int device, msx_ctx **out) {
     memset(&c->P, 0, sizeof(c->P));
     if (const char *e = getenv("MSX_NO_PF")) c->use_pf = !(e[0] == '1');
     if (const char *e = getenv("MSX_NO_SH2")) c->force_sh2 = e[0] == '0';
+    if (const char *e = getenv("MSX_Q256")) c->q256 = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("MSX_ZERO_COPY")) c->zero_copy = !(e[0] == '0');
     *out = c;  // returned even on failure so the caller can read msx_last_error
     HIP_TRY(c, hipSetDevice(device));
@@ -667,14 +674,18 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.iv2 = d_iv2; P.npair = npair;
     {   // the float32 tables in quads, for the 512-thread variants
         const int64_t nquad = (npair + 1023) / 1024 * 512;
-        float4 *d_h4 = nullptr, *d_dk4 = nullptr;
+        float4 *d_h4 = nullptr, *d_dk4 = nullptr, *d_h4b = nullptr, *d_dk4b = nullptr;
         HIP_TRY(c, hipMalloc((void **)&d_h4, sizeof(float4) * nn * nquad)); tr.push_back(d_h4);
         HIP_TRY(c, hipMalloc((void **)&d_dk4, sizeof(float4) * nquad)); tr.push_back(d_dk4);
+        HIP_TRY(c, hipMalloc((void **)&d_h4b, sizeof(float4) * nn * nquad)); tr.push_back(d_h4b);
+        HIP_TRY(c, hipMalloc((void **)&d_dk4b, sizeof(float4) * nquad)); tr.push_back(d_dk4b);
         const unsigned gq = (unsigned)((nquad + 255) / 256);
-        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, (unsigned)nn), dim3(256), 0, c->stream, d_h2, npair, nquad, d_h4);
-        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, 1), dim3(256), 0, c->stream, d_dk2, npair, nquad, d_dk4);
+        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, (unsigned)nn), dim3(256), 0, c->stream, d_h2, npair, nquad, (int64_t)512, d_h4);
+        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, 1), dim3(256), 0, c->stream, d_dk2, npair, nquad, (int64_t)512, d_dk4);
+        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, (unsigned)nn), dim3(256), 0, c->stream, d_h2, npair, nquad, (int64_t)256, d_h4b);
+        hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, 1), dim3(256), 0, c->stream, d_dk2, npair, nquad, (int64_t)256, d_dk4b);
         HIP_TRY(c, hipGetLastError());
-        P.h4 = d_h4; P.dk4 = d_dk4; P.nquad = nquad;
+        P.h4 = d_h4; P.dk4 = d_dk4; P.h4b = d_h4b; P.dk4b = d_dk4b; P.nquad = nquad;
     }
     // band integrals
     double *d_tab = nullptr;

@@ -80,10 +80,13 @@ __global__ void gather_statics_kernel(const double *__restrict__ kgrid, const in
 // eB = eA + 512 (pixels {x, x + 256, x + 1024, x + 1280}), so that a lane of a 512-thread workgroup fetches the H
 // (and dk) values of the two elements it takes per quad trip with ONE 16-byte load instead of two 8-byte ones.
 // src has `rows` rows of npair float2 (H: one row per grid node; dk: one row); dst rows of nquad float4.
-__global__ void gather_quads_kernel(const float2 *__restrict__ src, int64_t npair, int64_t nquad, float4 *__restrict__ dst) {
+// (stride = the workgroup size the table is for: 512, or 256 -- quad q = stride J + t holds elements eA = 2 stride J + t
+// and eB = eA + stride, the two elements a lane of such a workgroup takes per quad trip)
+__global__ void gather_quads_kernel(const float2 *__restrict__ src, int64_t npair, int64_t nquad, int64_t stride,
+                                    float4 *__restrict__ dst) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nquad) return;
-    const int64_t eA = (q >> 9) * 1024 + (q & 511), eB = eA + 512;
+    const int64_t eA = (q / stride) * 2 * stride + (q % stride), eB = eA + stride;
     const float2 *row = src + (int64_t)blockIdx.y * npair;
     const float2 a = eA < npair ? row[eA] : make_float2(0.f, 0.f), b = eB < npair ? row[eB] : make_float2(0.f, 0.f);
     dst[(int64_t)blockIdx.y * nquad + q] = make_float4(a.x, a.y, b.x, b.y);
