@@ -444,6 +444,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const unsigned int oA = (unsigned int)ecA << 4, oB = (unsigned int)ecB << 4;
         const unsigned int oq = (unsigned int)((e0 >> 1) + tid) << 4;  // quad (e0 / 1024) * 512 + tid, 16 bytes each
         constexpr int G = NC;  // corners per group of loads: all (the quad variants have the registers)
+        // data flux and u: with the rows at 512 threads (26 walkers 15.35 -> 14.65 us, 4 x 32,768 px 35.9 -> 34.7),
+        // after the blend at 256 (two workgroups per CU: 512 walkers 16.2 us early against 15.95 late)
+        constexpr bool kEarlyFUq = MAXT == 512;
+        double2 fA = make_double2(0.0, 0.0), uA = fA, fB = fA, uB = fA;
+        if (kEarlyFUq) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
         double sr[4] = {0.0, 0.0, 0.0, 0.0};
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         double2 klA = make_double2(0.0, 0.0), klB = klA;
@@ -476,7 +481,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         mA.y = blend_finish(sr[1], sh[1], klA.y, (double)dk.y, redc, RED, e2tab);
         mB.x = blend_finish(sr[2], sh[2], klB.x, (double)dk.z, redc, RED, e2tab);
         mB.y = blend_finish(sr[3], sh[3], klB.y, (double)dk.w, redc, RED, e2tab);
-        const double2 fA = ld_off(P.f2, oA), uA = ld_off(P.u2, oA), fB = ld_off(P.f2, oB), uB = ld_off(P.u2, oB);
+        if (!kEarlyFUq) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
         finish_elem(mA, fA, uA, ecA, liveA, std::integral_constant<int, 0>{});
         finish_elem(mB, fB, uB, ecB, liveB, std::integral_constant<int, SUB - 1>{});  // (256 threads: the trip's second element)
       }
