@@ -34,6 +34,7 @@ extern "C" {
 #define MSX_W_KEYERROR 2   /* a needed grid node is not staged                 (mft6.py:489-500)   */
 #define MSX_W_INDEXERROR 3 /* logg/Teff bracket runs past the last node        (mft6.py:453,477)   */
 #define MSX_W_VALUEERROR 4 /* Teff outside the isochrone table                 (mft6.py:95)        */
+#define MSX_W_HANDOVER 5   /* device fault, not a reference error: a linked launch's workgroups did not meet (MSX_PATH_LINKED) */
 
 /* evaluation modes for msx_logprob_batch* (modes 4 and 5 are reached through msx_opt_step / msx_opt_init) */
 #define MSX_MODE_LOGLIKE 0      /* loglikelihood   (mft6.py:1139-1205)                              */
@@ -160,6 +161,12 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
 #define MSX_PATH_FUSED 1
 #define MSX_PATH_SPLIT 2
 #define MSX_PATH_WIDE 3
+/* LINKED: the wide form in ONE launch.  The workgroups of a walker's first S-1 segments publish their model values
+ * and partials and leave; the workgroup of the last segment waits for them inside the kernel (bounded: 20 ms, then the
+ * walker reports MSX_W_HANDOVER), and runs the median / chi^2 phases.  Same bits.  MSX_PATH_AUTO takes it while
+ * walkers x segments <= #CUs / 2 (MSX_LINKED=0 in the environment: never; =1: whenever the spectrum has 2..8
+ * segments): 16 walkers x 16,384 px 29.1 us against 34.0 fused; with every CU busy it loses.      */
+#define MSX_PATH_LINKED 4
 int msx_set_path(msx_ctx *ctx, int32_t path);
 
 /* ---- f4: the pre-optimiser's chi^2 (fit_spec, mft6.py:856-1137) on the same kernel --------------- */

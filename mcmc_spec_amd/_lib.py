@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get('MSX_LIB') or os.path.join(_HERE, 'libmsx.so')
 
 MSX_OK = 0
 MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
-W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR = 0, 1, 2, 3, 4
+W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR, W_HANDOVER = 0, 1, 2, 3, 4, 5
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
-PATH_AUTO, PATH_FUSED, PATH_SPLIT, PATH_WIDE = 0, 1, 2, 3  # include/msx.h MSX_PATH_*
+PATH_AUTO, PATH_FUSED, PATH_SPLIT, PATH_WIDE, PATH_LINKED = 0, 1, 2, 3, 4  # include/msx.h MSX_PATH_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)
@@ -248,7 +248,7 @@ class Context:
                                                   C.c_void_p(stream_ptr), int(block_threads)))
 
     def set_path(self, path):
-        """PATH_AUTO / PATH_FUSED / PATH_SPLIT / PATH_WIDE: which form of the hot path launches take (same bits either way)."""
+        """PATH_AUTO / PATH_FUSED / PATH_SPLIT / PATH_WIDE / PATH_LINKED: which form of the hot path launches take (same bits either way)."""
         self.check(self.lib.msx_set_path(self.h, int(path)))
 
     def opt_init(self, theta0):

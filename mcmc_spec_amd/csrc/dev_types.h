@@ -80,6 +80,7 @@ struct DevProblem {
     double *model_scratch;     // [n][npix]: the model vectors of the split path (stages 3 -> 4) and of the GM variants
     struct WalkerRec *rec;     // [n] split / wide path: what the recipe stage leaves for the later ones
     struct SegPart *segparts;  // [n][segments] wide path: STAGE 3's partials
+    int32_t *seg_flag;         // [n] linked path: producers that have published their segment (the joiner resets it)
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;
@@ -101,7 +102,8 @@ struct DevProblem {
 };
 
 #ifdef MSX_STAMPS
-#define MSX_STAMP(P, wk, i) do { if (threadIdx.x == 0) (P).stamps[(wk) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+__shared__ int msx_stamp_off;  // linked path: a walker's producers leave the stamps to its joiner
+#define MSX_STAMP(P, wk, i) do { if (threadIdx.x == 0 && !msx_stamp_off) (P).stamps[(wk) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MSX_STAMP(P, wk, i) do { } while (0)
 #endif
@@ -135,6 +137,7 @@ constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPr
 constexpr int kTileWalkers = 8;     // split path: walkers that share one load of the pair rows
 constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the wide path
 constexpr int kSegBins = 2048;      // (= kLogBins, median.h)
+constexpr unsigned long long kHandoverTicks = 2000000ull;  // linked path: a joiner gives up after 20 ms of the 100 MHz wall clock
 
 // wide path: what STAGE 3 leaves per (walker, segment) for STAGE 4
 struct alignas(16) SegPart {

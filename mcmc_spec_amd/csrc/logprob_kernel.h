@@ -160,6 +160,14 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //   STAGE = 4  one workgroup per walker: model vector scratch -> LDS, the segments' partials combined (the fit
 //              sums serially over the segments, exactly as the fused kernel adds them), then the median / chi^2
 //              phases as ever
+// and the LINKED path, the wide path in ONE launch:
+//   STAGE = 5  one workgroup per (walker, segment), block = segment * pad8(n) + walker.  The workgroups of segments
+//              0 .. S-2 are PRODUCERS: stage 3's work, then one release-increment of P.seg_flag[wk] (agent scope) and
+//              exit -- they never wait.  The workgroup of the LAST segment is the walker's JOINER: it blends its own
+//              segment into LDS, waits for the S-1 increments (bounded: kHandoverTicks, then the walker fails with
+//              MSX_W_HANDOVER), takes the producers' model values and partials as stage 4 does and goes on as the
+//              fused kernel.  Joiners have the highest block indices: every producer a joiner waits for was
+//              dispatched before it, so the wait needs no co-residency guarantee beyond in-order dispatch.
 //
 // TABLE LAYOUT.  A CU pulls data from L2 at ~32 B per clock when every lane loads 16 bytes, and no faster per
 // instruction when lanes load less -- so every per-pixel table the blend reads is stored in ELEMENTS of two pixels,
@@ -193,15 +201,21 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
     __shared__ double e2tab[kExp2Tab];              // 2^(j/32) for the reddening factor (blend.h)
-    constexpr bool kRecipe = STAGE == 0 || STAGE == 1 || STAGE == 3;  // this stage runs phase 0
-    constexpr bool kBlend = STAGE == 0 || STAGE == 3;                 // ... computes model values from the tables
+    constexpr bool kRecipe = STAGE == 0 || STAGE == 1 || STAGE == 3 || STAGE == 5;  // this stage runs phase 0
+    constexpr bool kBlend = STAGE == 0 || STAGE == 3 || STAGE == 5;                 // ... computes model values from the tables
+    constexpr bool kSegs = STAGE == 3 || STAGE == 5;                                // one workgroup per (walker, segment)
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
     const bool smp_on = (ng_mode_fast >> 17) & 1;  // device-resident sampler: theta is a proposal built here (= P.smp_on)
-    const int nsegs = STAGE == 3 ? (ng_mode_fast >> 24) & 0xff : 1;  // STAGE 3: workgroups per walker
-    const int64_t wk = STAGE == 3 ? blockIdx.x / nsegs : blockIdx.x;
-    const int myseg = STAGE == 3 ? (int)(blockIdx.x - wk * nsegs) : 0;
+    const int nsegs = kSegs ? (ng_mode_fast >> 24) & 0xff : 1;  // STAGE 3 / 5: workgroups per walker
+    const int64_t npad = (n + 7) & ~7ll;                        // STAGE 5: a walker's workgroups are a multiple of 8 blocks apart
+    const int64_t wk = STAGE == 3 ? blockIdx.x / nsegs : STAGE == 5 ? blockIdx.x % npad : blockIdx.x;
+    const int myseg = STAGE == 3 ? (int)(blockIdx.x - wk * nsegs) : STAGE == 5 ? (int)(blockIdx.x / npad) : 0;
+    const bool producer = STAGE == 5 && myseg != nsegs - 1;  // (uniform)
+#ifdef MSX_STAMPS
+    if (threadIdx.x == 0) msx_stamp_off = (MSX_STAMPS == 2) ? (STAGE == 5 && !producer) : producer;  // (-DMSX_STAMPS=2: the producers' stamps)
+#endif
     RecipeRegs RR;
     if (kRecipe && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
@@ -215,7 +229,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     if (!kRecipe && P.rec[wk].status != MSX_W_OK) return;  // an earlier stage wrote this walker's final value (uniform branch)
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
     const double *__restrict__ model_in = (STAGE == 2 || STAGE == 4) ? P.model_scratch + wk * P.npix : nullptr;
-    double *const model_out = STAGE == 3 ? P.model_scratch + wk * P.npix : nullptr;
+    double *const model_out = (STAGE == 3 || producer) ? P.model_scratch + wk * P.npix : nullptr;
     const int tid = threadIdx.x;
     constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
     const int lane = tid & 63, wave = tid >> 6;
@@ -282,7 +296,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     }
     constexpr int NC = NS * 4;
     const int nseg_all = (ne + kSegElems - 1) / kSegElems;
-    const int seg_lo = STAGE == 3 ? myseg : 0, seg_hi = STAGE == 3 ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
+    const int seg_lo = kSegs ? myseg : 0, seg_hi = kSegs ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
     if (kRecipe && fast && wave == NS && !prior_late) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
     if (kRecipe) {
         if (fast) {
@@ -416,8 +430,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         for (int u = 0; u < U; ++u) {
             if (ok[u]) {
                 const double m = mm[u];
-                if (STAGE == 3) model_out[pp[u]] = m;                // the wide path's scratch (read back by STAGE 4)
-                else if (!(GM && STAGE == 2)) model[pp[u]] = m;      // (GM stage 2: the scratch row IS the model vector)
+                // (GM stage 2: the scratch row IS the model vector.  The segment kernels of the wide / linked paths
+                // write LDS too and copy the segment out after the loop: a global store among the loop's loads makes
+                // every wait for a row a wait for everything in flight -- 28-30k cycles per segment instead of 21k)
+                if (!(GM && STAGE == 2)) model[pp[u]] = m;
                 const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
                 const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
                 constexpr int slot = sub * U;  // (+ u: both unrolled)
@@ -553,14 +569,83 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
       if (wave < 3) qrun += reduce_published<MAXT>(&red[wave][0][0], lane);
       if (seg + 1 < seg_hi) __syncthreads();  // the next segment rewrites red
     }
+    if (STAGE == 3 || producer) {
+        // this segment's model values: LDS -> the scratch row (read back by STAGE 4 / the walker's joiner)
+        const int p_lo = myseg * kSegElems * 2, p_hi = (p_lo + kSegElems * 2 < npix) ? p_lo + kSegElems * 2 : npix;
+        if (((npix | p_hi) & 1) == 0) {
+            const double2 *src = reinterpret_cast<const double2 *>(model);
+            double2 *dst = reinterpret_cast<double2 *>(model_out);
+            for (int i = (p_lo >> 1) + tid; i < (p_hi >> 1); i += B) dst[i] = src[i];
+        } else {
+            for (int i = p_lo + tid; i < p_hi; i += B) model_out[i] = model[i];
+        }
+    }
     MSX_STAMP(P, wk, 2);
     // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
     // bound by the CU's memory pipeline and wave 0's loads are served first, so wave 0 leaves the pixel loop
     // thousands of cycles before the last wave.  (Other modes: inside block_median.)
     // (fused kernel: both run in waves 1 and 2 while wave 0 ranks the median's candidates, see phase B)
-    const bool late_side = STAGE == 0 && kRecipe && early;
-    if (STAGE != 0 && kRecipe && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
-    if (STAGE != 0 && kRecipe && fast && prior_late && wave == 1 && myseg == 0) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    const bool late_side = (STAGE == 0 || STAGE == 5) && kRecipe && early;
+    if (STAGE == 3 && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
+    if (STAGE == 3 && fast && prior_late && wave == 1 && myseg == 0) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    if (STAGE == 5 && !producer) {
+        // ---- the joiner meets its producers ----
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            int seen;
+            for (;;) {
+                seen = __hip_atomic_load(P.seg_flag + wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen >= nsegs - 1 || wall_clock64() - t0 > kHandoverTicks) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (seen >= nsegs - 1) __hip_atomic_store(P.seg_flag + wk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            S.has_second = seen >= nsegs - 1 ? 0u : ~0u;  // (the median's own flag, 0 on its entry: ~0 = the producers never came)
+        }
+        if (STAGE == 5) MSX_STAMP(P, wk, 5);
+        __syncthreads();
+        if (S.has_second != 0u) {
+            if (tid == 0) walker_done(P, D, wk, ndim, NAN, MSX_W_HANDOVER, logp, status);
+            return;
+        }
+        // their model values (whole segments: pixels [0, 8192 (S-1)) ) into LDS, their histogram counts onto this
+        // segment's, their fit sums before this segment's -- the order the fused kernel adds them in
+        const double *msrc = P.model_scratch + wk * P.npix;
+        const int nprod = (nsegs - 1) * kSegElems * 2;
+        const SegPart *sp = P.segparts + wk * nseg_all;
+        static_assert(kLogBins == 4 * MAXT || STAGE != 5, "four counters per thread");
+        uint4 hc = reinterpret_cast<const uint4 *>(sp[0].hist)[tid];  // (requested first; added below)
+        if ((npix & 1) == 0) {
+            // every load of a round in flight before its first store (a segment is 8 rounds of 512 x 16 bytes)
+            const double2 *src = reinterpret_cast<const double2 *>(msrc);
+            double2 *dst = reinterpret_cast<double2 *>(model);
+            for (int i0 = 0; i0 < (nprod >> 1); i0 += 8 * B) {
+                const double2 *a = src + i0 + tid;
+                double2 *d = dst + i0 + tid;
+                const double2 v0 = a[0], v1 = a[B], v2 = a[2 * B], v3 = a[3 * B], v4 = a[4 * B], v5 = a[5 * B], v6 = a[6 * B],
+                              v7 = a[7 * B];
+                d[0] = v0; d[B] = v1; d[2 * B] = v2; d[3 * B] = v3; d[4 * B] = v4; d[5 * B] = v5; d[6 * B] = v6; d[7 * B] = v7;
+            }
+        } else {
+            for (int i = tid; i < nprod; i += B) model[i] = msrc[i];
+        }
+        {
+            uint4 mine = reinterpret_cast<uint4 *>(S.hist)[tid];
+            for (int g = 0;; ) {
+                mine.x += hc.x; mine.y += hc.y; mine.z += hc.z; mine.w += hc.w;
+                if (++g >= nsegs - 1) break;
+                hc = reinterpret_cast<const uint4 *>(sp[g].hist)[tid];
+            }
+            reinterpret_cast<uint4 *>(S.hist)[tid] = mine;
+        }
+        if (wave < 3) {
+            double acc = 0.0;
+            for (int g = 0; g < nsegs - 1; ++g) acc += sp[g].q[wave];
+            qrun = acc + qrun;
+        }
+        __syncthreads();  // the counters are complete: running totals next
+        if (STAGE == 5) MSX_STAMP(P, wk, 6);
+    }
     if (STAGE == 4) {
         // the model vector from the scratch into LDS (the median's passes want it there) ...
         if ((npix & 1) == 0) {
@@ -583,7 +668,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         if (early) __syncthreads();  // the counters are complete: running totals next
     }
     // the early histogram is complete (the segment loop's barrier): its running totals, published by the barrier below
-    if (early && STAGE != 3) hist_prefix_inplace<MAXT>(S);
+    if (early && STAGE != 3 && !producer) hist_prefix_inplace<MAXT>(S);
     {
         // value range: order-preserving keys, a NaN anywhere counts as above +inf
         const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
@@ -595,7 +680,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             S.kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
             if (wave < 3) S.q[0][wave] = qrun;
         }
-        if (STAGE == 4 && tid < nseg_all) {  // (the segments' ranges ride in the slots of waves that have none of their own)
+        const int nother = STAGE == 4 ? nseg_all : (STAGE == 5 && !producer) ? nsegs - 1 : 0;  // segments blended elsewhere
+        if (tid < nother) {  // (the segments' ranges ride in the slots of waves that have none of their own)
             S.kmin[nw + tid] = P.segparts[wk * nseg_all + tid].kmin;
             S.kmax[nw + tid] = P.segparts[wk * nseg_all + tid].kmax;
         }
@@ -603,20 +689,29 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
 #pragma unroll
         for (int i = 0; i < 3; ++i) q[i] = S.q[0][i];
         kmin = S.kmin[0]; kmax = S.kmax[0];
-        const int nr = STAGE == 4 ? nw + nseg_all : nw;
+        const int nr = nw + nother;
         for (int x = 1; x < nr; ++x) {
             kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
             kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
         }
     }
-    if (STAGE == 3) {
-        // the segment's partials, and from segment 0 the recipe's scalars, for STAGE 4
+    if (STAGE == 3 || producer) {
+        // the segment's partials, and from segment 0 the recipe's scalars, for STAGE 4 (STAGE 5: for the joiner)
         SegPart *sp = P.segparts + wk * nseg_all + myseg;
         for (int b = tid; b < kLogBins; b += B) sp->hist[b] = S.hist[b];
         if (tid == 0) { sp->q[0] = q[0]; sp->q[1] = q[1]; sp->q[2] = q[2]; sp->kmin = kmin; sp->kmax = kmax; }
-        if (myseg == 0 && tid == kWave) {
+        if (STAGE == 3 && myseg == 0 && tid == kWave) {
             WalkerRec *R = P.rec + wk;
             R->lp = D.lp; R->chi_extra = D.chi_extra; R->status = MSX_W_OK;
+        }
+        if (STAGE == 5) {
+            // every thread's stores (model values, partials) have left the CU at the barrier; one agent-scope release
+            // by thread 0 then publishes them together with the increment
+            MSX_STAMP(P, wk, 3);
+            __syncthreads();
+            MSX_STAMP(P, wk, 4);
+            if (tid == 0) __hip_atomic_fetch_add(P.seg_flag + wk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            MSX_STAMP(P, wk, 7);
         }
         return;
     }
@@ -679,7 +774,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         __syncthreads();
     }
     MSX_STAMP(P, wk, 4);
-    MSX_STAMP(P, wk, 5);
+    if (STAGE != 5) MSX_STAMP(P, wk, 5);
 
     // ---- phase C: median scale, quadratic continuum fit, chi^2 (A8.2, A8.3, A9) ------------------
     // Pre-optimiser variants (fit_spec, mft6.py:856-1137): OPT_INIT normalises the data against the
@@ -726,7 +821,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             }
         }
     }
-    MSX_STAMP(P, wk, 6);
+    if (STAGE != 5) MSX_STAMP(P, wk, 6);
     if (!fused) red[0][wave][lane] = lane_partial<vk>(chia);
     if (opt_init) {
         const unsigned long long a = wave_min_u64(dmin), b = wave_max_u64(dmax);

@@ -17,7 +17,7 @@ struct alignas(16) BlockScratch {
     unsigned long long above[kMaxWaves];
     double chi[kMaxWaves];
     unsigned int wave_tot[kMaxWaves];
-    unsigned int hist[kLogBins];  // block_median and radix_select use the first kBins / 256
+    alignas(16) unsigned int hist[kLogBins];  // block_median and radix_select use the first kBins / 256
     unsigned long long cand[kSelectFinish];
     unsigned long long sel_result[2];
     unsigned int sel_bin, sel_k, sel_cnt, cand_n, has_second;

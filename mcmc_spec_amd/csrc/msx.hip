@@ -108,6 +108,7 @@ struct msx_ctx {
     int32_t *d_perm = nullptr, *d_hdr = nullptr, *d_tmp = nullptr;
     TileHdr *d_tiles = nullptr;
     SegPart *d_segparts = nullptr;  // wide path: [split_batch][segments]
+    int32_t *d_seg_flag = nullptr;  // linked path: [split_batch] producers arrived (zero between launches)
     int nseg = 1;                   // segments of the staged spectrum (8192 pixels each)
     int64_t split_batch = 0;        // walkers per sub-batch (0 = split path unavailable for this problem)
     // MSX_PATH_AUTO takes the split path at / above these sizes.  Measured: the fused kernel is bound by
@@ -120,6 +121,7 @@ struct msx_ctx {
     // measured, the blend of 128 walkers x 16,384 px already draws ~10 TB/s from the L2s on 128 CUs and
     // 256 CUs draw 11 -- the L2 -> CU fabric, not the CU count, bounds it, and the second launch costs more than it saves.
     int64_t wide_max_blocks_per_cu = 0;
+    int32_t linked = -1;            // MSX_LINKED: -1 = automatic (walkers x segments <= #CUs / 2), 0 never, 1 whenever possible
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
     unsigned char *d_recipe_block = nullptr;  // ... and its tables in one block (dev_types.h), freed with the problem
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
@@ -198,10 +200,10 @@ void free_problem(msx_ctx *c) {
     if (c->d_opt_med) (void)hipFree(c->d_opt_med);
     c->d_opt_flux = c->d_opt_med = nullptr;
     c->opt_chains = 0;
-    void *sp[] = {c->d_rec, c->d_perm, c->d_hdr, c->d_tmp, c->d_tiles, c->d_model_scratch, c->d_segparts};
+    void *sp[] = {c->d_rec, c->d_perm, c->d_hdr, c->d_tmp, c->d_tiles, c->d_model_scratch, c->d_segparts, c->d_seg_flag};
     for (void *p : sp)
         if (p) (void)hipFree(p);
-    c->d_rec = nullptr; c->d_perm = c->d_hdr = c->d_tmp = nullptr; c->d_tiles = nullptr; c->d_segparts = nullptr;
+    c->d_rec = nullptr; c->d_perm = c->d_hdr = c->d_tmp = nullptr; c->d_tiles = nullptr; c->d_segparts = nullptr; c->d_seg_flag = nullptr;
     c->d_model_scratch = nullptr; c->cap_model_scratch = 0; c->split_batch = 0;
 }
 
@@ -301,7 +303,8 @@ DevProblem problem_at(const DevProblem &P0, int64_t off, int mode, int ndim) {
 //   STAGE 1 the recipe alone: 256 threads, no dynamic LDS.
 template <int STAGE>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
-    const dim3 g((unsigned)(STAGE == 3 ? A.n * c->nseg : A.n));
+    // (STAGE 5: block = segment * pad8(n) + walker, see the kernel)
+    const dim3 g((unsigned)(STAGE == 3 ? A.n * c->nseg : STAGE == 5 ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
     const size_t lds = sizeof(double) * (size_t)P.npix;
 #define MSX_LEAD_ARGS (P.smp_on ? (const double *)P.smp_coords : A.theta), (const unsigned char *)c->d_recipe_block, A.niso_nt, \
                       A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, P.smp_rec
@@ -312,9 +315,9 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
     if constexpr (STAGE == 1) {
         if (P.nspec == 2) MSX_GO(2, 2, 256, false, false, false, 0); else MSX_GO(3, 2, 256, false, false, false, 0);
-    } else if constexpr (STAGE == 3) {  // (the grid is walkers x segments; the model goes to the scratch: no dynamic LDS)
-        if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, 0); else MSX_GO(3, 2, 512, false, false, false, 0);
-    } else if constexpr (STAGE == 4) {
+    } else if constexpr (STAGE == 3) {  // (the grid is walkers x segments; a segment's model values pass through LDS)
+        if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
+    } else if constexpr (STAGE == 4 || STAGE == 5) {  // (STAGE 5: the joiner holds the whole model vector; one workgroup per CU)
         if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
     } else if (c->model_in_global) {
         // spectra longer than the LDS: the model vector lives in the global scratch (STAGE 0 writes it there itself)
@@ -379,6 +382,10 @@ int raise_dynamic_lds_limits(msx_ctx *c) {
     HIP_TRY(c, raise_stage<2>());
     HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 4>));
     HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 4>));
+    HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 3>));
+    HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 3>));
+    HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 5>));
+    HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 5>));
     HIP_TRY(c, raise_one(broaden_conv_kernel));
     done[c->device] = true;
     return MSX_OK;
@@ -397,6 +404,7 @@ int msx_create(int device, msx_ctx **out) {
     if (const char *e = getenv("MSX_NO_PF")) c->use_pf = !(e[0] == '1');
     if (const char *e = getenv("MSX_NO_SH2")) c->force_sh2 = e[0] == '0';
     if (const char *e = getenv("MSX_Q256")) c->q256 = e[0] == '1' ? 1 : 0;
+    if (const char *e = getenv("MSX_LINKED")) c->linked = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("MSX_ZERO_COPY")) c->zero_copy = !(e[0] == '0');
     *out = c;  // returned even on failure so the caller can read msx_last_error
     HIP_TRY(c, hipSetDevice(device));
@@ -756,6 +764,9 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         P.model_scratch = c->d_model_scratch;
         P.rec = c->d_rec;
         P.segparts = c->d_segparts;
+        HIP_TRY(c, hipMalloc((void **)&c->d_seg_flag, sizeof(int32_t) * sb));
+        HIP_TRY(c, hipMemset(c->d_seg_flag, 0, sizeof(int32_t) * sb));
+        P.seg_flag = c->d_seg_flag;
         if (const char *e = getenv("MSX_SPLIT_MIN")) c->split_min_walkers = std::max<int64_t>(1, atoll(e));
         if (const char *e = getenv("MSX_SPLIT_MIN_NPIX")) c->split_min_npix = std::max<int64_t>(1, atoll(e));
         if (const char *e = getenv("MSX_WIDE_MAX")) c->wide_max_blocks_per_cu = std::max<int64_t>(0, atoll(e));
@@ -788,7 +799,7 @@ int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
 #endif
 
 int msx_set_path(msx_ctx *c, int32_t path) {
-    if (!c || path < MSX_PATH_AUTO || path > MSX_PATH_WIDE) return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path");
+    if (!c || path < MSX_PATH_AUTO || path > MSX_PATH_LINKED) return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path");
     c->path = path;
     return MSX_OK;
 }
@@ -835,14 +846,25 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     const int64_t cus0 = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     const bool can_wide = can_split && c->nseg >= 2 && c->nseg <= 8 && !c->model_in_global;
     bool wide = can_wide && !split && n * c->nseg <= c->wide_max_blocks_per_cu * cus0;
-    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_SPLIT) wide = false;
+    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_SPLIT || c->path == MSX_PATH_LINKED) wide = false;
     if (c->path == MSX_PATH_WIDE) {
         if (!can_wide) return fail(c, MSX_ERR_STATE, "msx_set_path(WIDE): needs a spectrum of 2..8 segments of 8192 pixels and a mode with a split form");
         wide = true;
     }
+    // linked (STAGE 5): the wide form in one launch -- the segments' workgroups hand over to the walker's last one
+    // inside the kernel.  MSX_PATH_AUTO takes it while the launch fills at most HALF the CUs (16 walkers x 16,384 px
+    // 29.1 against 34.0 us fused, 64 walkers 32.1 against 33.9; at 128 walkers every CU is busy, the blend runs at the
+    // L2's aggregate rate instead of the CU's own and the hand-over's fences cost more than the blend gains: 36.9
+    // against 34.8).  MSX_LINKED=0 / 1 in the environment: never / whenever possible.
+    bool linked = can_wide && !split && !wide && c->linked != 0 && (c->linked > 0 || 2 * n * c->nseg <= cus0);
+    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_SPLIT || c->path == MSX_PATH_WIDE) linked = false;
+    if (c->path == MSX_PATH_LINKED) {
+        if (!can_wide) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels and a mode with a split form");
+        linked = true;
+    }
     // sub-batches: the split path's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
     // hold split_batch walkers
-    const int64_t step = (split || wide || c->model_in_global) ? c->split_batch : n;
+    const int64_t step = (split || wide || linked || c->model_in_global) ? c->split_batch : n;
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min<int64_t>(step, n - off);
@@ -855,6 +877,12 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
             A3.ng_mode_fast |= c->nseg << 24;
             if ((rc = launch_logprob<3>(c, P, A3, 512, false))) return rc;
             if ((rc = launch_logprob<4>(c, P, A, 512, false))) return rc;
+            continue;
+        }
+        if (linked) {
+            LaunchArgs A5 = A;
+            A5.ng_mode_fast |= c->nseg << 24;
+            if ((rc = launch_logprob<5>(c, P, A5, 512, false))) return rc;
             continue;
         }
         if (!split) {

@@ -152,7 +152,7 @@ def test_split_spectrum_longer_than_lds():
 def three(eng, fn, *a, **k):
     from mcmc_spec_amd import _lib
     out = []
-    for path in (_lib.PATH_FUSED, _lib.PATH_WIDE, _lib.PATH_SPLIT):
+    for path in (_lib.PATH_FUSED, _lib.PATH_WIDE, _lib.PATH_SPLIT, _lib.PATH_LINKED):
         eng.ctx.set_path(path)
         out.append(fn(*a, **k))
     eng.ctx.set_path(_lib.PATH_AUTO)
@@ -176,11 +176,14 @@ def test_wide_path_config4_bits(n):
     if n >= 5:
         th[1, 1] = 2999.0            # rejected by the prior box: segment 0 of stage 3 alone finishes it
         th[3, 2] = 0.0               # no reddening
-    f, w, s = three(eng, eng.logposterior, th)
-    assert np.array_equal(f, w) and np.array_equal(f, s)
+    f, w, s, l = three(eng, eng.logposterior, th)
+    assert np.array_equal(f, w) and np.array_equal(f, s) and np.array_equal(f, l)
     assert np.isfinite(f).sum() >= n - 1
-    f, w, s = three(eng, eng.loglikelihood, th[:1], optimize=True)
-    assert np.array_equal(f, w) and np.array_equal(f, s)
+    # the automatic choice (the linked form while walkers x segments <= #CUs), and again: the hand-over flags are back at zero
+    for _ in range(2):
+        assert np.array_equal(f, eng.logposterior(th))
+    f, w, s, l = three(eng, eng.loglikelihood, th[:1], optimize=True)
+    assert np.array_equal(f, w) and np.array_equal(f, s) and np.array_equal(f, l)
 
 
 def test_wide_path_three_segments_against_the_oracle():
@@ -197,18 +200,20 @@ def test_wide_path_three_segments_against_the_oracle():
     eng.stage_specs(c.specs)
     eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
                       bands=bands.make_bands(c.tables, *c.vega))
-    f, w, s = three(eng, eng.loglikelihood, c.theta[:12])
-    assert np.array_equal(f, w) and np.array_equal(f, s) and np.all(np.isfinite(f))
+    f, w, s, l = three(eng, eng.loglikelihood, c.theta[:12])
+    assert np.array_equal(f, w) and np.array_equal(f, s) and np.array_equal(f, l) and np.all(np.isfinite(f))
     one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
                                    c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
     assert rel_err(w[0], one) < TIGHT
     bad = c.theta[:6].copy()
     bad[2, 0] = 2800.0
-    eng.ctx.set_path(_lib.PATH_WIDE)
-    with pytest.raises(ValueError):
-        eng.loglikelihood(bad)
-    # a one-segment spectrum has no wide form
+    for path in (_lib.PATH_WIDE, _lib.PATH_LINKED):
+        eng.ctx.set_path(path)
+        with pytest.raises(ValueError):
+            eng.loglikelihood(bad)
+    # a one-segment spectrum has no wide / linked form
     e1 = make_engine(c)
-    e1.ctx.set_path(_lib.PATH_WIDE)
-    with pytest.raises(_lib.MsxError):
-        e1.loglikelihood(c.theta[:4])
+    for path in (_lib.PATH_WIDE, _lib.PATH_LINKED):
+        e1.ctx.set_path(path)
+        with pytest.raises(_lib.MsxError):
+            e1.loglikelihood(c.theta[:4])

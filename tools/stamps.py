@@ -38,7 +38,7 @@ def main():
     lp = torch.empty(n, dtype=torch.float64, device=dev)
     st = torch.empty(n, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
-    eng.ctx.set_path(_lib.PATH_SPLIT if args.path == 'split' else _lib.PATH_FUSED)
+    eng.ctx.set_path({'split': _lib.PATH_SPLIT, 'linked': _lib.PATH_LINKED}.get(args.path, _lib.PATH_FUSED))
     for _ in range(20):
         eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), s, {'logpost': _lib.MODE_LOGPOST, 'loglike': _lib.MODE_LOGLIKE}[args.mode], args.block)
     torch.cuda.synchronize()
@@ -63,6 +63,26 @@ def main():
         for i, nm in enumerate(['(entry)', 'bin scan', 'chi2+gather pass+barrier', 'rank']):
             print('    median/{:24s} median {:8d} cycles'.format(nm, int(np.median(dm[:, i]))))
         print('  first start -> last end: {} cycles'.format(int(o[:, 7].max() - o[:, 0].min())))
+        return
+    if args.path == 'linked' and os.environ.get('MSX_STAMPS_PRODUCERS'):  # library built with -DMSX_STAMPS=2
+        o = out.astype(np.int64)
+        order = [0, 1, 2, 3, 4, 7]
+        names = ['phase0 recipe', 'phaseA blend + copy to the scratch', 'fit sums + range + partials stored', 'barrier', 'release + increment']
+        print('linked path, producers (segment 0), walkers {}: median total {} cycles'.format(n, int(np.median(o[:, 7] - o[:, 0]))))
+        for i, nm in enumerate(names):
+            v = o[:, order[i + 1]] - o[:, order[i]]
+            print('  {:36s} median {:8d} cycles'.format(nm, int(np.median(v))))
+        return
+    if args.path == 'linked':  # the joiner's stamps (the producers write none)
+        o = out.astype(np.int64)
+        order = [0, 1, 2, 5, 6, 3, 4, 7, 15]
+        names = ['phase0 recipe', 'phaseA blend (last segment)', 'wait for the producers', 'their model values + partials', 'fit sums + range',
+                 'median + chi2 pass', 'tail', 'closing barrier + store']
+        print('linked path, joiners, walkers {}: median total {} cycles'.format(n, int(np.median(o[:, 15] - o[:, 0]))))
+        for i, nm in enumerate(names):
+            v = o[:, order[i + 1]] - o[:, order[i]]
+            print('  {:32s} median {:8d} cycles'.format(nm, int(np.median(v))))
+        print('  first start -> last end: {} cycles'.format(int(o[:, 15].max() - o[:, 0].min())))
         return
     d = np.diff(out[:, :8].astype(np.int64), axis=1)
     names = ['phase0 recipe', 'phaseA blend', 'fit sums + range (barriers)', 'median + chi2 pass', '-', 'tail', 'final reduce']

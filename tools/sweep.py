@@ -41,7 +41,7 @@ def main():
         lp = torch.empty(n, dtype=torch.float64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
         for path in args.paths.split(','):
-          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'split': _lib.PATH_SPLIT, 'wide': _lib.PATH_WIDE}[path])
+          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'split': _lib.PATH_SPLIT, 'wide': _lib.PATH_WIDE, 'linked': _lib.PATH_LINKED}[path])
           for B in [int(x) for x in args.blocks.split(',')]:
             def go(sp):
                 eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), sp, _lib.MODE_LOGPOST, B)
