@@ -518,7 +518,11 @@ def main():
             bt = 256
         else:
             bt = 512 if n <= 2 * cus else 256
-        if bt == 256 and n <= 2 * cus:
+        nseg = (args.npix + 8191) // 8192
+        if block == 0 and 2 <= nseg <= 8 and args.npix * 8 <= 134 * 1024 and 2 * n * nseg <= cus and os.environ.get('MSX_LINKED', '') != '0':
+            kernel_name = ('logprob_kernel<NS=2, 512 threads, linked> (one workgroup per walker and 8192-pixel segment, handed over inside '
+                           'the launch; four pixels per lane and trip)')
+        elif bt == 256 and n <= 2 * cus:
             kernel_name = 'logprob_kernel<NS=2, 256 threads, two per CU> (four pixels per lane and trip)'
         elif bt == 256:
             kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'

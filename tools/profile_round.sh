@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3
 cd $root
 python3 tools/pmc_summary.py --kt $out/kt --fetch $out/pmc_fetch --write $out/pmc_write --kernel logprob_kernel \
   --out $dst/${tag}_logprob \
-  --note "rocprofv3 on: python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-extras (kernel-trace/stats) and --steps 50 --warmup 5 (two separate --pmc passes: FETCH_SIZE, WRITE_SIZE); config 2: 256 walkers, 4096 px, block auto (512 threads, the <= 128-VGPR variant)" > /dev/null
+  --note "rocprofv3 on: python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-extras (kernel-trace/stats) and --steps 50 --warmup 5 (two separate --pmc passes: FETCH_SIZE, WRITE_SIZE); config 2: 256 walkers, 4096 px, block auto (512 threads, one workgroup per CU: the PF quad-trip variant named in the kernel column)" > /dev/null
 grep '^{' $out/bench_kt.json > $dst/${tag}_bench_under_rocprof.json
 # ---- SQ counters
 for cs in 4096:256 4096:3072 16384:128; do
@@ -48,7 +48,14 @@ print(json.dumps(out['points'], indent=1))
 PY
 # ---- the other forms of the path, per kernel
 PATHS="fused split" tools/prof_split.sh $tag "4096:3072,4096:16384" > $dst/${tag}_forms_4096px.txt 2>&1
-PATHS="fused wide split" tools/prof_split.sh $tag "16384:128" > $dst/${tag}_forms_16384px.txt 2>&1
+PATHS="fused wide linked split" tools/prof_split.sh $tag "16384:128" > $dst/${tag}_forms_16384px.txt 2>&1
 python3 tools/sweep.py --blocks 0 --paths fused --walkers 26,128,256,512,1024,2048,4096,16384 > $dst/${tag}_sweep_4096px.jsonl 2>/dev/null
 python3 tools/sweep.py --blocks 0 --paths fused --npix 16384 --phot --walkers 32,128,512 > $dst/${tag}_sweep_16384px.jsonl 2>/dev/null
+# ---- the linked form against the fused kernel (few walkers x long spectrum), and where its time goes (diagnostic builds)
+{
+  python3 tools/sweep.py --blocks 0 --paths fused,linked --npix 16384 --phot --iters 200 --walkers 8,16,32,48,64,96,128 2>/dev/null
+  if [ -f build/libmsx_stamps.so ]; then MSX_LIB=build/libmsx_stamps.so python3 tools/stamps.py --walkers 128 --npix 16384 --path linked 2>/dev/null; fi
+  if [ -f build/libmsx_stamps2.so ]; then MSX_STAMPS_PRODUCERS=1 MSX_LIB=build/libmsx_stamps2.so python3 tools/stamps.py --walkers 128 --npix 16384 --path linked 2>/dev/null; fi
+  if [ -f build/libmsx_stamps.so ]; then MSX_LINKED=0 MSX_LIB=build/libmsx_stamps.so python3 tools/stamps.py --walkers 128 --npix 16384 2>/dev/null; fi
+} > $dst/${tag}_linked_16384px.txt
 ls -la $dst
