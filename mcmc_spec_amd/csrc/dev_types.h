@@ -81,6 +81,7 @@ struct DevProblem {
     struct WalkerRec *rec;     // [n] split / wide path: what the recipe stage leaves for the later ones
     struct SegPart *segparts;  // [n][segments] wide path: STAGE 3's partials
     int32_t *seg_flag;         // [n] linked path: producers that have published their segment (the joiner resets it)
+    int32_t linked_fault;      // test hook (MSX_LINKED_FAULT=1 at msx_stage_problem): producers skip the increment, joiners must time out
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;

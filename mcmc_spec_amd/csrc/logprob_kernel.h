@@ -710,7 +710,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             MSX_STAMP(P, wk, 3);
             __syncthreads();
             MSX_STAMP(P, wk, 4);
-            if (tid == 0) __hip_atomic_fetch_add(P.seg_flag + wk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !P.linked_fault) __hip_atomic_fetch_add(P.seg_flag + wk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             MSX_STAMP(P, wk, 7);
         }
         return;

@@ -767,6 +767,8 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         HIP_TRY(c, hipMalloc((void **)&c->d_seg_flag, sizeof(int32_t) * sb));
         HIP_TRY(c, hipMemset(c->d_seg_flag, 0, sizeof(int32_t) * sb));
         P.seg_flag = c->d_seg_flag;
+        P.linked_fault = 0;
+        if (const char *e = getenv("MSX_LINKED_FAULT")) P.linked_fault = e[0] == '1';  // (tests: the bounded wait)
         if (const char *e = getenv("MSX_SPLIT_MIN")) c->split_min_walkers = std::max<int64_t>(1, atoll(e));
         if (const char *e = getenv("MSX_SPLIT_MIN_NPIX")) c->split_min_npix = std::max<int64_t>(1, atoll(e));
         if (const char *e = getenv("MSX_WIDE_MAX")) c->wide_max_blocks_per_cu = std::max<int64_t>(0, atoll(e));

@@ -217,3 +217,28 @@ def test_wide_path_three_segments_against_the_oracle():
         e1.ctx.set_path(path)
         with pytest.raises(_lib.MsxError):
             e1.loglikelihood(c.theta[:4])
+
+
+def test_linked_hand_over_that_never_comes_fails_loudly_and_soon(monkeypatch):
+    """MSX_LINKED_FAULT=1 (read when the problem is staged) makes the producers skip their increment: every joiner
+    gives up after 20 ms of wall clock, the walker reports MSX_W_HANDOVER and Python raises -- no hang, no value.
+    Staged again without the fault, the same context evaluates the same walkers like the fused kernel."""
+    import time
+    import bench
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+    monkeypatch.setenv('MSX_LINKED_FAULT', '1')
+    eng = Engine(0)
+    W = bench.build_workload(eng, 16384, True)
+    th = synth.draw_walkers(40, seed=77, tmin=W['tmin'], tmax=W['tmax'])
+    eng.ctx.set_path(_lib.PATH_LINKED)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='did not meet'):
+        eng.logposterior(th)
+    assert time.time() - t0 < 5.0
+    monkeypatch.delenv('MSX_LINKED_FAULT')
+    W = bench.build_workload(eng, 16384, True)
+    eng.ctx.set_path(_lib.PATH_LINKED)
+    a = eng.logposterior(th)
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    assert np.array_equal(a, eng.logposterior(th)) and np.all(np.isfinite(a))
