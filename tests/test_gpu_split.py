@@ -242,3 +242,25 @@ def test_linked_hand_over_that_never_comes_fails_loudly_and_soon(monkeypatch):
     a = eng.logposterior(th)
     eng.ctx.set_path(_lib.PATH_FUSED)
     assert np.array_equal(a, eng.logposterior(th)) and np.all(np.isfinite(a))
+
+
+@pytest.mark.parametrize('npix', [8193, 9001, 16383])
+def test_segment_forms_with_an_odd_pixel_count(npix):
+    """Odd pixel counts (the scratch rows are then only 8-byte aligned: the segment copies take their scalar paths), a
+    second segment of ONE pixel, and one pixel short of two full segments: wide and linked against fused, and the oracle."""
+    from mcmc_spec_amd import bands
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    rng = np.random.default_rng(npix)
+    wl = rng.uniform(0.56, 0.89, npix)
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    f, w, s, l = three(eng, eng.loglikelihood, c.theta[:9])
+    assert np.array_equal(f, w) and np.array_equal(f, s) and np.array_equal(f, l) and np.all(np.isfinite(f))
+    one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(l[0], one) < TIGHT
