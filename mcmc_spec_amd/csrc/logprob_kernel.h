@@ -167,7 +167,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //              segment into LDS, waits for the S-1 increments (bounded: kHandoverTicks, then the walker fails with
 //              MSX_W_HANDOVER), takes the producers' model values and partials as stage 4 does and goes on as the
 //              fused kernel.  Joiners have the highest block indices: every producer a joiner waits for was
-//              dispatched before it, so the wait needs no co-residency guarantee beyond in-order dispatch.
+//              dispatched before it, so the wait needs no co-residency guarantee beyond in-order dispatch -- and
+//              because a walker's blocks are a multiple of 8 apart they sit in the SAME XCD's dispatch queue
+//              (blocks go round-robin over the 8 XCDs), so the order holds even when the XCDs' dispatchers progress at
+//              different rates.  (Producers never wait: whatever else holds CUs, they finish.)
 //
 // TABLE LAYOUT.  A CU pulls data from L2 at ~32 B per clock when every lane loads 16 bytes, and no faster per
 // instruction when lanes load less -- so every per-pixel table the blend reads is stored in ELEMENTS of two pixels,
