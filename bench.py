@@ -393,9 +393,11 @@ def main():
     # guide's graph-replay floor), which a 20-step run (what the driver times) would otherwise pay several times.
     # Step i of a replay uses problem i mod nprob, theta batch i mod nbatch, output buffer i mod 2: any even chunk.
     if want_graph and not direct and args.steps >= 4:
-        # (kernel-only runs: the first two steps go out as plain launches, so that the GPU is already busy while the
-        # host prepares the graph launch -- ~15 us that a 20-step run would otherwise spend with the GPU idle)
-        head = 2 if (not use_gather and args.steps >= 8 and os.environ.get('MSX_BENCH_NO_HEAD') != '1') else 0
+        # (kernel-only runs: the first four steps go out as plain launches, so that the GPU is already busy while the
+        # host prepares the graph launch -- 25-40 us that a 20-step run would otherwise spend with the GPU idle; same-box
+        # means of three 20-step runs: 19.7 us per step with none, 19.1 with two, 18.5 with four, 18.4-18.6 with 8 / 12)
+        head = int(os.environ.get('MSX_BENCH_HEAD', '4')) if (not use_gather and args.steps >= 8 and os.environ.get('MSX_BENCH_NO_HEAD') != '1') else 0
+        head = max(0, min(head, args.steps - 4))
         chunk = min(args.steps - head, int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '200'))) // 2 * 2
         from mcmc_spec_amd.benchutil import capture_agreed
 
@@ -443,6 +445,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    gev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
     t0 = time.perf_counter()
     first_eager = 0
     gev = []
@@ -452,7 +455,7 @@ def main():
             launch(i)
         for _ in range((args.steps - head) // chunk):
             if not use_gather:  # kernels only in the graph: a replay's elapsed time / chunk is the kernel time
-                gev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                gev.append(gev_pool[len(gev)] if len(gev) < len(gev_pool) else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
                 gev[-1][0].record(stream)
             graph.replay()
             if not use_gather:
