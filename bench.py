@@ -437,9 +437,23 @@ def main():
     ev_run = 8
     nev = args.steps // ev_run
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(nev, 1))]
-    for i in range(ramp):  # the device warm-up (see above)
-        reuse_guard(i)
-        launch(i)
+    # the device warm-up (see above): at least `ramp` launches, then on in runs of 500 until two consecutive runs take
+    # the same time to 0.7 % (a box that sat idle needs more than one that has just run the tests), 20,000 at most
+    ramp_done = 0
+    if ramp > 0:
+        ra, rb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        prev, stable = None, 0
+        while ramp_done < ramp or (stable < 2 and ramp_done < 20000):
+            ra.record(stream)
+            for i in range(500):
+                reuse_guard(i)
+                launch(i)
+            rb.record(stream)
+            rb.synchronize()
+            ramp_done += 500
+            cur = ra.elapsed_time(rb)
+            stable = stable + 1 if (prev is not None and abs(cur - prev) <= 0.007 * prev) else 0
+            prev = cur
     drain()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -607,7 +621,7 @@ def main():
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': W.get('nwin'),
                        'grid': '26x4x135000 f64 synthetic',
                        'block_threads': block or 'auto', 'collective': collective,
-                       'device_warmup': '{} untimed launches before the {} warm-up steps (sustained-load clocks)'.format(ramp, args.warmup),
+                       'device_warmup': '{} untimed launches (>= {}, until two runs of 500 agree to 0.7 %) after the {} warm-up steps, right before the timed region (sustained-load clocks)'.format(ramp_done, ramp, args.warmup),
                        'step_loop': ('{} eager + hipGraph of {} steps x {} replays + {} eager'.format(
                            head, chunk, (args.steps - head) // chunk, args.steps - head - (args.steps - head) // chunk * chunk)
                            if graph is not None else 'eager')},
