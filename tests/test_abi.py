@@ -78,3 +78,25 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
             assert m and int(m.group(1)) <= (64 if capped else 0), block
             seen += 1
     assert seen >= 12   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; stages 0-2
+
+
+def test_python_constants_mirror_the_header():
+    """Every status / mode / path / limit constant `_lib.py` restates has the value `include/msx.h` defines."""
+    from mcmc_spec_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'msx.h')).read()
+    defs = {m.group(1): int(m.group(2).strip('()')) for m in re.finditer(r'#define (MSX_[A-Z0-9_]+) (\(?-?\d+\)?)', text)}
+    pairs = {'MSX_OK': _lib.MSX_OK, 'MSX_ERR_INVALID': _lib.MSX_ERR_INVALID, 'MSX_ERR_HIP': _lib.MSX_ERR_HIP,
+             'MSX_ERR_STATE': _lib.MSX_ERR_STATE, 'MSX_ERR_RANGE': _lib.MSX_ERR_RANGE,
+             'MSX_W_OK': _lib.W_OK, 'MSX_W_REJECT': _lib.W_REJECT, 'MSX_W_KEYERROR': _lib.W_KEYERROR,
+             'MSX_W_INDEXERROR': _lib.W_INDEXERROR, 'MSX_W_VALUEERROR': _lib.W_VALUEERROR, 'MSX_W_HANDOVER': _lib.W_HANDOVER,
+             'MSX_MODE_LOGLIKE': _lib.MODE_LOGLIKE, 'MSX_MODE_LOGPOST': _lib.MODE_LOGPOST, 'MSX_MODE_CHISQ': _lib.MODE_CHISQ,
+             'MSX_MODE_LOGPRIOR': _lib.MODE_LOGPRIOR, 'MSX_BLOCK_512_SHARED': _lib.BLOCK_512_SHARED,
+             'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_SPLIT': _lib.PATH_SPLIT,
+             'MSX_PATH_WIDE': _lib.PATH_WIDE, 'MSX_PATH_LINKED': _lib.PATH_LINKED,
+             'MSX_MAX_SPEC': _lib.MAX_SPEC, 'MSX_MAX_BANDS': _lib.MAX_BANDS, 'MSX_MAX_DIM': _lib.MAX_DIM}
+    for name, val in pairs.items():
+        assert defs[name] == val, name
+    # and nothing of those families is defined in the header without a mirror
+    for name in defs:
+        if name.startswith(('MSX_W_', 'MSX_PATH_', 'MSX_ERR_')):
+            assert name in pairs, name
