@@ -3,6 +3,9 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=8 -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
     MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 256 --block 1024
+    MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 128 --npix 16384 --path linked     # the joiners' stamps
+(-DMSX_STAMPS=2 -o build/libmsx_stamps2.so: the linked form's PRODUCERS write the stamps instead;
+    MSX_STAMPS_PRODUCERS=1 MSX_LIB=build/libmsx_stamps2.so python tools/stamps.py --walkers 128 --npix 16384 --path linked)
 """
 import argparse
 import ctypes as C
@@ -21,7 +24,7 @@ def main():
     ap.add_argument('--npix', type=int, default=4096)
     ap.add_argument('--mode', default='logpost')
     ap.add_argument('--av0', action='store_true', help='all walkers at A_V = 0: no reddening, the blend loads R only')
-    ap.add_argument('--path', default='fused', help='fused | split (split: the stamps are those of the LAST kernel, stage 2)')
+    ap.add_argument('--path', default='fused', help='fused | split | linked (split: the stamps are those of the LAST kernel, stage 2; linked: the joiners)')
     args = ap.parse_args()
     import torch
     from bench import build_workload
