@@ -524,7 +524,8 @@ def main():
 
     if rank == 0:
         kern_s = kern_ms * 1e-3
-        req = eng.ctx.bytes_per_eval()  # bytes one walker's workgroup requests from the memory system (L2-served)
+        # bytes one walker's workgroup requests from the memory system (L2-served), for the variant THIS launch took
+        req = eng.ctx.bytes_per_eval(n if block != _lib.BLOCK_512_SHARED else 10 ** 9)
         cus = 256
         # (mirrors pick_block / launch_logprob of csrc/msx.hip)
         if block in (256, 512):
@@ -645,8 +646,9 @@ def main():
                 th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
                 lp_, st_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
                 us = device_time_us(eng, th, lp_, st_, stream, m, max(5, min(50, 200000 // m)))
-                row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6,
-                       'requested_GBps': m * req / us / 1e3, 'frac_of_l2_peak': m * req / us / 1e3 / L2_PEAK_GBPS}
+                req_m = eng.ctx.bytes_per_eval(m)
+                row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6, 'requested_bytes_per_eval': req_m,
+                       'requested_GBps': m * req_m / us / 1e3, 'frac_of_l2_peak': m * req_m / us / 1e3 / L2_PEAK_GBPS}
                 vi = valu_by_regime.get((args.npix, 3072)) if m > 1024 else None   # the 256-thread variant's count
                 if vi:
                     row['valu_issue_frac'] = vi * m / (us * 1e-6) / issue_peak
@@ -661,7 +663,7 @@ def main():
                 us = device_time_us(e4, th, lp_, st_, stream, 128, 50)
                 extra['config4_per_gpu_share'] = {'walkers': 128, 'npix': 16384, 'photometry_bands': 6, 'device_us': us,
                                                   'evals_per_s': 128 / us * 1e6,
-                                                  'requested_bytes_per_eval': e4.ctx.bytes_per_eval()}
+                                                  'requested_bytes_per_eval': e4.ctx.bytes_per_eval(128)}
         if extra:
             out['extra'] = extra
         sys.stdout.flush()

@@ -143,29 +143,22 @@ int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
 
-/* Two forms of the same path, same bits.  FUSED: one launch, one workgroup per walker (latency-optimal for a few
- * hundred walkers of <= 8k pixels).  SPLIT: recipe kernel -> tile planner -> walker-tiled blend kernel (the walkers
- * of one grid cell share ONE load of their 4*nspec pair rows; pixels spread over all CUs) -> per-walker median /
- * chi^2 kernel, in sub-batches whose model vectors stay cache-resident.  MSX_PATH_AUTO takes the split form at or
- * above MSX_SPLIT_MIN walkers / MSX_SPLIT_MIN_NPIX pixels (environment variables read by msx_stage_problem; unset =
- * never: on MI355X the fused kernel measured faster at every size).  All scratch is sized by
- * msx_stage_problem: no launch allocates or synchronises.  MSX_PATH_SPLIT fails with MSX_ERR_STATE for modes / problems that have no split form
- * (logprior alone, the no-spectrum variant, the optimiser modes, tables beyond the register recipe).                 */
-/* WIDE: two launches for few walkers x long spectra (2..8 segments of 8192 pixels): one workgroup per (walker,
- * segment) runs recipe + blend + the segment's fit sums / histogram, one workgroup per walker then combines the
- * segments and runs the median / chi^2 phases -- so that e.g. 128 walkers x 16384 pixels use all 256 CUs.  Same
- * bits as FUSED (which sums long spectra segment by segment too).  MSX_PATH_AUTO takes it while walkers x segments
- * <= MSX_WIDE_MAX x #CUs (environment; default 0 = never: measured slower than FUSED on MI355X, whose L2 -> CU
- * fabric, not its CU count, bounds the blend of such launches -- DESIGN.md).                                     */
+/* Two forms of the same path, same bits.
+ * FUSED: one launch, one workgroup per walker.
+ * LINKED: for few walkers x long spectra (2..8 segments of 8192 pixels), one workgroup per (walker, segment) in ONE
+ * launch, so that e.g. 32 walkers x 16,384 pixels use 64 CUs instead of 32.  The workgroups of a walker's first S-1
+ * segments publish their model values and partials and leave; the workgroup of the last segment waits for them inside
+ * the kernel (bounded: 20 ms), and runs the median / chi^2 phases.  MSX_PATH_AUTO takes it while walkers x segments
+ * <= #CUs / 2 (MSX_LINKED=0 in the environment: never; =1: whenever the spectrum has 2..8 segments): 16 walkers x
+ * 16,384 px 29.1 us against 34.0 fused; with every CU busy it loses.
+ * A hand-over that times out fails its walker with MSX_W_HANDOVER and POISONS the context's linked form: a device-side
+ * word makes every later linked launch fail ALL its walkers with MSX_W_HANDOVER (never a value computed from stale
+ * flags), MSX_PATH_AUTO takes the fused form once a synchronous entry point has seen the status, an explicit
+ * MSX_PATH_LINKED is refused with MSX_ERR_STATE -- until msx_stage_problem clears flags and word together.
+ * (Values 2 and 3 were the split and wide forms of rounds 1-2: measured slower than FUSED at every size and removed;
+ * the measurements are kept in DESIGN.md.)                                                                        */
 #define MSX_PATH_AUTO 0
 #define MSX_PATH_FUSED 1
-#define MSX_PATH_SPLIT 2
-#define MSX_PATH_WIDE 3
-/* LINKED: the wide form in ONE launch.  The workgroups of a walker's first S-1 segments publish their model values
- * and partials and leave; the workgroup of the last segment waits for them inside the kernel (bounded: 20 ms, then the
- * walker reports MSX_W_HANDOVER), and runs the median / chi^2 phases.  Same bits.  MSX_PATH_AUTO takes it while
- * walkers x segments <= #CUs / 2 (MSX_LINKED=0 in the environment: never; =1: whenever the spectrum has 2..8
- * segments): 16 walkers x 16,384 px 29.1 us against 34.0 fused; with every CU busy it loses.      */
 #define MSX_PATH_LINKED 4
 int msx_set_path(msx_ctx *ctx, int32_t path);
 
@@ -240,11 +233,32 @@ int msx_comm_allgather_dev(msx_ctx *ctx, const double *d_send, double *d_recv, i
                            int32_t slot);
 int msx_comm_wait_slot(msx_ctx *ctx, int32_t slot, void *compute_stream);
 
+/* ---- the "fake collective" -- a LOOPBACK group.  `world` contexts of ONE process on ONE device stand
+ * for ranks 0..world-1 (ctxs[r] becomes rank r); the sharded sampler's all-gather becomes device copies between the
+ * ranks' gathered vectors (rank r takes block p out of rank p's vector, in place at p * ceil(ns / world), exactly
+ * where RCCL's in-place all-gather puts it).  Every rank-dependent line of the sharded path -- block offsets, ragged
+ * and empty shards, the NaN-payload status, the apply kernel over the gathered vector -- then runs on a one-GPU box,
+ * no RCCL involved.  After msx_sampler_begin + msx_sampler_shard(r, world) on every rank, msx_sampler_enqueue_group
+ * queues one chunk on all ranks in lock-step (same randomness for all, as the sharded form requires) in place of the
+ * per-rank msx_sampler_enqueue; collect / end stay per rank.  The group ends when its first member is destroyed.    */
+int msx_comm_init_loopback(msx_ctx **ctxs, int32_t world);
+int msx_sampler_enqueue_group(msx_ctx **ctxs, int32_t world, int32_t slot /* 0|1 */, int64_t nsteps, const int32_t *sidx,
+                              const int32_t *cidx, const int32_t *partner, const double *zz, const double *zfac,
+                              const double *logu);
+
 /* ---- measurement helpers ----------------------------------------------------------------------- */
 /* float4 device-to-device copy of `bytes` bytes, `iters` times; returns GB/s (read+write counted)  */
 int msx_stream_copy_gbps(msx_ctx *ctx, int64_t bytes, int32_t iters, double *gbps_out);
-/* bytes the hot kernel requests from memory per walker for the staged problem (pair table form)   */
-int msx_bytes_per_eval(msx_ctx *ctx, int64_t *requested_bytes);
+/* bytes the hot kernel requests from the memory system per walker, for the variant an automatic launch of n walkers
+ * of the staged problem takes (the one-workgroup-per-CU variants keep u and the data flux in LDS for the chi^2 pass:
+ * 132 instead of 148 bytes per pixel of a binary)                                                                  */
+int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
+
+/* ---- test hooks (used by tests/ only) ------------------------------------------------------------ */
+/* MSX_HOOK_LINKED_FAULT: value != 0 makes the producers of the linked form skip their signal, so that every joiner
+ * runs into its bounded wait; takes effect at the next launch, without restaging                                  */
+#define MSX_HOOK_LINKED_FAULT 1
+int msx_test_hook(msx_ctx *ctx, int32_t what, int32_t value);
 
 #ifdef __cplusplus
 }

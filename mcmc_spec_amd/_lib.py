@@ -19,7 +19,8 @@ MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
 W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR, W_HANDOVER = 0, 1, 2, 3, 4, 5
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
-PATH_AUTO, PATH_FUSED, PATH_SPLIT, PATH_WIDE, PATH_LINKED = 0, 1, 2, 3, 4  # include/msx.h MSX_PATH_*
+PATH_AUTO, PATH_FUSED, PATH_LINKED = 0, 1, 4  # include/msx.h MSX_PATH_*
+HOOK_LINKED_FAULT = 1  # include/msx.h MSX_HOOK_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)
@@ -109,8 +110,12 @@ def load():
         'msx_comm_init': (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
         'msx_comm_allgather_dev': (C.c_int, [vp, vp, vp, C.c_int64, vp, C.c_int32]),
         'msx_comm_wait_slot': (C.c_int, [vp, C.c_int32, vp]),
+        'msx_comm_init_loopback': (C.c_int, [C.POINTER(vp), C.c_int32]),
+        'msx_sampler_enqueue_group': (C.c_int, [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),
         'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
-        'msx_bytes_per_eval': (C.c_int, [vp, _ip]),
+        'msx_bytes_per_eval': (C.c_int, [vp, C.c_int64, _ip]),
+        'msx_test_hook': (C.c_int, [vp, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library skew, fail loudly
@@ -125,7 +130,8 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
             'msx_logprob_batch_dev', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
-            'msx_stream_copy_gbps', 'msx_bytes_per_eval']
+            'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
+            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook']
 
 
 def as_f64(a):
@@ -248,7 +254,7 @@ class Context:
                                                   C.c_void_p(stream_ptr), int(block_threads)))
 
     def set_path(self, path):
-        """PATH_AUTO / PATH_FUSED / PATH_SPLIT / PATH_WIDE / PATH_LINKED: which form of the hot path launches take (same bits either way)."""
+        """PATH_AUTO / PATH_FUSED / PATH_LINKED: which form of the hot path launches take (same bits either way)."""
         self.check(self.lib.msx_set_path(self.h, int(path)))
 
     def opt_init(self, theta0):
@@ -351,7 +357,31 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
         self.check(self.lib.msx_comm_init(self.h, buf, int(rank), int(world)))
 
-    def bytes_per_eval(self):
+    # ---- loopback group: the ranks of a sharded run as contexts of one process (include/msx.h) ---------
+    @staticmethod
+    def comm_init_loopback(contexts):
+        """``contexts[r]`` becomes rank r of a loopback group of ``len(contexts)`` ranks (all on one device)."""
+        arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        contexts[0].check(contexts[0].lib.msx_comm_init_loopback(arr, len(contexts)))
+
+    @staticmethod
+    def sampler_enqueue_group(contexts, slot, sidx, cidx, partner, zz, zfac, logu):
+        """One chunk on every rank of a loopback group, in lock-step (arrays as for sampler_enqueue)."""
+        i32p = C.POINTER(C.c_int32)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (sidx, cidx, partner)]
+        dbl = [as_f64(a) for a in (zz, zfac, logu)]
+        nsteps = dbl[0].shape[0]
+        harr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        contexts[0].check(contexts[0].lib.msx_sampler_enqueue_group(
+            harr, len(contexts), int(slot), nsteps, arrs[0].ctypes.data_as(i32p), arrs[1].ctypes.data_as(i32p),
+            arrs[2].ctypes.data_as(i32p), dptr(dbl[0]), dptr(dbl[1]), dptr(dbl[2])))
+        return nsteps
+
+    def bytes_per_eval(self, n=256):
+        """Bytes the variant an automatic launch of ``n`` walkers takes requests from the memory system, per walker."""
         out = C.c_int64()
-        self.check(self.lib.msx_bytes_per_eval(self.h, C.byref(out)))
+        self.check(self.lib.msx_bytes_per_eval(self.h, int(n), C.byref(out)))
         return out.value
+
+    def test_hook(self, what, value):
+        self.check(self.lib.msx_test_hook(self.h, int(what), int(value)))

@@ -77,11 +77,13 @@ struct DevProblem {
     double *opt_flux;          // [nchains][npix]
     double *opt_med;           // [nchains]
     const int32_t *opt_chain;  // [n] (OPT_STEP launches)
-    double *model_scratch;     // [n][npix]: the model vectors of the split path (stages 3 -> 4) and of the GM variants
-    struct WalkerRec *rec;     // [n] split / wide path: what the recipe stage leaves for the later ones
-    struct SegPart *segparts;  // [n][segments] wide path: STAGE 3's partials
-    int32_t *seg_flag;         // [n] linked path: producers that have published their segment (the joiner resets it)
-    int32_t linked_fault;      // test hook (MSX_LINKED_FAULT=1 at msx_stage_problem): producers skip the increment, joiners must time out
+    double *model_scratch;     // [rows][npix]: the model vectors of the GM variants (spectra beyond the LDS) and the
+                               // producers' segments of the linked form
+    struct SegPart *segparts;  // [rows][segments] linked form: the producers' partials
+    int32_t *seg_flag;         // [rows] linked form: producers that have published their segment (the joiner resets it)
+    int32_t *linked_poison;    // linked form: != 0 once a hand-over has timed out on this context -- every later linked
+                               // launch fails all its walkers with MSX_W_HANDOVER until msx_stage_problem clears it
+    int32_t linked_fault;      // test hook (msx_test_hook / MSX_LINKED_FAULT=1): producers skip the increment, joiners must time out
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;
@@ -135,12 +137,11 @@ struct WalkerDesc {
 // offsets: the register-resident recipe takes at most 256 isochrone points, 64 Teff x 32 logg nodes; the presence
 // mask is one uint32 per Teff node, bit g = node (t, g) is in the grid).
 constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPresent = 5120, kRecipeBlockBytes = 5376;
-constexpr int kTileWalkers = 8;     // split path: walkers that share one load of the pair rows
-constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the wide path
+constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the linked form
 constexpr int kSegBins = 2048;      // (= kLogBins, median.h)
 constexpr unsigned long long kHandoverTicks = 2000000ull;  // linked path: a joiner gives up after 20 ms of the 100 MHz wall clock
 
-// wide path: what STAGE 3 leaves per (walker, segment) for STAGE 4
+// linked form: what a producer leaves per (walker, segment) for the walker's joiner
 struct alignas(16) SegPart {
     double q[3];                    // the segment's three fit sums
     unsigned long long kmin, kmax;  // its value range (order-preserving keys; ~0 / 0 = empty, kmax = ~0: a NaN)
@@ -148,34 +149,6 @@ struct alignas(16) SegPart {
     unsigned int hist[kSegBins];    // its share of the median's logarithmic histogram
 };
 static_assert(sizeof(SegPart) == 64 + 4 * kSegBins, "SegPart layout");
-
-// What the recipe leaves behind for stages 3 and 4.
-struct alignas(16) WalkerRec {
-    double w[kMaxCorners];      // bilinear weight x (R/d)^2 per corner, corners in canonical (sorted-node) order
-    double redc, lp, chi_extra;
-    unsigned long long key;     // hash of node[0 .. 4*NS)  (top bit always set: 0 marks an empty planner slot)
-    int32_t node[kMaxCorners];
-    int32_t status;             // MSX_W_OK: stages 3 and 4 run; anything else: stage 1 has written the final value
-    int32_t pad[3];
-};
-static_assert(sizeof(WalkerRec) == 192, "WalkerRec layout");
-
-struct alignas(16) TileHdr {
-    int32_t start, count;       // walkers perm[start .. start + count) share node[]
-    int32_t node[kMaxCorners];
-    int32_t pad[2];
-};
-static_assert(sizeof(TileHdr) == 64, "TileHdr layout");
-
-__device__ __forceinline__ unsigned long long hash_nodes(const int *node, int nc) {
-    unsigned long long h = 0x9E3779B97F4A7C15ull;
-    for (int c = 0; c < nc; ++c) {
-        h ^= (unsigned long long)(unsigned int)node[c] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h *= 0xBF58476D1CE4E5B9ull;
-        h ^= h >> 31;
-    }
-    return h | 0x8000000000000000ull;
-}
 
 }  // namespace
 

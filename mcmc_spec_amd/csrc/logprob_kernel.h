@@ -148,25 +148,15 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // PF = phase A leaves the walker-independent pixel vectors it loads anyway (u, data flux) in LDS, in the tables'
 //      own layout, and the chi^2 pass reads them there instead of pulling them through the CU's L2 port a second
 //      time (one workgroup per CU only: 3 npix doubles of LDS).
-// STAGE = 0: the fused kernel.  The split path (split_kernels.h) runs the same code in two pieces:
-//   STAGE = 1  phase 0 only: the walker's recipe goes to P.rec[wk] (rejected / failed walkers get their final
-//              value here, like the fused kernel); launched with 256 threads, no dynamic LDS
-//   STAGE = 2  everything after the blend: the model vector comes from P.model_scratch (written by
-//              blend_tiles_kernel), the recipe's scalars from P.rec[wk]
-// and the WIDE path (few walkers, long spectra: one workgroup per walker leaves CUs idle) in two others:
-//   STAGE = 3  one workgroup per (walker, SEGMENT of 8192 pixels): recipe, blend of that segment -> model scratch,
-//              the segment's fit sums / value range / histogram -> P.segparts; segment 0 leaves the recipe's
-//              scalars in P.rec[wk] (and the final value of rejected / failed walkers)
-//   STAGE = 4  one workgroup per walker: model vector scratch -> LDS, the segments' partials combined (the fit
-//              sums serially over the segments, exactly as the fused kernel adds them), then the median / chi^2
-//              phases as ever
-// and the LINKED path, the wide path in ONE launch:
-//   STAGE = 5  one workgroup per (walker, segment), block = segment * pad8(n) + walker.  The workgroups of segments
-//              0 .. S-2 are PRODUCERS: stage 3's work, then one release-increment of P.seg_flag[wk] (agent scope) and
-//              exit -- they never wait.  The workgroup of the LAST segment is the walker's JOINER: it blends its own
+// LK = the LINKED form of the same kernel, for few walkers x long spectra (one workgroup per walker leaves CUs idle):
+//              one workgroup per (walker, SEGMENT of 8192 pixels), block = segment * pad8(n) + walker.  The workgroups of segments
+//              0 .. S-2 are PRODUCERS: recipe, blend of their segment -> model scratch, the segment's fit sums / value
+//              range / histogram -> P.segparts, then a release-increment of P.seg_flag[wk] (agent scope) and exit -- they
+//              never wait.  The workgroup of the LAST segment is the walker's JOINER: it blends its own
 //              segment into LDS, waits for the S-1 increments (bounded: kHandoverTicks, then the walker fails with
-//              MSX_W_HANDOVER), takes the producers' model values and partials as stage 4 does and goes on as the
-//              fused kernel.  Joiners have the highest block indices: every producer a joiner waits for was
+//              MSX_W_HANDOVER and the context's linked form is POISONED: see below), copies the producers' model values
+//              into LDS, combines the segments' partials (the fit sums serially over the segments, exactly as the fused
+//              kernel adds them) and goes on as the fused kernel.  Joiners have the highest block indices: every producer a joiner waits for was
 //              dispatched before it, so the wait needs no co-residency guarantee beyond in-order dispatch -- and
 //              because a walker's blocks are a multiple of 8 apart they sit in the SAME XCD's dispatch queue
 //              (blocks go round-robin over the 8 XCDs), so the order holds even when the XCDs' dispatchers progress at
@@ -177,7 +167,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // element e = pixels {pa, pa + 256}, pa = (e >> 8) * 512 + (e & 255): a lane's 16-byte load (8-byte for the float32
 // table) brings both of its pixels, for workgroups of 256 and of 512 threads alike.  Per grid node and pixel the
 // tables hold R = lo + (hi - lo) t (float64) and H = hi t (float32): see blend_pixel_rh (blend.h).
-template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, int STAGE = 0>
+template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false>
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
@@ -204,35 +194,42 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
     __shared__ double e2tab[kExp2Tab];              // 2^(j/32) for the reddening factor (blend.h)
-    constexpr bool kRecipe = STAGE == 0 || STAGE == 1 || STAGE == 3 || STAGE == 5;  // this stage runs phase 0
-    constexpr bool kBlend = STAGE == 0 || STAGE == 3 || STAGE == 5;                 // ... computes model values from the tables
-    constexpr bool kSegs = STAGE == 3 || STAGE == 5;                                // one workgroup per (walker, segment)
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
     const bool smp_on = (ng_mode_fast >> 17) & 1;  // device-resident sampler: theta is a proposal built here (= P.smp_on)
-    const int nsegs = kSegs ? (ng_mode_fast >> 24) & 0xff : 1;  // STAGE 3 / 5: workgroups per walker
-    const int64_t npad = (n + 7) & ~7ll;                        // STAGE 5: a walker's workgroups are a multiple of 8 blocks apart
-    const int64_t wk = STAGE == 3 ? blockIdx.x / nsegs : STAGE == 5 ? blockIdx.x % npad : blockIdx.x;
-    const int myseg = STAGE == 3 ? (int)(blockIdx.x - wk * nsegs) : STAGE == 5 ? (int)(blockIdx.x / npad) : 0;
-    const bool producer = STAGE == 5 && myseg != nsegs - 1;  // (uniform)
+    const int nsegs = LK ? (ng_mode_fast >> 24) & 0xff : 1;  // linked: workgroups per walker
+    const int64_t npad = (n + 7) & ~7ll;                     // linked: a walker's workgroups are a multiple of 8 blocks apart
+    const int64_t wk = LK ? blockIdx.x % npad : blockIdx.x;
+    const int myseg = LK ? (int)(blockIdx.x / npad) : 0;
+    const bool producer = LK && myseg != nsegs - 1;  // (uniform)
 #ifdef MSX_STAMPS
-    if (threadIdx.x == 0) msx_stamp_off = (MSX_STAMPS == 2) ? (STAGE == 5 && !producer) : producer;  // (-DMSX_STAMPS=2: the producers' stamps)
+    if (threadIdx.x == 0) msx_stamp_off = (MSX_STAMPS == 2) ? (LK && !producer) : producer;  // (-DMSX_STAMPS=2: the producers' stamps)
 #endif
     RecipeRegs RR;
-    if (kRecipe && fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
+    if (fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
+    if (LK) {
+        // a poisoned context (an earlier launch's hand-over timed out, see the joiner below): no flag is trusted,
+        // every walker of every linked launch fails loudly until the problem is staged again
+        if (__hip_atomic_load(P.linked_poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            if (!producer && threadIdx.x == 0) {
+                logp[wk] = nan_with_status(MSX_W_HANDOVER);
+                status[wk] = MSX_W_HANDOVER;
+                if (P.smp_on) atomicMax(P.smp_worst, MSX_W_HANDOVER);
+            }
+            return;
+        }
+    }
     // theta, requested before anything that waits for the kernel-argument segment (the recipe waves; the sampler
     // builds its proposal below instead)
     // (one VECTOR load, lane k takes coordinate k: a scalar load would share its counter with the kernel-argument
     // fetches below and be waited for together with them)
     double theta_lane = 0.0;
-    if (kRecipe && fast && !smp_on && (threadIdx.x >> 6) < NS && (threadIdx.x & 63) < ndim)
+    if (fast && !smp_on && (threadIdx.x >> 6) < NS && (threadIdx.x & 63) < ndim)
         theta_lane = theta[wk * ndim + (threadIdx.x & 63)];
-    if (!kRecipe && P.rec[wk].status != MSX_W_OK) return;  // an earlier stage wrote this walker's final value (uniform branch)
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
-    const double *__restrict__ model_in = (STAGE == 2 || STAGE == 4) ? P.model_scratch + wk * P.npix : nullptr;
-    double *const model_out = (STAGE == 3 || producer) ? P.model_scratch + wk * P.npix : nullptr;
+    double *const model_out = producer ? P.model_scratch + wk * P.npix : nullptr;
     const int tid = threadIdx.x;
     constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
     const int lane = tid & 63, wave = tid >> 6;
@@ -255,7 +252,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // The prior terms (f1) depend on theta alone and only the walker's last lines read them: an idle wave computes
     // them beside the recipe waves -- or, where phase A follows (`early` modes of the blending stages), a wave that
     // idles while wave 0 ranks the median's candidates (rejected walkers never read them).
-    const bool prior_late = kBlend && early;
+    const bool prior_late = early;
     if (smp_on) {  // stretch-move proposal q = c - (c - s) z for this walker (mft6.py:1494 drives emcee's move)
         // two dependent levels from wave start: the walker's record {own index, partner's index, z} (a preloaded
         // pointer) -> the two coordinate rows of the resident ensemble (the `theta` argument).  Every recipe wave
@@ -293,30 +290,25 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     }
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
-    if (kBlend) fill_exp2_table(e2tab, tid - (B - kWave));  // the last wave (no recipe work); published by phase 0's barrier
-    if (!kRecipe) {  // the recipe's scalars come from an earlier stage's record; no phase 0
-        if (tid == 0) { D.lp = P.rec[wk].lp; D.chi_extra = P.rec[wk].chi_extra; D.status = MSX_W_OK; }
-    }
+    fill_exp2_table(e2tab, tid - (B - kWave));  // the last wave (no recipe work); published by phase 0's barrier
     constexpr int NC = NS * 4;
     const int nseg_all = (ne + kSegElems - 1) / kSegElems;
-    const int seg_lo = kSegs ? myseg : 0, seg_hi = kSegs ? myseg + 1 : (STAGE == 4 ? 0 : nseg_all);
-    if (kRecipe && fast && wave == NS && !prior_late) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
-    if (kRecipe) {
-        if (fast) {
-            if (wave < NS) {
-                double tv[ndim];
+    const int seg_lo = LK ? myseg : 0, seg_hi = LK ? myseg + 1 : nseg_all;
+    if (fast && wave == NS && !prior_late) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+    if (fast) {
+        if (wave < NS) {
+            double tv[ndim];
 #pragma unroll
-                for (int k = 0; k < ndim; ++k) tv[k] = readlane_f64(theta_lane, k);
-                recipe_part1_regs<NS>(P, gates, RR, niso, nt, ng, mode, theta_lane, tv, D, lane, wk, wave);
-            }
-        } else if (wave == 0) {
-            const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
-            build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
+            for (int k = 0; k < ndim; ++k) tv[k] = readlane_f64(theta_lane, k);
+            recipe_part1_regs<NS>(P, gates, RR, niso, nt, ng, mode, theta_lane, tv, D, lane, wk, wave);
         }
+    } else if (wave == 0) {
+        const RecipeTabs T = {P.iso_t, P.iso_g, P.iso_l, P.av_edges, P.av_mu, P.av_sig, P.teff_nodes, P.logg_nodes};
+        build_recipe_wave<NS>(P, T, mode, th_row, ndim, D, lane, wk);
     }
     __syncthreads();
     int wst = D.status;
-    if (kRecipe && fast) {  // first star that failed decides, like the reference's star-by-star loop ...
+    if (fast) {  // first star that failed decides, like the reference's star-by-star loop ...
         wst = D.stat[0];
 #pragma unroll
         for (int k = 1; k < NS; ++k) wst = (wst == MSX_W_OK) ? D.stat[k] : wst;
@@ -326,28 +318,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         for (int k = 1; k < NS; ++k) wst = (wst != MSX_W_REJECT && D.stat[k] == MSX_W_VALUEERROR) ? MSX_W_VALUEERROR : wst;
     }
     if (wst != MSX_W_OK) {
-        if (tid == 0 && myseg == 0) {
-            walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
-            if (STAGE == 1 || STAGE == 3) P.rec[wk].status = wst;
-        }
-        return;
-    }
-    if (STAGE == 1) {
-        // (the host only takes the split path for the likelihood / posterior / chi^2 modes of a problem with a
-        // spectrum term and the register-resident recipe)  The walker is alive: finish its scalars -- wave NS left
-        // D.lp before the barrier above, wave 0 adds the contrast / photometry chi^2 -- and leave the record.
-        if (wave == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
-        __syncthreads();
-        WalkerRec *R = P.rec + wk;
-        if (tid < NS * 4) { R->node[tid] = D.node[tid]; R->w[tid] = D.w[tid]; }
-        if (tid == kWave) {
-            R->redc = D.redc; R->lp = D.lp; R->chi_extra = D.chi_extra;
-            int nd[NS * 4];
-#pragma unroll
-            for (int c = 0; c < NS * 4; ++c) nd[c] = D.node[c];
-            R->key = hash_nodes(nd, NS * 4);
-            R->status = MSX_W_OK;
-        }
+        if (tid == 0 && myseg == 0) walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
         return;
     }
     if (mode == MSX_MODE_LOGPRIOR) {  // logprior alone (mft6.py:1207-1272): no spectrum pass
@@ -379,7 +350,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // take the float32 values from the quad tables: one 16-byte load where two elements need two 8-byte ones
     // (512 threads: not the <= 128-VGPR variant, which has no room for a quad's rows; 256 threads: only the variant
     // that runs two per CU instead of three -- SH there -- and so has 256 VGPRs)
-    constexpr bool kQuad = kBlend && ((MAXT == 512 && !SH) || (MAXT == 256 && SH));
+    constexpr bool kQuad = (MAXT == 512 && !SH) || (MAXT == 256 && SH);
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
     const float2 *rows_h[NC];   // H = hi t
     const float4 *rows_h4[NC];  // ... by quad
@@ -387,14 +358,14 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     float wf[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int64_t off = !kBlend ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
+        const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
         rows_r[c] = P.r2 + off;
         rows_h[c] = P.h2 + off;
         rows_h4[c] = (MAXT == 512 ? P.h4 : P.h4b) + (!kQuad ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * P.nquad);
-        w[c] = !kBlend ? 0.0 : uniform_f64(D.w[c]);
+        w[c] = uniform_f64(D.w[c]);
         wf[c] = uniform_f32((float)w[c]);
     }
-    const double redc = !kBlend ? 0.0 : uniform_f64(D.redc);
+    const double redc = uniform_f64(D.redc);
     const bool redden = redc != 0.0;
     // Sums are taken in an order that does not depend on the workgroup size.  Pixel p belongs to SLOT p mod 1024;
     // a slot accumulates its pixels in ascending order in ONE lane's register, the 64 slots of VIRTUAL wave v
@@ -407,7 +378,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // so a walker's log-probability has the same bits whatever launch (batch size, shard, rank) evaluates it.
     // Spectra longer than 8192 pixels are summed SEGMENT by segment (kSegElems elements): each segment's slots are
     // reduced as above and the segments' sums added serially -- one more level of the same fixed association, and
-    // what lets the wide path give each segment to a workgroup of its own (STAGE 3 / 4).
+    // what lets the linked form give each segment to a workgroup of its own.
     constexpr int vk = kMaxWaves / (MAXT / kWave);  // slots per lane: 4 or 2
     double q[3];
     unsigned long long kmin = ~0ull, kmax = 0ull;
@@ -433,10 +404,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         for (int u = 0; u < U; ++u) {
             if (ok[u]) {
                 const double m = mm[u];
-                // (GM stage 2: the scratch row IS the model vector.  The segment kernels of the wide / linked paths
-                // write LDS too and copy the segment out after the loop: a global store among the loop's loads makes
-                // every wait for a row a wait for everything in flight -- 28-30k cycles per segment instead of 21k)
-                if (!(GM && STAGE == 2)) model[pp[u]] = m;
+                // (the linked form's producers write LDS too and copy the segment out after the loop: a global store
+                // among the loop's loads makes every wait for a row a wait for everything in flight -- 28-30k cycles
+                // per segment instead of 21k)
+                model[pp[u]] = m;
                 const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
                 const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
                 constexpr int slot = sub * U;  // (+ u: both unrolled)
@@ -518,12 +489,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         double2 f2v = make_double2(0.0, 0.0), u2v = make_double2(0.0, 0.0);
         if (kEarlyFU) { f2v = ld_off(P.f2, o16); u2v = ld_off(P.u2, o16); }
         double2 m2;
-        if (!kBlend) {
-            const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
-            // blend_tiles_kernel's output for this walker
-            m2 = make_double2(model_in[pa < npix ? pa : npix - 1], model_in[pb < npix ? pb : npix - 1]);
-        } else {
-            // the model values of the two pixels (blend.h; the split path's blend kernel runs the same chain).
+        {
+            // the model values of the two pixels (blend.h).
             // All corners' loads are issued together (192 bytes in flight per lane) -- except in the variant that
             // shares its CU (128 VGPRs), which takes the rows one star at a time.
             constexpr int G = SH ? 4 : NC;  // corners per group of loads
@@ -537,6 +504,9 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 float2 hh[G];
 #pragma unroll
                 for (int c = 0; c < G; ++c) {
+#ifdef MSX_EXP_HALFROWS  // measurement build only (wrong values): the second star re-uses the first star's loads
+                    if (c0 + c >= 4) { rr[c] = rr[(c0 + c - 4) % G]; hh[c] = hh[(c0 + c - 4) % G]; continue; }
+#endif
                     rr[c] = ld_off(rows_r[c0 + c], o16);
                     hh[c] = RED ? ld_off(rows_h[c0 + c], o8) : make_float2(0.f, 0.f);
                 }
@@ -572,8 +542,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
       if (wave < 3) qrun += reduce_published<MAXT>(&red[wave][0][0], lane);
       if (seg + 1 < seg_hi) __syncthreads();  // the next segment rewrites red
     }
-    if (STAGE == 3 || producer) {
-        // this segment's model values: LDS -> the scratch row (read back by STAGE 4 / the walker's joiner)
+    if (producer) {
+        // this segment's model values: LDS -> the scratch row (read back by the walker's joiner)
         const int p_lo = myseg * kSegElems * 2, p_hi = (p_lo + kSegElems * 2 < npix) ? p_lo + kSegElems * 2 : npix;
         if (((npix | p_hi) & 1) == 0) {
             const double2 *src = reinterpret_cast<const double2 *>(model);
@@ -588,10 +558,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // bound by the CU's memory pipeline and wave 0's loads are served first, so wave 0 leaves the pixel loop
     // thousands of cycles before the last wave.  (Other modes: inside block_median.)
     // (fused kernel: both run in waves 1 and 2 while wave 0 ranks the median's candidates, see phase B)
-    const bool late_side = (STAGE == 0 || STAGE == 5) && kRecipe && early;
-    if (STAGE == 3 && early && wave == 0 && myseg == 0) recipe_band_terms<NS>(P, mode, th_row, D, lane);
-    if (STAGE == 3 && fast && prior_late && wave == 1 && myseg == 0) recipe_prior_terms<NS>(P, mode, th_row, D, lane);
-    if (STAGE == 5 && !producer) {
+    const bool late_side = early;
+    if (LK && !producer) {
         // ---- the joiner meets its producers ----
         if (tid == 0) {
             const unsigned long long t0 = wall_clock64();
@@ -602,10 +570,18 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (seen >= nsegs - 1) __hip_atomic_store(P.seg_flag + wk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            if (seen >= nsegs - 1) {
+                __hip_atomic_store(P.seg_flag + wk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            } else {
+                // The producers did not come in time.  They may still increment the flag later in this launch, and
+                // nobody can tell when the last one has: the flags of this context are not to be trusted again.  POISON
+                // the linked form (sticky, device side): every linked launch checks the word first and reports
+                // MSX_W_HANDOVER for all of its walkers until msx_stage_problem clears flags and word together.
+                __hip_atomic_store(P.linked_poison, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             S.has_second = seen >= nsegs - 1 ? 0u : ~0u;  // (the median's own flag, 0 on its entry: ~0 = the producers never came)
         }
-        if (STAGE == 5) MSX_STAMP(P, wk, 5);
+        MSX_STAMP(P, wk, 5);
         __syncthreads();
         if (S.has_second != 0u) {
             if (tid == 0) walker_done(P, D, wk, ndim, NAN, MSX_W_HANDOVER, logp, status);
@@ -616,7 +592,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const double *msrc = P.model_scratch + wk * P.npix;
         const int nprod = (nsegs - 1) * kSegElems * 2;
         const SegPart *sp = P.segparts + wk * nseg_all;
-        static_assert(kLogBins == 4 * MAXT || STAGE != 5, "four counters per thread");
+        static_assert(kLogBins == 4 * MAXT || !LK, "four counters per thread");
         uint4 hc = reinterpret_cast<const uint4 *>(sp[0].hist)[tid];  // (requested first; added below)
         if ((npix & 1) == 0) {
             // every load of a round in flight before its first store (a segment is 8 rounds of 512 x 16 bytes)
@@ -647,31 +623,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             qrun = acc + qrun;
         }
         __syncthreads();  // the counters are complete: running totals next
-        if (STAGE == 5) MSX_STAMP(P, wk, 6);
-    }
-    if (STAGE == 4) {
-        // the model vector from the scratch into LDS (the median's passes want it there) ...
-        if ((npix & 1) == 0) {
-            const double2 *src = reinterpret_cast<const double2 *>(model_in);
-            double2 *dst = reinterpret_cast<double2 *>(model);
-            for (int i = tid; i < (npix >> 1); i += B) dst[i] = src[i];
-        } else {
-            for (int i = tid; i < npix; i += B) model[i] = model_in[i];
-        }
-        // ... and the segments' partials: histogram counts add up, the value range is the union
-        const SegPart *sp = P.segparts + wk * nseg_all;
-        for (int b = tid; b < kLogBins; b += B) {
-            unsigned int cnt = 0;
-            for (int g = 0; g < nseg_all; ++g) cnt += sp[g].hist[b];
-            S.hist[b] = cnt;
-        }
-        if (wave < 3) {  // the fit sums: serially over the segments, like the fused kernel's qrun
-            for (int g = 0; g < nseg_all; ++g) qrun += sp[g].q[wave];
-        }
-        if (early) __syncthreads();  // the counters are complete: running totals next
+        MSX_STAMP(P, wk, 6);
     }
     // the early histogram is complete (the segment loop's barrier): its running totals, published by the barrier below
-    if (early && STAGE != 3 && !producer) hist_prefix_inplace<MAXT>(S);
+    if (early && !producer) hist_prefix_inplace<MAXT>(S);
     {
         // value range: order-preserving keys, a NaN anywhere counts as above +inf
         const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
@@ -683,7 +638,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             S.kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
             if (wave < 3) S.q[0][wave] = qrun;
         }
-        const int nother = STAGE == 4 ? nseg_all : (STAGE == 5 && !producer) ? nsegs - 1 : 0;  // segments blended elsewhere
+        const int nother = (LK && !producer) ? nsegs - 1 : 0;  // segments blended elsewhere
         if (tid < nother) {  // (the segments' ranges ride in the slots of waves that have none of their own)
             S.kmin[nw + tid] = P.segparts[wk * nseg_all + tid].kmin;
             S.kmax[nw + tid] = P.segparts[wk * nseg_all + tid].kmax;
@@ -698,24 +653,26 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
         }
     }
-    if (STAGE == 3 || producer) {
-        // the segment's partials, and from segment 0 the recipe's scalars, for STAGE 4 (STAGE 5: for the joiner)
+    if (producer) {
+        // the segment's partials, for the joiner
         SegPart *sp = P.segparts + wk * nseg_all + myseg;
         for (int b = tid; b < kLogBins; b += B) sp->hist[b] = S.hist[b];
         if (tid == 0) { sp->q[0] = q[0]; sp->q[1] = q[1]; sp->q[2] = q[2]; sp->kmin = kmin; sp->kmax = kmax; }
-        if (STAGE == 3 && myseg == 0 && tid == kWave) {
-            WalkerRec *R = P.rec + wk;
-            R->lp = D.lp; R->chi_extra = D.chi_extra; R->status = MSX_W_OK;
-        }
-        if (STAGE == 5) {
-            // every thread's stores (model values, partials) have left the CU at the barrier; one agent-scope release
-            // by thread 0 then publishes them together with the increment
-            MSX_STAMP(P, wk, 3);
-            __syncthreads();
-            MSX_STAMP(P, wk, 4);
-            if (tid == 0 && !P.linked_fault) __hip_atomic_fetch_add(P.seg_flag + wk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            MSX_STAMP(P, wk, 7);
-        }
+        // EVERY wave first waits until its own stores (model values, histogram counters) have been acknowledged by the
+        // XCD's L2 -- s_waitcnt vmcnt(0), no cache operation; written out because the compiler's workgroup-scope
+        // release fence omits the wait (waves of one workgroup share their L1) -- and only then joins the barrier: a wave's wait covers its own stores only, and a CU's requests to different L2 channels are not
+        // ordered among themselves, so without it thread 0 could publish the flag while other waves' stores were still
+        // in flight.  After the barrier everything the workgroup wrote sits in the L2, and thread 0's agent-scope
+        // release (ONE write-back of that L2, then the increment) publishes it to the joiner's XCD.  (An agent-scope
+        // release in every wave is equally correct and costs eight write-backs per workgroup: 64 walkers x 16,384 px
+        // 40.3 us against 31.7.)
+        MSX_STAMP(P, wk, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        MSX_STAMP(P, wk, 4);
+        if (tid == 0 && !P.linked_fault) __hip_atomic_fetch_add(P.seg_flag + wk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        MSX_STAMP(P, wk, 7);
         return;
     }
     MSX_STAMP(P, wk, 3);
@@ -733,7 +690,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
     const double *th_w = th_row;
     auto side = [&]() __attribute__((always_inline)) {
-        if (kRecipe && fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
+        if (fast && wave == 2) recipe_band_terms<NS>(P, mode, th_w, D, lane);
     };
     // The spectrum chi^2 factorises: with P(u) = c0 + c1 u + c2 u^2 the raw fit of data/model (from the q
     // sums), the fit of data/(scale*model) is P/scale, data' = scale*data/P and
@@ -777,7 +734,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         __syncthreads();
     }
     MSX_STAMP(P, wk, 4);
-    if (STAGE != 5) MSX_STAMP(P, wk, 5);
+    if (!LK) MSX_STAMP(P, wk, 5);
 
     // ---- phase C: median scale, quadratic continuum fit, chi^2 (A8.2, A8.3, A9) ------------------
     // Pre-optimiser variants (fit_spec, mft6.py:856-1137): OPT_INIT normalises the data against the
@@ -824,7 +781,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             }
         }
     }
-    if (STAGE != 5) MSX_STAMP(P, wk, 6);
+    if (!LK) MSX_STAMP(P, wk, 6);
     if (!fused) red[0][wave][lane] = lane_partial<vk>(chia);
     if (opt_init) {
         const unsigned long long a = wave_min_u64(dmin), b = wave_max_u64(dmax);

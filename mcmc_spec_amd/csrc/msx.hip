@@ -19,8 +19,7 @@
 //   blend.h            the per-pixel model arithmetic shared by the fused and the walker-tiled kernels
 //   recipe.h           phase 0: gates, isochrone, brackets, weights, prior and band terms
 //   median.h           exact median selects (block_median, logbin_median, radix fallback)
-//   logprob_kernel.h   the hot kernel and its variants (fused; recipe-only and median/chi^2-only stages)
-//   split_kernels.h    the split path's planner and walker-tiled blend kernel
+//   logprob_kernel.h   the hot kernel and its variants (fused; linked = several workgroups per walker in one launch)
 //   staging_kernels.h  CCM89, pair gather, band integrals, broadening, resample, composite, stream copy
 //   msx.hip            host context + the C ABI of include/msx.h
 //
@@ -42,6 +41,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -55,7 +55,6 @@
 #include "recipe.h"
 #include "median.h"
 #include "logprob_kernel.h"
-#include "split_kernels.h"
 #include "staging_kernels.h"
 
 // ================================================================================================
@@ -94,6 +93,7 @@ struct msx_ctx {
     int q256 = -1;           // 256-thread launches: the two-per-CU quad-trip variant always (1) / never (0) / up to two walkers per CU (-1); MSX_Q256
     bool force_sh2 = false;  // MSX_NO_SH2=0: binaries take the <= 128-VGPR variant even with a CU to themselves (A/B measurements)
     bool zero_copy = true;   // host-pointer entry point without copy commands; MSX_ZERO_COPY=0 restores them
+    int64_t pad_lds = 0;     // MSX_PAD_LDS=bytes: extra dynamic LDS per workgroup (occupancy experiments only)
     bool model_in_global = false;
     // RCCL all-gather of log-probabilities: communicator + its own stream + per-slot events
     void *rccl_comm = nullptr;
@@ -101,27 +101,24 @@ struct msx_ctx {
     hipEvent_t ev_ready = nullptr;
     hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
     int comm_world = 0, comm_rank = 0;
+    // LOOPBACK group (msx_comm_init_loopback): `comm_world` contexts of this process stand for the ranks of one job;
+    // the all-gather of the sharded sampler becomes same-process device copies between their gathered vectors, driven
+    // in lock-step by msx_sampler_enqueue_group.  No RCCL: the rank >= 1 paths run on a one-GPU box (tests).
+    std::vector<msx_ctx *> loop_peers;   // all members in rank order (this context at [comm_rank]); empty = none
+    hipEvent_t loop_eval_done = nullptr; // this rank's block of log p(q) is in its gathered vector
+    hipEvent_t loop_copied = nullptr;    // this rank has copied every peer's block (peers may overwrite theirs)
+    // Scratch rows (walkers per sub-batch), sized once at msx_stage_problem and only for the forms that can run on
+    // the staged spectrum: model vectors of the GM variants (> 17,152 pixels) and of the linked form's producers
+    // (2..8 segments of 8192 pixels), the producers' partials and hand-over flags.  No launch allocates.
     double *d_model_scratch = nullptr;
-    int64_t cap_model_scratch = 0;  // doubles
-    // split path (split_kernels.h): per-sub-batch records, walker order, tiles; sized at msx_stage_problem
-    WalkerRec *d_rec = nullptr;
-    int32_t *d_perm = nullptr, *d_hdr = nullptr, *d_tmp = nullptr;
-    TileHdr *d_tiles = nullptr;
-    SegPart *d_segparts = nullptr;  // wide path: [split_batch][segments]
-    int32_t *d_seg_flag = nullptr;  // linked path: [split_batch] producers arrived (zero between launches)
+    SegPart *d_segparts = nullptr;  // linked form: [scratch_rows][segments]
+    int32_t *d_seg_flag = nullptr;  // linked form: [scratch_rows] producers arrived (zero between launches), + the poison word
     int nseg = 1;                   // segments of the staged spectrum (8192 pixels each)
-    int64_t split_batch = 0;        // walkers per sub-batch (0 = split path unavailable for this problem)
-    // MSX_PATH_AUTO takes the split path at / above these sizes.  Measured: the fused kernel is bound by
-    // VALU issue, not by the L2 port, once a few workgroups share a CU, so sharing row loads buys nothing and the
-    // split form's extra round trip through the model scratch costs; the defaults therefore never pick it.
-    // MSX_SPLIT_MIN / MSX_SPLIT_MIN_NPIX (environment, read at msx_stage_problem) lower them.
-    int64_t split_min_walkers = INT64_MAX, split_min_npix = INT64_MAX;
-    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _SPLIT / _WIDE (msx_set_path)
-    // MSX_PATH_AUTO takes the wide path while walkers x segments <= this x #CUs (MSX_WIDE_MAX).  Default 0 = never:
-    // measured, the blend of 128 walkers x 16,384 px already draws ~10 TB/s from the L2s on 128 CUs and
-    // 256 CUs draw 11 -- the L2 -> CU fabric, not the CU count, bounds it, and the second launch costs more than it saves.
-    int64_t wide_max_blocks_per_cu = 0;
+    int64_t scratch_rows = 0;       // 0 = neither form applies: launches are never cut into sub-batches
+    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _LINKED (msx_set_path)
     int32_t linked = -1;            // MSX_LINKED: -1 = automatic (walkers x segments <= #CUs / 2), 0 never, 1 whenever possible
+    bool linked_poisoned = false;   // a hand-over of the linked form timed out on this context (seen by a synchronous
+                                    // entry point): MSX_PATH_AUTO takes the fused form until the problem is staged again
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
     unsigned char *d_recipe_block = nullptr;  // ... and its tables in one block (dev_types.h), freed with the problem
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
@@ -200,11 +197,11 @@ void free_problem(msx_ctx *c) {
     if (c->d_opt_med) (void)hipFree(c->d_opt_med);
     c->d_opt_flux = c->d_opt_med = nullptr;
     c->opt_chains = 0;
-    void *sp[] = {c->d_rec, c->d_perm, c->d_hdr, c->d_tmp, c->d_tiles, c->d_model_scratch, c->d_segparts, c->d_seg_flag};
+    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag};
     for (void *p : sp)
         if (p) (void)hipFree(p);
-    c->d_rec = nullptr; c->d_perm = c->d_hdr = c->d_tmp = nullptr; c->d_tiles = nullptr; c->d_segparts = nullptr; c->d_seg_flag = nullptr;
-    c->d_model_scratch = nullptr; c->cap_model_scratch = 0; c->split_batch = 0;
+    c->d_segparts = nullptr; c->d_seg_flag = nullptr; c->d_model_scratch = nullptr; c->scratch_rows = 0;
+    c->linked_poisoned = false;
 }
 
 void free_grid(msx_ctx *c) {
@@ -254,6 +251,13 @@ int launch_conv(msx_ctx *c, const double *d_in, int64_t in_stride, double *d_tmp
     return MSX_OK;
 }
 
+// A synchronous entry point has seen the walkers' statuses: MSX_W_HANDOVER anywhere means the linked form's flags are
+// no longer trustworthy on this context (the device-side poison word says the same to every later linked launch).
+void note_handover(msx_ctx *c, const int32_t *status, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        if (status[i] == MSX_W_HANDOVER) { c->linked_poisoned = true; return; }
+}
+
 int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
     // Measured at 4096 px: up to one walker per CU, 512 threads owning the CU with the pixel statics in
     // LDS; up to 2 per CU, 512 threads sharing the CU two by two (<= 128 VGPRs); beyond, 256 threads three per CU
@@ -298,38 +302,43 @@ DevProblem problem_at(const DevProblem &P0, int64_t off, int mode, int ndim) {
     return P;
 }
 
-// One launch of logprob_kernel<..., STAGE> over A.n walkers with workgroups of B threads.
-//   STAGE 0 fused, STAGE 2 median / chi^2 from the stored model vectors: every variant of the table in pick_block();
-//   STAGE 1 the recipe alone: 256 threads, no dynamic LDS.
-template <int STAGE>
+// a 512-thread workgroup of a launch of n walkers has its CU to itself (long spectra: one per CU anyway)
+bool owns_cu(const msx_ctx *c, int64_t n) {
+    return n <= c->prop.multiProcessorCount || sizeof(double) * (size_t)c->P.npix > 70 * 1024;
+}
+// ... and takes the variant that keeps u and the data flux in LDS for the chi^2 pass (PF)
+bool takes_pf(const msx_ctx *c, int64_t n) {
+    return !c->model_in_global && !(c->P.nspec == 2 && c->force_sh2 && sizeof(double) * (size_t)c->P.npix <= 70 * 1024) &&
+           owns_cu(c, n) && c->pf_ok && c->use_pf;
+}
+
+// One launch of logprob_kernel<..., LK> over A.n walkers with workgroups of B threads (LK: the linked form, one
+// workgroup per walker and segment; else the fused kernel in the variant the table in pick_block() names).
+template <bool LK>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
-    // (STAGE 5: block = segment * pad8(n) + walker, see the kernel)
-    const dim3 g((unsigned)(STAGE == 3 ? A.n * c->nseg : STAGE == 5 ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
-    const size_t lds = sizeof(double) * (size_t)P.npix;
+    // (linked: block = segment * pad8(n) + walker, see the kernel)
+    const dim3 g((unsigned)(LK ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
+    const size_t lds = sizeof(double) * (size_t)P.npix + (size_t)c->pad_lds;
 #define MSX_LEAD_ARGS (P.smp_on ? (const double *)P.smp_coords : A.theta), (const unsigned char *)c->d_recipe_block, A.niso_nt, \
                       A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, P.smp_rec
-#define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                      \
-    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, STAGE>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
+#define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                   \
+    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, LK>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
                        A.logp, A.status)
     // dynamic LDS: the model vector; PF adds u and the data flux in the tables' pair layout
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
-    if constexpr (STAGE == 1) {
-        if (P.nspec == 2) MSX_GO(2, 2, 256, false, false, false, 0); else MSX_GO(3, 2, 256, false, false, false, 0);
-    } else if constexpr (STAGE == 3) {  // (the grid is walkers x segments; a segment's model values pass through LDS)
-        if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
-    } else if constexpr (STAGE == 4 || STAGE == 5) {  // (STAGE 5: the joiner holds the whole model vector; one workgroup per CU)
+    if constexpr (LK) {  // (the joiner holds the whole model vector; one workgroup per CU)
         if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
     } else if (c->model_in_global) {
-        // spectra longer than the LDS: the model vector lives in the global scratch (STAGE 0 writes it there itself)
+        // spectra longer than the LDS: the model vector lives in the global scratch (the kernel writes it there itself)
         if (P.nspec == 2) MSX_GO(2, 2, 512, true, false, false, 0); else MSX_GO(3, 2, 512, true, false, false, 0);
     } else {
         // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
-        const bool own_cu = A.n <= c->prop.multiProcessorCount || lds > 70 * 1024;  // (long spectra: one per CU anyway)
+        const bool own_cu = owns_cu(c, A.n);
         // binaries between one and two walkers per CU: the <= 128-VGPR variant, two workgroups per CU.  With a CU to
         // itself a workgroup takes the quad-walking variants (pixel statics staged in LDS when they fit): 256 walkers x
         // 4096 px 16.7-16.9 us against 17.0-17.1 for the <= 128-VGPR variant; MSX_NO_SH2=0 in the environment forces the latter
         const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024 && c->force_sh2;
-        const bool pf = B == 512 && !shared512 && !sh2 && own_cu && c->pf_ok && c->use_pf;
+        const bool pf = B == 512 && !shared512 && !sh2 && takes_pf(c, A.n);
         const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
         if (P.nspec == 2) {
             // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
@@ -363,30 +372,27 @@ hipError_t raise_one(K kernel) {
     const int room = (160 * 1024 - (int)at.sharedSizeBytes) & ~15;
     return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room);
 }
-template <int STAGE>
-hipError_t raise_stage() {
+hipError_t raise_all() {
     hipError_t e = hipSuccess;
-#define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__, STAGE>)
-    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 512, false, false, false); MSX_R(2, 2, 512, false, true, false);
-    if (STAGE == 0) MSX_R(2, 2, 256, false, true, false);
-    MSX_R(2, 2, 512, false, false, true);
-    MSX_R(3, 2, 256, false, false, false); MSX_R(3, 2, 512, false, false, false);
-    MSX_R(3, 2, 512, false, false, true);
+#define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__>)
+    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 256, false, true, false);
+    MSX_R(2, 2, 512, false, false, false); MSX_R(2, 2, 512, false, true, false); MSX_R(2, 2, 512, false, false, true);
+    MSX_R(3, 2, 256, false, false, false); MSX_R(3, 2, 512, false, false, false); MSX_R(3, 2, 512, false, false, true);
+    MSX_R(2, 2, 512, false, false, false, true); MSX_R(3, 2, 512, false, false, false, true);  // linked
 #undef MSX_R
+    if (e == hipSuccess) e = raise_one(broaden_conv_kernel);
     return e;
 }
+constexpr int kMaxDevices = 64;
 int raise_dynamic_lds_limits(msx_ctx *c) {
-    static bool done[16] = {};
-    if (c->device < 0 || c->device >= 16 || done[c->device]) return MSX_OK;
-    HIP_TRY(c, raise_stage<0>());
-    HIP_TRY(c, raise_stage<2>());
-    HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 4>));
-    HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 4>));
-    HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 3>));
-    HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 3>));
-    HIP_TRY(c, raise_one(logprob_kernel<2, 2, 512, false, false, false, 5>));
-    HIP_TRY(c, raise_one(logprob_kernel<3, 2, 512, false, false, false, 5>));
-    HIP_TRY(c, raise_one(broaden_conv_kernel));
+    // once per device and process; contexts may be created and staged from several host threads
+    static std::mutex mu;
+    static bool done[kMaxDevices] = {};
+    if (c->device < 0 || c->device >= kMaxDevices)
+        return fail(c, MSX_ERR_INVALID, "device index beyond the per-device table of dynamic-LDS limits (64 devices)");
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[c->device]) return MSX_OK;
+    HIP_TRY(c, raise_all());
     done[c->device] = true;
     return MSX_OK;
 }
@@ -406,6 +412,7 @@ int msx_create(int device, msx_ctx **out) {
     if (const char *e = getenv("MSX_Q256")) c->q256 = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("MSX_LINKED")) c->linked = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("MSX_ZERO_COPY")) c->zero_copy = !(e[0] == '0');
+    if (const char *e = getenv("MSX_PAD_LDS")) c->pad_lds = std::max<int64_t>(0, atoll(e));
     *out = c;  // returned even on failure so the caller can read msx_last_error
     HIP_TRY(c, hipSetDevice(device));
     HIP_TRY(c, hipGetDeviceProperties(&c->prop, device));
@@ -425,6 +432,10 @@ void msx_destroy(msx_ctx *c) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->rccl_comm && rccl().ok) (void)rccl().CommDestroy(c->rccl_comm);
+    for (msx_ctx *p : c->loop_peers)  // a loopback group ends with its first member
+        if (p != c) { p->loop_peers.clear(); p->comm_world = 0; p->comm_rank = 0; }
+    if (c->loop_eval_done) (void)hipEventDestroy(c->loop_eval_done);
+    if (c->loop_copied) (void)hipEventDestroy(c->loop_copied);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     for (hipEvent_t e : c->ev_done)
@@ -742,37 +753,33 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
                                   hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    // Scratch of the split path, sized once here so that no launch ever allocates or synchronises: a batch is
-    // cut into sub-batches whose model vectors (walkers x npix doubles) stay inside the Infinity Cache between the
-    // blend kernel that writes them and the median / chi^2 kernel that reads them back.
-    {
+    // Scratch, sized once here so that no launch ever allocates or synchronises -- and only for the forms the staged
+    // spectrum can take: the GM variants (model vectors beyond the LDS) and the linked form (2..8 segments).  A batch
+    // beyond `scratch_rows` walkers is then cut into sub-batches.  Everything else (config 2, 3, 5) allocates nothing.
+    c->nseg = (int)((npair + kSegElems - 1) / kSegElems);
+    const bool can_link = c->nseg >= 2 && c->nseg <= 8 && !model_in_global;
+    P.linked_fault = 0;
+    if (const char *e = getenv("MSX_LINKED_FAULT")) P.linked_fault = e[0] == '1';  // (tests: the bounded wait)
+    if (model_in_global || can_link) {
         int64_t budget = 96ll << 20;
-        if (const char *e = getenv("MSX_SPLIT_SCRATCH_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
+        if (const char *e = getenv("MSX_SCRATCH_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
         int64_t sb = budget / (int64_t)(sizeof(double) * p->npix);
         sb = std::max<int64_t>(256, std::min<int64_t>(sb, 16384));
-        if (const char *e = getenv("MSX_SPLIT_BATCH")) sb = std::max<int64_t>(1, atoll(e));
+        if (const char *e = getenv("MSX_SCRATCH_ROWS")) sb = std::max<int64_t>(1, atoll(e));
         HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * sb * p->npix));
-        c->cap_model_scratch = sb * p->npix;
-        HIP_TRY(c, hipMalloc((void **)&c->d_rec, sizeof(WalkerRec) * sb));
-        HIP_TRY(c, hipMalloc((void **)&c->d_perm, sizeof(int32_t) * sb));
-        HIP_TRY(c, hipMalloc((void **)&c->d_tmp, sizeof(int32_t) * 2 * sb));
-        HIP_TRY(c, hipMalloc((void **)&c->d_tiles, sizeof(TileHdr) * sb));
-        HIP_TRY(c, hipMalloc((void **)&c->d_hdr, 64));
-        c->nseg = (int)((npair + kSegElems - 1) / kSegElems);
-        HIP_TRY(c, hipMalloc((void **)&c->d_segparts, sizeof(SegPart) * sb * c->nseg));
-        c->split_batch = sb;
+        c->scratch_rows = sb;
         P.model_scratch = c->d_model_scratch;
-        P.rec = c->d_rec;
-        P.segparts = c->d_segparts;
-        HIP_TRY(c, hipMalloc((void **)&c->d_seg_flag, sizeof(int32_t) * sb));
-        HIP_TRY(c, hipMemset(c->d_seg_flag, 0, sizeof(int32_t) * sb));
-        P.seg_flag = c->d_seg_flag;
-        P.linked_fault = 0;
-        if (const char *e = getenv("MSX_LINKED_FAULT")) P.linked_fault = e[0] == '1';  // (tests: the bounded wait)
-        if (const char *e = getenv("MSX_SPLIT_MIN")) c->split_min_walkers = std::max<int64_t>(1, atoll(e));
-        if (const char *e = getenv("MSX_SPLIT_MIN_NPIX")) c->split_min_npix = std::max<int64_t>(1, atoll(e));
-        if (const char *e = getenv("MSX_WIDE_MAX")) c->wide_max_blocks_per_cu = std::max<int64_t>(0, atoll(e));
+        if (can_link) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_segparts, sizeof(SegPart) * sb * c->nseg));
+            P.segparts = c->d_segparts;
+            // hand-over flags, and behind them the poison word (cleared together, here and nowhere else)
+            HIP_TRY(c, hipMalloc((void **)&c->d_seg_flag, sizeof(int32_t) * (sb + 1)));
+            HIP_TRY(c, hipMemset(c->d_seg_flag, 0, sizeof(int32_t) * (sb + 1)));
+            P.seg_flag = c->d_seg_flag;
+            P.linked_poison = c->d_seg_flag + sb;
+        }
     }
+    c->linked_poisoned = false;
 #ifdef MSX_STAMPS
     {   // diagnostic build only: per-walker shader-clock stamps
         unsigned long long *st = nullptr;
@@ -801,7 +808,8 @@ int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
 #endif
 
 int msx_set_path(msx_ctx *c, int32_t path) {
-    if (!c || path < MSX_PATH_AUTO || path > MSX_PATH_LINKED) return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path");
+    if (!c || (path != MSX_PATH_AUTO && path != MSX_PATH_FUSED && path != MSX_PATH_LINKED))
+        return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path (MSX_PATH_AUTO, _FUSED or _LINKED)");
     c->path = path;
     return MSX_OK;
 }
@@ -833,85 +841,43 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
                      ((Pc.dist_fit ? 1 : 0) << 18) | ((Pc.use_av ? 1 : 0) << 19);
 
     // ---- which form of the path -------------------------------------------------------------------------
-    // split (split_kernels.h): many walkers (shared row loads) or long spectra (pixels over all CUs).  Only the
-    // likelihood / posterior / chi^2 modes of a problem with a spectrum term, float64 pairs and small recipe tables.
-    const bool can_split = c->split_batch > 0 && fast && !Pc.no_spectrum && !Pc.smp_on &&
-                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool split = can_split && (n >= c->split_min_walkers || Pc.npix >= c->split_min_npix);
-    if (c->path == MSX_PATH_FUSED) split = false;
-    if (c->path == MSX_PATH_SPLIT) {
-        if (!can_split) return fail(c, MSX_ERR_STATE, "msx_set_path(SPLIT): this problem / mode has no split form");
-        split = true;
-    }
-    // wide (logprob_kernel STAGE 3 / 4): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel
-    // segment) for the blend, so that a launch of <= #CUs / 2 walkers still uses every CU
-    const int64_t cus0 = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-    const bool can_wide = can_split && c->nseg >= 2 && c->nseg <= 8 && !c->model_in_global;
-    bool wide = can_wide && !split && n * c->nseg <= c->wide_max_blocks_per_cu * cus0;
-    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_SPLIT || c->path == MSX_PATH_LINKED) wide = false;
-    if (c->path == MSX_PATH_WIDE) {
-        if (!can_wide) return fail(c, MSX_ERR_STATE, "msx_set_path(WIDE): needs a spectrum of 2..8 segments of 8192 pixels and a mode with a split form");
-        wide = true;
-    }
-    // linked (STAGE 5): the wide form in one launch -- the segments' workgroups hand over to the walker's last one
-    // inside the kernel.  MSX_PATH_AUTO takes it while the launch fills at most HALF the CUs (16 walkers x 16,384 px
-    // 29.1 against 34.0 us fused, 64 walkers 32.1 against 33.9; at 128 walkers every CU is busy, the blend runs at the
-    // L2's aggregate rate instead of the CU's own and the hand-over's fences cost more than the blend gains: 36.9
+    // linked (logprob_kernel<..., LK>): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel segment), the
+    // segments' workgroups hand over to the walker's last one inside the kernel, so that a launch of <= #CUs / 2 walkers
+    // still uses every CU.  Only the likelihood / posterior / chi^2 modes of a problem with a spectrum term and the
+    // register-resident recipe.  MSX_PATH_AUTO takes it while the launch fills at most HALF the CUs (16 walkers x
+    // 16,384 px 29.1 against 34.0 us fused, 64 walkers 32.1 against 33.9; at 128 walkers every CU is busy, the blend runs
+    // at the L2's aggregate rate instead of the CU's own and the hand-over's fences cost more than the blend gains: 36.9
     // against 34.8).  MSX_LINKED=0 / 1 in the environment: never / whenever possible.
-    bool linked = can_wide && !split && !wide && c->linked != 0 && (c->linked > 0 || 2 * n * c->nseg <= cus0);
-    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_SPLIT || c->path == MSX_PATH_WIDE) linked = false;
+    // A context whose hand-over has once timed out is POISONED until the problem is staged again: AUTO takes the
+    // fused form, an explicit MSX_PATH_LINKED is refused (and the kernel itself fails every walker, for callers of
+    // this entry point who never looked at the statuses).
+    const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum && !Pc.smp_on &&
+                          (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    bool linked = can_link && !c->linked_poisoned && c->linked != 0 && (c->linked > 0 || 2 * n * c->nseg <= cus);
+    if (c->path == MSX_PATH_FUSED) linked = false;
     if (c->path == MSX_PATH_LINKED) {
-        if (!can_wide) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels and a mode with a split form");
+        if (!can_link) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
+        if (c->linked_poisoned)
+            return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): a hand-over timed out on this context (MSX_W_HANDOVER); stage the problem again");
         linked = true;
     }
-    // sub-batches: the split path's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
-    // hold split_batch walkers
-    const int64_t step = (split || wide || linked || c->model_in_global) ? c->split_batch : n;
-    const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    // sub-batches: the linked form's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
+    // hold scratch_rows walkers
+    const int64_t step = (linked || c->model_in_global) ? c->scratch_rows : n;
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min<int64_t>(step, n - off);
         A.theta = d_theta + off * ndim; A.logp = d_logp + off; A.status = d_status + off; A.n = m;
         const DevProblem P = problem_at(Pc, off, mode, ndim);
         const int B = block_threads > 0 ? block_threads : pick_block(c, m, Pc.npix);
         int rc;
-        if (wide) {
-            LaunchArgs A3 = A;
-            A3.ng_mode_fast |= c->nseg << 24;
-            if ((rc = launch_logprob<3>(c, P, A3, 512, false))) return rc;
-            if ((rc = launch_logprob<4>(c, P, A, 512, false))) return rc;
-            continue;
-        }
         if (linked) {
             LaunchArgs A5 = A;
             A5.ng_mode_fast |= c->nseg << 24;
-            if ((rc = launch_logprob<5>(c, P, A5, 512, false))) return rc;
-            continue;
+            if ((rc = launch_logprob<true>(c, P, A5, 512, false))) return rc;
+        } else {
+            if ((rc = launch_logprob<false>(c, P, A, B, shared512))) return rc;
         }
-        if (!split) {
-            if ((rc = launch_logprob<0>(c, P, A, B, shared512))) return rc;
-            continue;
-        }
-        // 1. recipes -> records (rejected walkers are finished here)
-        if ((rc = launch_logprob<1>(c, P, A, 256, false))) return rc;
-        // 2. group by grid cell, cut into tiles
-        hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kPlanThreads), 0, s, c->d_rec, (int)m, Pc.nspec * 4, c->d_perm,
-                           c->d_tiles, c->d_hdr, c->d_tmp, c->d_tmp + c->split_batch);
-        HIP_TRY(c, hipGetLastError());
-        // 3. blend: (tile, 512-pixel chunk) work items, grid-strided; the grid is a multiple of 8 (XCD-local chunks)
-        {
-            const int64_t nchunk = Pc.npair / 256;
-            const int64_t items = m * nchunk;  // upper bound: one tile per walker
-            const unsigned grid = (unsigned)(std::min<int64_t>((items + 7) / 8 * 8, cus * 8));
-            if (Pc.nspec == 2)
-                hipLaunchKernelGGL((blend_tiles_kernel<2>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles, c->d_hdr,
-                                   Pc.r2, Pc.h2, Pc.kl2, Pc.dk2, (int)Pc.npix, (int)Pc.npair, c->d_model_scratch);
-            else
-                hipLaunchKernelGGL((blend_tiles_kernel<3>), dim3(grid), dim3(256), 0, s, c->d_rec, c->d_perm, c->d_tiles, c->d_hdr,
-                                   Pc.r2, Pc.h2, Pc.kl2, Pc.dk2, (int)Pc.npix, (int)Pc.npair, c->d_model_scratch);
-            HIP_TRY(c, hipGetLastError());
-        }
-        // 4. per walker: fit sums, exact median, chi^2, combine
-        if ((rc = launch_logprob<2>(c, P, A, B, shared512))) return rc;
     }
     return MSX_OK;
 }
@@ -955,6 +921,7 @@ int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, 
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         memcpy(logp_out, h_out, sizeof(double) * n);
         memcpy(status_out, h_st, sizeof(int32_t) * n);
+        note_handover(c, status_out, n);
         return MSX_OK;
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, h_theta, sizeof(double) * n * ndim, hipMemcpyHostToDevice, c->stream));
@@ -966,6 +933,7 @@ int msx_logprob_batch(msx_ctx *c, int32_t mode, const double *theta, int64_t n, 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(logp_out, h_out, sizeof(double) * n);
     memcpy(status_out, reinterpret_cast<int32_t *>(h_out + n), sizeof(int32_t) * n);
+    note_handover(c, status_out, n);
     return MSX_OK;
 }
 
@@ -1116,8 +1084,9 @@ int msx_sampler_shard(msx_ctx *c, int32_t rank, int32_t world) {
     SamplerRun *r = c->smp;
     if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_shard: call msx_sampler_begin first");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, MSX_ERR_INVALID, "msx_sampler_shard: bad rank / world");
-    if (world > 1 && (!c->rccl_comm || c->comm_world != world || c->comm_rank != rank))
-        return fail(c, MSX_ERR_STATE, "msx_sampler_shard: msx_comm_init(rank, world) must come first");
+    const bool have_comm = c->rccl_comm || !c->loop_peers.empty();
+    if (world > 1 && (!have_comm || c->comm_world != world || c->comm_rank != rank))
+        return fail(c, MSX_ERR_STATE, "msx_sampler_shard: msx_comm_init(rank, world) or msx_comm_init_loopback must come first");
     for (auto &sl : r->slot)
         if (sl.busy) return fail(c, MSX_ERR_STATE, "msx_sampler_shard: chunks are already in flight");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1131,9 +1100,21 @@ int msx_sampler_shard(msx_ctx *c, int32_t rank, int32_t world) {
     return MSX_OK;
 }
 
-int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
-                        const int32_t *partner, const double *zz, const double *zfac, const double *logu) {
-    if (!c) return MSX_ERR_INVALID;
+// ---- one chunk of the device-resident sampler, in pieces ------------------------------------------------------
+// msx_sampler_enqueue = prepare; { eval; gather; apply } per half-step; finish.  The loopback group's entry point
+// (msx_sampler_enqueue_group) runs the same pieces for all its ranks in lock-step, with device copies for the gather.
+struct ChunkPtrs {
+    int64_t nh = 0;
+    double *d_zz = nullptr, *d_zfac = nullptr, *d_logu = nullptr;
+    int32_t *d_sidx = nullptr, *d_cidx = nullptr, *d_partner = nullptr;
+    const SmpRec *d_rec = nullptr;
+    double *d_chain = nullptr, *d_lpchain = nullptr;
+    int64_t *d_nacc_snap = nullptr;
+    int32_t *d_worst = nullptr;
+};
+
+static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
+                         const int32_t *partner, const double *zz, const double *zfac, const double *logu, ChunkPtrs *cp) {
     SamplerRun *r = c->smp;
     if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: call msx_sampler_begin first");
     if (slot < 0 || slot > 1 || nsteps < 1 || nsteps > r->cap_steps || !sidx || !cidx || !partner || !zz || !zfac || !logu)
@@ -1164,51 +1145,71 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
     HIP_TRY(c, hipMemcpyAsync(sl.d_in, sl.h_in, r->in_bytes(nsteps), hipMemcpyHostToDevice, r->up));
     HIP_TRY(c, hipEventRecord(sl.in_ready, r->up));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.in_ready, 0));
-    double *d_zz = (double *)sl.d_in, *d_zfac = d_zz + nh, *d_logu = d_zfac + nh;
-    int32_t *d_sidx = (int32_t *)(d_logu + nh), *d_cidx = d_sidx + nh, *d_partner = d_cidx + nh;
-    const SmpRec *d_rec = (const SmpRec *)(d_partner + nh);
-    double *d_chain = (double *)sl.d_out, *d_lpchain = d_chain + nsteps * nw * ndim;
-    int64_t *d_nacc_snap = (int64_t *)(d_lpchain + nsteps * nw);
-    int32_t *d_worst = (int32_t *)(d_nacc_snap + nw);
-    HIP_TRY(c, hipMemsetAsync(d_worst, 0, sizeof(int32_t), c->stream));
+    cp->nh = nh;
+    cp->d_zz = (double *)sl.d_in; cp->d_zfac = cp->d_zz + nh; cp->d_logu = cp->d_zfac + nh;
+    cp->d_sidx = (int32_t *)(cp->d_logu + nh); cp->d_cidx = cp->d_sidx + nh; cp->d_partner = cp->d_cidx + nh;
+    cp->d_rec = (const SmpRec *)(cp->d_partner + nh);
+    cp->d_chain = (double *)sl.d_out; cp->d_lpchain = cp->d_chain + nsteps * nw * ndim;
+    cp->d_nacc_snap = (int64_t *)(cp->d_lpchain + nsteps * nw);
+    cp->d_worst = (int32_t *)(cp->d_nacc_snap + nw);
+    HIP_TRY(c, hipMemsetAsync(cp->d_worst, 0, sizeof(int32_t), c->stream));
     DevProblem &P = c->P;
     P.smp_on = 1;
-    P.smp_coords = r->d_coords; P.smp_logp = r->d_logp; P.smp_q = r->d_q; P.smp_naccept = r->d_nacc; P.smp_worst = d_worst;
+    P.smp_coords = r->d_coords; P.smp_logp = r->d_logp; P.smp_q = r->d_q; P.smp_naccept = r->d_nacc; P.smp_worst = cp->d_worst;
+    return MSX_OK;
+}
+
+// the half-step's pointers; then this rank's evaluation: the whole half-step fused (unsharded), or log p(q) of its
+// block of the proposals only, accept deferred (sharded)
+static int chunk_half_eval(msx_ctx *c, const ChunkPtrs &cp, int64_t st, int half) {
+    SamplerRun *r = c->smp;
+    DevProblem &P = c->P;
+    const int64_t ns = r->ns, nw = r->nw;
+    const int ndim = r->ndim;
+    const int64_t off = (st * 2 + half) * ns;
+    P.smp_sidx = cp.d_sidx + off; P.smp_cidx = cp.d_cidx + off; P.smp_partner = cp.d_partner + off;
+    P.smp_zz = cp.d_zz + off; P.smp_zfac = cp.d_zfac + off; P.smp_logu = cp.d_logu + off; P.smp_rec = cp.d_rec + off;
+    P.smp_chain_row = cp.d_chain + st * nw * ndim; P.smp_lp_row = cp.d_lpchain + st * nw;
+    if (!r->sharded) return msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
+    // sharded: (1) this rank's block of proposals -> log p(q) only; (2) ONE all-gather of shard_m float64 per rank, in
+    // place in the gathered vector; (3) every rank finishes the half-step for all ns walkers
+    const int64_t lo = std::min<int64_t>(r->rank * r->shard_m, ns), hi = std::min<int64_t>(lo + r->shard_m, ns);
     int rc = MSX_OK;
-    for (int64_t st = 0; st < nsteps && rc == MSX_OK; ++st) {
-        for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
-            const int64_t off = (st * 2 + half) * ns;
-            P.smp_sidx = d_sidx + off; P.smp_cidx = d_cidx + off; P.smp_partner = d_partner + off;
-            P.smp_zz = d_zz + off; P.smp_zfac = d_zfac + off; P.smp_logu = d_logu + off; P.smp_rec = d_rec + off;
-            P.smp_chain_row = d_chain + st * nw * ndim; P.smp_lp_row = d_lpchain + st * nw;
-            if (!r->sharded) {
-                rc = msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
-                continue;
-            }
-            // sharded: (1) this rank's block of proposals -> log p(q) only; (2) ONE all-gather of shard_m float64
-            // per rank, in place in the gathered vector; (3) every rank finishes the half-step for all ns walkers
-            const int64_t lo = std::min<int64_t>(r->rank * r->shard_m, ns), hi = std::min<int64_t>(lo + r->shard_m, ns);
-            DevProblem keep = P;
-            if (hi > lo) {
-                P.smp_defer = 1;
-                P.smp_sidx += lo; P.smp_cidx += lo; P.smp_partner += lo; P.smp_zz += lo; P.smp_zfac += lo; P.smp_logu += lo;
-                P.smp_rec += lo;
-                P.smp_q = r->d_q + lo * ndim;
-                rc = msx_logprob_batch_dev(c, r->mode, r->d_q + lo * ndim, hi - lo, ndim, r->d_newlp_all + lo, r->d_wst + lo,
-                                           c->stream, 0);
-            }
-            P = keep;
-            if (rc != MSX_OK) break;
-            if (c->rccl_comm && c->comm_world == r->world) {  // (a one-rank communicator still runs the collective)
-                const int nrc = rccl().AllGather(r->d_newlp_all + r->rank * r->shard_m, r->d_newlp_all, (size_t)r->shard_m,
-                                                 kNcclFloat64, c->rccl_comm, c->stream);
-                if (nrc != 0) { rc = fail(c, MSX_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(nrc)); break; }
-            }
-            hipLaunchKernelGGL(sampler_apply_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, P,
-                               r->d_newlp_all, ns, ndim);
-            if (hipGetLastError() != hipSuccess) rc = fail(c, MSX_ERR_HIP, "sampler_apply_kernel launch failed");
-        }
+    if (hi > lo) {
+        const DevProblem keep = P;
+        P.smp_defer = 1;
+        P.smp_sidx += lo; P.smp_cidx += lo; P.smp_partner += lo; P.smp_zz += lo; P.smp_zfac += lo; P.smp_logu += lo;
+        P.smp_rec += lo;
+        P.smp_q = r->d_q + lo * ndim;
+        rc = msx_logprob_batch_dev(c, r->mode, r->d_q + lo * ndim, hi - lo, ndim, r->d_newlp_all + lo, r->d_wst + lo, c->stream, 0);
+        P = keep;
     }
+    return rc;
+}
+
+static int chunk_half_gather_rccl(msx_ctx *c) {
+    SamplerRun *r = c->smp;
+    if (!(c->rccl_comm && c->comm_world == r->world)) return MSX_OK;  // (world 1 without a communicator: nothing to do)
+    // (a one-rank communicator still runs the collective)
+    const int nrc = rccl().AllGather(r->d_newlp_all + r->rank * r->shard_m, r->d_newlp_all, (size_t)r->shard_m, kNcclFloat64,
+                                     c->rccl_comm, c->stream);
+    if (nrc != 0) return fail(c, MSX_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(nrc));
+    return MSX_OK;
+}
+
+static int chunk_half_apply(msx_ctx *c) {
+    SamplerRun *r = c->smp;
+    if (!r->sharded) return MSX_OK;
+    hipLaunchKernelGGL(sampler_apply_kernel, dim3((unsigned)((r->ns + 255) / 256)), dim3(256), 0, c->stream, c->P,
+                       r->d_newlp_all, r->ns, r->ndim);
+    if (hipGetLastError() != hipSuccess) return fail(c, MSX_ERR_HIP, "sampler_apply_kernel launch failed");
+    return MSX_OK;
+}
+
+static int chunk_finish(msx_ctx *c, int32_t slot, int64_t nsteps, const ChunkPtrs &cp, int rc) {
+    SamplerRun *r = c->smp;
+    SamplerRun::Slot &sl = r->slot[slot];
+    DevProblem &P = c->P;
     P.smp_on = 0;
     P.smp_defer = 0;
     if (rc != MSX_OK) {
@@ -1218,7 +1219,7 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
         return rc;
     }
     // acceptance counters keep running while this chunk's results travel: snapshot them in stream order
-    HIP_TRY(c, hipMemcpyAsync(d_nacc_snap, r->d_nacc, sizeof(int64_t) * nw, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cp.d_nacc_snap, r->d_nacc, sizeof(int64_t) * r->nw, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(sl.kernels_done, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(r->copy, sl.kernels_done, 0));
     HIP_TRY(c, hipMemcpyAsync(sl.h_out, sl.d_out, r->out_bytes(nsteps), hipMemcpyDeviceToHost, r->copy));
@@ -1226,6 +1227,86 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
     sl.nsteps = nsteps;
     sl.busy = true;
     return MSX_OK;
+}
+
+int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
+                        const int32_t *partner, const double *zz, const double *zfac, const double *logu) {
+    if (!c) return MSX_ERR_INVALID;
+    if (c->smp && c->smp->sharded && c->smp->world > 1) {
+        if (!c->loop_peers.empty())
+            return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: the ranks of a loopback group advance together (msx_sampler_enqueue_group)");
+        if (!c->rccl_comm || c->comm_world != c->smp->world)
+            return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: the run is sharded over a communicator that no longer exists");
+    }
+    ChunkPtrs cp;
+    int rc = chunk_prepare(c, slot, nsteps, sidx, cidx, partner, zz, zfac, logu, &cp);
+    if (rc != MSX_OK) return rc;
+    for (int64_t st = 0; st < nsteps && rc == MSX_OK; ++st)
+        for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
+            rc = chunk_half_eval(c, cp, st, half);
+            if (rc == MSX_OK && c->smp->sharded) rc = chunk_half_gather_rccl(c);
+            if (rc == MSX_OK) rc = chunk_half_apply(c);
+        }
+    return chunk_finish(c, slot, nsteps, cp, rc);
+}
+
+int msx_sampler_enqueue_group(msx_ctx **ctxs, int32_t world, int32_t slot, int64_t nsteps, const int32_t *sidx,
+                              const int32_t *cidx, const int32_t *partner, const double *zz, const double *zfac,
+                              const double *logu) {
+    if (!ctxs || world < 1 || !ctxs[0]) return MSX_ERR_INVALID;
+    msx_ctx *c0 = ctxs[0];
+    for (int r = 0; r < world; ++r) {
+        msx_ctx *c = ctxs[r];
+        if (!c || (int)c->loop_peers.size() != world || c->loop_peers[(size_t)r] != c || c->comm_rank != r)
+            return fail(c0, MSX_ERR_STATE, "msx_sampler_enqueue_group: the contexts are not the ranks 0..world-1 of one loopback group");
+        if (!c->smp || !c->smp->sharded || c->smp->world != world || c->smp->rank != r)
+            return fail(c0, MSX_ERR_STATE, "msx_sampler_enqueue_group: every rank needs msx_sampler_begin + msx_sampler_shard(rank, world) first");
+        if (c->smp->ns != c0->smp->ns || c->smp->ndim != c0->smp->ndim)
+            return fail(c0, MSX_ERR_STATE, "msx_sampler_enqueue_group: the ranks hold different ensembles");
+    }
+    std::vector<ChunkPtrs> cp((size_t)world);
+    std::vector<int> rcs((size_t)world, MSX_OK);
+    int rc = MSX_OK;
+    for (int r = 0; r < world && rc == MSX_OK; ++r)   // every rank is fed the same randomness
+        rc = rcs[(size_t)r] = chunk_prepare(ctxs[r], slot, nsteps, sidx, cidx, partner, zz, zfac, logu, &cp[(size_t)r]);
+    if (rc != MSX_OK) {  // nothing is queued yet on the ranks after the failing one; the prepared ones are unwound
+        for (int r = 0; r < world; ++r) { ctxs[r]->P.smp_on = 0; ctxs[r]->P.smp_defer = 0; }
+        if (ctxs[0] != c0 || c0->err.empty()) c0->err = "msx_sampler_enqueue_group: a rank refused the chunk";
+        return rc;
+    }
+    const int64_t m = c0->smp->shard_m;
+    for (int64_t st = 0; st < nsteps && rc == MSX_OK; ++st)
+        for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
+            // (1) every rank evaluates its block into its own gathered vector -- once the peers have taken the
+            //     previous half-step's block out of it
+            for (int r = 0; r < world && rc == MSX_OK; ++r) {
+                msx_ctx *c = ctxs[r];
+                for (int p = 0; p < world; ++p)
+                    if (p != r && hipStreamWaitEvent(c->stream, ctxs[p]->loop_copied, 0) != hipSuccess) rc = fail(c0, MSX_ERR_HIP, "loopback: hipStreamWaitEvent");
+                if (rc == MSX_OK) rc = chunk_half_eval(c, cp[(size_t)r], st, half);
+                if (rc == MSX_OK && hipEventRecord(c->loop_eval_done, c->stream) != hipSuccess) rc = fail(c0, MSX_ERR_HIP, "loopback: hipEventRecord");
+            }
+            // (2) the all-gather: rank r copies block p out of rank p's vector, in place at p * m; (3) apply
+            for (int r = 0; r < world && rc == MSX_OK; ++r) {
+                msx_ctx *c = ctxs[r];
+                for (int p = 0; p < world && rc == MSX_OK; ++p) {
+                    if (p == r) continue;
+                    hipError_t e = hipStreamWaitEvent(c->stream, ctxs[p]->loop_eval_done, 0);
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(c->smp->d_newlp_all + p * m, ctxs[p]->smp->d_newlp_all + p * m, sizeof(double) * (size_t)m,
+                                           hipMemcpyDeviceToDevice, c->stream);
+                    if (e != hipSuccess) rc = fail(c0, MSX_ERR_HIP, std::string("loopback all-gather: ") + hipGetErrorString(e));
+                }
+                if (rc == MSX_OK && hipEventRecord(c->loop_copied, c->stream) != hipSuccess) rc = fail(c0, MSX_ERR_HIP, "loopback: hipEventRecord");
+                if (rc == MSX_OK) rc = chunk_half_apply(c);
+            }
+        }
+    int out = rc;
+    for (int r = 0; r < world; ++r) {
+        const int f = chunk_finish(ctxs[r], slot, nsteps, cp[(size_t)r], rc);
+        if (out == MSX_OK) out = f;
+    }
+    return out;
 }
 
 int msx_sampler_collect(msx_ctx *c, int32_t slot, double *chain_out, double *logp_out, int64_t *naccept,
@@ -1346,6 +1427,33 @@ int msx_comm_init(msx_ctx *c, const uint8_t *id128, int32_t rank, int32_t world)
     return MSX_OK;
 }
 
+int msx_comm_init_loopback(msx_ctx **ctxs, int32_t world) {
+    if (!ctxs || world < 1 || !ctxs[0]) return MSX_ERR_INVALID;
+    msx_ctx *c0 = ctxs[0];
+    for (int r = 0; r < world; ++r) {
+        if (!ctxs[r]) return fail(c0, MSX_ERR_INVALID, "msx_comm_init_loopback: null context");
+        if (ctxs[r]->rccl_comm || !ctxs[r]->loop_peers.empty())
+            return fail(c0, MSX_ERR_STATE, "msx_comm_init_loopback: a context already belongs to a communicator");
+        if (ctxs[r]->device != c0->device)
+            return fail(c0, MSX_ERR_INVALID, "msx_comm_init_loopback: the ranks of a loopback group share one device");
+        for (int q = 0; q < r; ++q)
+            if (ctxs[q] == ctxs[r]) return fail(c0, MSX_ERR_INVALID, "msx_comm_init_loopback: one context per rank");
+    }
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    for (int r = 0; r < world; ++r) {
+        msx_ctx *c = ctxs[r];
+        HIP_TRY(c0, hipEventCreateWithFlags(&c->loop_eval_done, hipEventDisableTiming));
+        HIP_TRY(c0, hipEventCreateWithFlags(&c->loop_copied, hipEventDisableTiming));
+        // (recorded once so that the first half-step's waits find completed events)
+        HIP_TRY(c0, hipEventRecord(c->loop_eval_done, c->stream));
+        HIP_TRY(c0, hipEventRecord(c->loop_copied, c->stream));
+        c->loop_peers.assign(ctxs, ctxs + world);
+        c->comm_world = world;
+        c->comm_rank = r;
+    }
+    return MSX_OK;
+}
+
 int msx_comm_allgather_dev(msx_ctx *c, const double *d_send, double *d_recv, int64_t count, void *compute_stream,
                            int32_t slot) {
     if (!c || !d_send || !d_recv || count < 1 || slot < 0 || slot > 3) return fail(c, MSX_ERR_INVALID, "msx_comm_allgather_dev: bad arguments");
@@ -1410,14 +1518,26 @@ int msx_stream_copy_gbps(msx_ctx *c, int64_t bytes, int32_t iters, double *gbps_
     return MSX_OK;
 }
 
-int msx_bytes_per_eval(msx_ctx *c, int64_t *requested_bytes) {
-    if (!c || !requested_bytes) return MSX_ERR_INVALID;
+int msx_bytes_per_eval(msx_ctx *c, int64_t n, int64_t *requested_bytes) {
+    if (!c || !requested_bytes || n < 1) return MSX_ERR_INVALID;
     if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_bytes_per_eval: no problem staged");
     const int64_t npix = c->P.npix;
-    // pair rows (16 B x corners) + per-pixel statics read in phases A and C
-    // blend: 12-B {R, H} per corner + {k_lo f64, dk f32} + flux, u;  chi^2 pass: u, flux, 1/err^2
-    *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + 24) + 8 * (2 * c->P.nspec + 2) + 12;
+    // what the variant an automatic launch of n walkers takes requests from the memory system, per walker:
+    //   blend: 12-B {R f64, H f32} per corner + {k_lo f64, dk f32} + data flux, u (f64)        per pixel
+    //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
+    const bool pf = pick_block(c, n, npix) == 512 && takes_pf(c, n);
+    *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
     return MSX_OK;
+}
+
+int msx_test_hook(msx_ctx *c, int32_t what, int32_t value) {
+    if (!c) return MSX_ERR_INVALID;
+    if (what == MSX_HOOK_LINKED_FAULT) {
+        if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_test_hook: no problem staged");
+        c->P.linked_fault = value != 0;
+        return MSX_OK;
+    }
+    return fail(c, MSX_ERR_INVALID, "msx_test_hook: unknown hook");
 }
 
 }  // extern "C"

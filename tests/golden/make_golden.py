@@ -406,6 +406,37 @@ def main():
         out['C_loglike'], out['C_logprior'], out['C_logpost'] = np.array(ll3), np.array(lp3), np.array(po3)
         print('triple: {} walkers, {} inside the box'.format(len(po3), int(np.isfinite(po3).sum())))
 
+        # ------------------------------------------------------------ triple system, dist_fit=False (mft6.py:1397-1455)
+        # Gates (:1411): Teff box, the two RATIOS >= 0.05 (R1 is not tested), plx >= 0, A_V >= 0; the Gaussian list is
+        # shorter (:1425-1442: Teff x 3, A_V, R1, ratio 2 -- no ratio 3, no parallax term).  Extra walkers: R1 = 0.03 and
+        # plx = 0.3 (both pass here, fail with dist_fit), ratio 2 / ratio 3 below 0.05, plx < 0, A_V < 0, Teff outside.
+        prior3_nd = [3800.0, 3400.0, 0.0, 60.0, 80.0, 1.0, 0.12, 0.03, 0.5, 0.4, 0.3, 0.05, 0.04, 0.03, 2.0732e-3, 0.0277e-3]
+        th3_nd = np.vstack([th3[:10], [[3850.0, 3400.0, 3100.0, 0.1, 0.03, 0.4, 0.3, 2e-3], [3850.0, 3400.0, 3100.0, 0.1, 0.5, 0.4, 0.3, 0.3],
+                                       [3850.0, 3400.0, 3100.0, 0.1, 0.5, 0.049, 0.3, 2e-3], [3850.0, 3400.0, 3100.0, 0.1, 0.5, 0.4, 0.049, 2e-3],
+                                       [3850.0, 3400.0, 3100.0, 0.1, 0.5, 0.4, 0.3, -1e-3], [3850.0, 3400.0, 3100.0, -0.1, 0.5, 0.4, 0.3, 2e-3],
+                                       [3850.0, 3400.0, 4201.0, 0.1, 0.5, 0.4, 0.3, 2e-3]]])
+        out['theta3_nodist'] = th3_nd
+        out['prior3_nodist'] = np.array(prior3_nd)
+        for rp in (False, True):
+            lp_ref, po_ref = [], []
+            for pq in th3_nd:
+                lp = mft6.logprior(list(pq), 3, 0, 3000.0, 4200.0, matrix, 10.0, 20.0, prior=prior3_nd, ext=True,
+                                   dist_fit=False, rad_prior=rp)
+                lo = orc.logprior(list(pq), 3, 3000.0, 4200.0, matrix, av_prior, prior=prior3_nd, dist_fit=False,
+                                  rad_prior=rp)
+                assert (lp == lo) or abs(lp - lo) <= 1e-13 * abs(lp), (lp, lo)
+                po = mft6.logposterior(list(pq), frC, 3, 0, [wb, sb], eb, 1700, rB, specs, ctm4, ptm6, tmiB, tmaB, None,
+                                       3000.0, 4200.0, matrix, 10.0, 20.0, prior=prior3_nd, dist_fit=False, rad_prior=rp)
+                oo = orc.logposterior(list(pq), frC, 3, [wb, sb], eb, rB, specs, ctm4, ptm6, tmiB, tmaB, 3000.0, 4200.0,
+                                      matrix, av_prior, prior=prior3_nd, dist_fit=False, rad_prior=rp, bandlib=bandlib)
+                assert (po == oo) or abs(po - oo) <= 1e-13 * abs(po), (po, oo)
+                lp_ref.append(lp)
+                po_ref.append(po)
+            tag = 'radprior' if rp else 'noradprior'
+            out['C_nodist_logprior_' + tag] = np.array(lp_ref)
+            out['C_nodist_logpost_' + tag] = np.array(po_ref)
+        print('triple, dist_fit=False: {} walkers, {} inside the box'.format(len(th3_nd), int(np.isfinite(po_ref).sum())))
+
         # ------------------------------------------------------------ f4: fit_spec (pre-optimiser), dataset B
         # The reference draws its proposals from the unseeded global RNG (make_varied_param, mft6.py:211-228);
         # to get a reproducible trajectory the draw is redirected to a seeded Generator with the same call

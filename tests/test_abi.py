@@ -77,7 +77,7 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
             capped = 'Li256E' in ln or 'Li512ELb0ELb1E' in ln   # 256 threads, or 512 with SH (shared CU)
             assert m and int(m.group(1)) <= (64 if capped else 0), block
             seen += 1
-    assert seen >= 12   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; stages 0-2
+    assert seen >= 12   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; linked
 
 
 def test_python_constants_mirror_the_header():
@@ -91,8 +91,8 @@ def test_python_constants_mirror_the_header():
              'MSX_W_INDEXERROR': _lib.W_INDEXERROR, 'MSX_W_VALUEERROR': _lib.W_VALUEERROR, 'MSX_W_HANDOVER': _lib.W_HANDOVER,
              'MSX_MODE_LOGLIKE': _lib.MODE_LOGLIKE, 'MSX_MODE_LOGPOST': _lib.MODE_LOGPOST, 'MSX_MODE_CHISQ': _lib.MODE_CHISQ,
              'MSX_MODE_LOGPRIOR': _lib.MODE_LOGPRIOR, 'MSX_BLOCK_512_SHARED': _lib.BLOCK_512_SHARED,
-             'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_SPLIT': _lib.PATH_SPLIT,
-             'MSX_PATH_WIDE': _lib.PATH_WIDE, 'MSX_PATH_LINKED': _lib.PATH_LINKED,
+             'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_LINKED': _lib.PATH_LINKED,
+             'MSX_HOOK_LINKED_FAULT': _lib.HOOK_LINKED_FAULT,
              'MSX_MAX_SPEC': _lib.MAX_SPEC, 'MSX_MAX_BANDS': _lib.MAX_BANDS, 'MSX_MAX_DIM': _lib.MAX_DIM}
     for name, val in pairs.items():
         assert defs[name] == val, name

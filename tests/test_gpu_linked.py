@@ -1,0 +1,187 @@
+"""The LINKED form of the hot path (several workgroups per walker in one launch, hand-over inside the kernel:
+mcmc_spec_amd/csrc/logprob_kernel.h, LK) against the fused kernel, the oracle and its own failure mode.
+
+The contract is stronger than the parity bar: both forms call the same per-pixel function and sum in the same
+canonical order (long spectra segment by segment in either form), so a walker's value must have the SAME BITS
+whichever form evaluates it.  And a hand-over that fails must never turn into a silent value -- not in the launch
+that fails, and not in any later one.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from common import golden_case, rel_err
+from test_gpu_parity import make_engine
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-9
+
+
+def both(eng, fn, *a, **k):
+    from mcmc_spec_amd import _lib
+    out = []
+    for path in (_lib.PATH_FUSED, _lib.PATH_LINKED):
+        eng.ctx.set_path(path)
+        out.append(fn(*a, **k))
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    return out
+
+
+@pytest.mark.parametrize('n', [1, 5, 128, 300])
+def test_linked_config4_bits(n):
+    """BASELINE config 4's spectrum (16,384 px + photometry): the linked form (one workgroup per walker and 8192-pixel
+    segment) gives the fused kernel's bits for any walker count, also beyond the sizes the automatic choice would
+    take it for; the fused kernel itself sums such a spectrum segment by segment."""
+    import bench
+    from mcmc_spec_amd import synth
+    from mcmc_spec_amd.engine import Engine
+    key = 'wide16k'
+    if key not in common._cache:
+        eng = Engine(0)
+        common._cache[key] = (eng, bench.build_workload(eng, 16384, True))
+    eng, W = common._cache[key]
+    th = synth.draw_walkers(n, seed=40 + n, tmin=W['tmin'], tmax=W['tmax'])
+    if n >= 5:
+        th[1, 1] = 2999.0            # rejected by the prior box: segment 0's workgroup alone finishes it
+        th[3, 2] = 0.0               # no reddening
+    f, l = both(eng, eng.logposterior, th)
+    assert np.array_equal(f, l)
+    assert np.isfinite(f).sum() >= n - 1
+    # the automatic choice (the linked form while walkers x segments <= #CUs), and again: the hand-over flags are back at zero
+    for _ in range(2):
+        assert np.array_equal(f, eng.logposterior(th))
+    f, l = both(eng, eng.loglikelihood, th[:1], optimize=True)
+    assert np.array_equal(f, l)
+
+
+def test_linked_three_segments_against_the_oracle():
+    """17,000 pixels = two full segments and a short third, unsorted wavelengths: against the oracle and the fused
+    kernel; an error status (Teff outside the isochrone, likelihood mode) comes back through segment 0."""
+    from mcmc_spec_amd import _lib, bands
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    rng = np.random.default_rng(5)
+    wl = rng.uniform(0.56, 0.89, 17000)
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    f, l = both(eng, eng.loglikelihood, c.theta[:12])
+    assert np.array_equal(f, l) and np.all(np.isfinite(f))
+    one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(l[0], one) < TIGHT
+    bad = c.theta[:6].copy()
+    bad[2, 0] = 2800.0
+    eng.ctx.set_path(_lib.PATH_LINKED)
+    with pytest.raises(ValueError):
+        eng.loglikelihood(bad)
+    # a one-segment spectrum has no linked form (and allocates no scratch for one)
+    e1 = make_engine(c)
+    e1.ctx.set_path(_lib.PATH_LINKED)
+    with pytest.raises(_lib.MsxError):
+        e1.loglikelihood(c.theta[:4])
+    with pytest.raises(_lib.MsxError):   # the split / wide forms of rounds 1-2 are gone
+        e1.ctx.set_path(2)
+
+
+def _config4_engine():
+    import bench
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    return eng, bench.build_workload(eng, 16384, True)
+
+
+def test_linked_hand_over_that_never_comes_fails_loudly_and_poisons_the_context():
+    """The fault hook makes the producers skip their signal: every joiner gives up after 20 ms of wall clock, the
+    walker reports MSX_W_HANDOVER and Python raises -- no hang, no value.  From then on, WITHOUT staging again and
+    with the fault gone, the context must never hand out a value computed from the flags the failed launch left
+    behind: the automatic choice takes the fused form (bit-equal), an explicit PATH_LINKED is refused; staging again
+    brings the linked form back."""
+    import time
+    from mcmc_spec_amd import _lib, synth
+    eng, W = _config4_engine()
+    th = synth.draw_walkers(40, seed=77, tmin=W['tmin'], tmax=W['tmax'])
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    want = eng.logposterior(th)
+    eng.ctx.set_path(_lib.PATH_LINKED)
+    assert np.array_equal(eng.logposterior(th), want)
+    eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 1)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='did not meet'):
+        eng.logposterior(th)
+    assert time.time() - t0 < 5.0
+    eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 0)          # the fault is gone; the problem is NOT staged again
+    with pytest.raises(_lib.MsxError, match='timed out'):
+        eng.logposterior(th)                               # explicit linked form: refused
+    eng.ctx.set_path(_lib.PATH_AUTO)                       # 40 walkers x 2 segments <= #CUs / 2: would be linked
+    assert np.array_equal(eng.logposterior(th), want)      # ... takes the fused form instead
+    W = __import__('bench').build_workload(eng, 16384, True)   # staged afresh: flags and poison cleared
+    eng.ctx.set_path(_lib.PATH_LINKED)
+    assert np.array_equal(eng.logposterior(th), want) and np.all(np.isfinite(want))
+
+
+def test_linked_poison_reaches_callers_who_never_read_a_status():
+    """The device-pointer entry point does not synchronise, so its caller may launch again before -- or without ever --
+    looking at the statuses of a launch whose hand-over failed.  The poison word lives on the device: every later
+    linked launch on the context reports MSX_W_HANDOVER for ALL its walkers (NaN with the status in its payload),
+    not a value read through stale flags."""
+    import torch
+    from mcmc_spec_amd import _lib, synth
+    eng, W = _config4_engine()
+    n = 24
+    thn = synth.draw_walkers(n, seed=78, tmin=W['tmin'], tmax=W['tmax'])
+    dev = torch.device('cuda', 0)
+    th = torch.from_numpy(thn).to(dev)
+    lp = torch.zeros(n, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    sp = torch.cuda.current_stream(dev).cuda_stream
+    eng.ctx.set_path(_lib.PATH_LINKED)
+
+    def launch():
+        eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), sp, _lib.MODE_LOGPOST, 0)
+
+    launch()
+    torch.cuda.synchronize()
+    good = lp.cpu().numpy().copy()
+    assert np.all(st.cpu().numpy() == _lib.W_OK) and np.all(np.isfinite(good))
+    eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 1)
+    launch()                                               # every joiner times out; nobody reads the statuses
+    eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 0)
+    for _ in range(2):                                     # healthy launches, same context, not staged again
+        lp.zero_()
+        st.zero_()
+        launch()
+        torch.cuda.synchronize()
+        assert np.all(st.cpu().numpy() == _lib.W_HANDOVER)
+        assert np.all(np.isnan(lp.cpu().numpy()))
+    eng.ctx.set_path(_lib.PATH_FUSED)                      # the fused form does not depend on any of it
+    launch()
+    torch.cuda.synchronize()
+    assert np.array_equal(lp.cpu().numpy(), good)
+
+
+@pytest.mark.parametrize('npix', [8193, 9001, 16383])
+def test_segment_forms_with_an_odd_pixel_count(npix):
+    """Odd pixel counts (the scratch rows are then only 8-byte aligned: the segment copies take their scalar paths), a
+    second segment of ONE pixel, and one pixel short of two full segments: linked against fused, and the oracle."""
+    from mcmc_spec_amd import bands
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    rng = np.random.default_rng(npix)
+    wl = rng.uniform(0.56, 0.89, npix)
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    f, l = both(eng, eng.loglikelihood, c.theta[:9])
+    assert np.array_equal(f, l) and np.all(np.isfinite(f))
+    one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(l[0], one) < TIGHT

@@ -812,6 +812,30 @@ def test_dist_fit_false_branch_matches_reference_golden(rad_prior):
     assert np.isfinite(want[10]) and np.isfinite(want[11])   # R1 = 1.7 and plx = 0.3 pass without dist_fit
 
 
+@pytest.mark.parametrize('rad_prior', [False, True])
+def test_triple_dist_fit_false_branch_matches_reference_golden(rad_prior):
+    """The last prior branch: ndim 8 with dist_fit=False (mft6.py:1397-1455).  Gates (:1411): Teff box, the two RATIOS
+    >= 0.05 -- R1 is not tested --, plx >= 0, A_V >= 0; Gaussian terms for Teff x 3, A_V, R1 and ratio 2 only
+    (:1425-1442).  Through the drop-in signatures, against the reference's own logprior / logposterior."""
+    c = golden_case('C')
+    g = c.g
+    m = _dropin(c)
+    th = g['theta3_nodist']
+    prior = list(g['prior3_nodist'])
+    args = [c.fr, 3, 0, c.data, c.err, 1700, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, None, c.tmin, c.tmax, c.matrix, 10.0,
+            20.0]
+    tag = 'radprior' if rad_prior else 'noradprior'
+    got = m.logposterior(th, *args, prior=prior, a=True, dist_fit=False, rad_prior=rad_prior)
+    want = g['C_nodist_logpost_' + tag]
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and rel_err(got, want).max() < TIGHT
+    lp = m.logprior(th, 3, 0, c.tmin, c.tmax, c.matrix, 10.0, 20.0, prior=prior, ext=True, dist_fit=False,
+                    rad_prior=rad_prior)
+    wantp = g['C_nodist_logprior_' + tag]
+    assert np.array_equal(np.isinf(lp), np.isinf(wantp)) and rel_err(lp, wantp).max() < 1e-12
+    assert np.isfinite(want[10]) and np.isfinite(want[11])   # R1 = 0.03 and plx = 0.3 pass without dist_fit
+    assert np.all(np.isinf(want[12:]))                       # ratio 2, ratio 3, plx < 0, A_V < 0, Teff outside
+
+
 def test_nospec_variant_matches_mft6_nospec_golden():
     """The mft6_nospec.py likelihood (spectrum term commented out, mft6_nospec.py:1163-1196) is a flag on the
     same kernel; golden values come from the reference's mft6_nospec.py itself."""
@@ -867,7 +891,9 @@ def test_resampled_tables_stay_at_rounding_level_under_heavy_extinction():
     e = rel_err(got, want)
     print('resampled tables, A_V in {0, 0.3, 1, 3}: max relative deviation from the oracle', e.max())
     assert e.max() < 1e-11
-    assert eng.ctx.bytes_per_eval() == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12   # 12 bytes per node-pixel are in use
+    # 12 bytes per node-pixel are in use; a workgroup with a CU to itself keeps u and the data flux in LDS for the chi^2 pass
+    assert eng.ctx.bytes_per_eval(100000) == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12
+    assert eng.ctx.bytes_per_eval(64) == 700 * (12 * 8 + 12 + 16 + 8) + 8 * 6 + 12
 
 
 def test_fuzzed_problems_against_the_oracle():

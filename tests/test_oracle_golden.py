@@ -154,6 +154,28 @@ def test_dist_fit_false_prior(rad_prior):
     assert np.array_equal(np.isinf(lp), np.isinf(want)) and rel_err(lp, want).max() < 1e-13
 
 
+@pytest.mark.parametrize('rad_prior', [False, True])
+def test_triple_dist_fit_false_prior_and_posterior(rad_prior):
+    """ndim 8, dist_fit=False (mft6.py:1397-1455): the oracle against the reference's logprior on every walker and
+    its logposterior on a few (a posterior costs a full spectrum synthesis on the CPU)."""
+    c = golden_case('C')
+    g = c.g
+    tag = 'radprior' if rad_prior else 'noradprior'
+    prior = list(g['prior3_nodist'])
+    th = g['theta3_nodist']
+    lp = np.array([orc.logprior(list(t), 3, c.tmin, c.tmax, c.matrix, common.av_prior, prior=prior, dist_fit=False,
+                                rad_prior=rad_prior) for t in th])
+    want = g['C_nodist_logprior_' + tag]
+    assert np.array_equal(np.isinf(lp), np.isinf(want)) and rel_err(lp, want).max() < 1e-13
+    assert np.isfinite(want[10]) and np.isfinite(want[11]) and np.all(np.isinf(want[12:]))
+    for i in (0, 10, 11, 13):
+        po = orc.logposterior(list(th[i]), c.fr, 3, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, c.tmin,
+                              c.tmax, c.matrix, common.av_prior, prior=prior, dist_fit=False, rad_prior=rad_prior,
+                              bandlib=c.bandlib)
+        w = g['C_nodist_logpost_' + tag][i]
+        assert (po == w) or abs(po - w) < 1e-13 * abs(w)
+
+
 def test_nospec_variant():
     c = golden_case('B')
     got = [orc.loglikelihood(list(t), c.fr, 2, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, c.matrix,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter pass (counters only, its own run) over one sweep point; prints per-kernel means.
-#   gpurun -- 'tools/pmc_kernels.sh tag 4096 3072 split'
-tag=${1:-x}; npix=${2:-4096}; n=${3:-3072}; path=${4:-split}
+#   gpurun -- 'tools/pmc_kernels.sh tag 4096 3072 fused'
+tag=${1:-x}; npix=${2:-4096}; n=${3:-3072}; path=${4:-fused}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/pmck_${tag}_${npix}_${n}_$path
 mkdir -p $out
@@ -17,7 +17,7 @@ for d in ('sq', 'sq2'):
     for f in glob.glob(out + '/%s/**/*_counter_collection.csv' % d, recursive=True):
         for row in csv.DictReader(open(f)):
             k = row.get('Kernel_Name', '')
-            if not any(s in k for s in ('logprob_kernel', 'blend_tiles', 'plan_tiles')):
+            if not any(s in k for s in ('logprob_kernel', 'logprob_pair_kernel', 'pair_plan_kernel')):
                 continue
             short = k.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
             acc[short][row['Counter_Name']].append(float(row['Counter_Value']))

@@ -47,8 +47,8 @@ json.dump(out, open('%s/%s_valu.json' % (dst, tag), 'w'), indent=1)
 print(json.dumps(out['points'], indent=1))
 PY
 # ---- the other forms of the path, per kernel
-PATHS="fused split" tools/prof_split.sh $tag "4096:3072,4096:16384" > $dst/${tag}_forms_4096px.txt 2>&1
-PATHS="fused wide linked split" tools/prof_split.sh $tag "16384:128" > $dst/${tag}_forms_16384px.txt 2>&1
+PATHS="fused split" tools/prof_forms.sh $tag "4096:3072,4096:16384" > $dst/${tag}_forms_4096px.txt 2>&1
+PATHS="fused wide linked split" tools/prof_forms.sh $tag "16384:128" > $dst/${tag}_forms_16384px.txt 2>&1
 python3 tools/sweep.py --blocks 0 --paths fused --walkers 26,128,256,512,1024,2048,4096,16384 > $dst/${tag}_sweep_4096px.jsonl 2>/dev/null
 python3 tools/sweep.py --blocks 0 --paths fused --npix 16384 --phot --walkers 32,128,512 > $dst/${tag}_sweep_16384px.jsonl 2>/dev/null
 # ---- the linked form against the fused kernel (few walkers x long spectrum), and where its time goes (diagnostic builds)

@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--npix', type=int, default=4096)
     ap.add_argument('--mode', default='logpost')
     ap.add_argument('--av0', action='store_true', help='all walkers at A_V = 0: no reddening, the blend loads R only')
-    ap.add_argument('--path', default='fused', help='fused | split | linked (split: the stamps are those of the LAST kernel, stage 2; linked: the joiners)')
+    ap.add_argument('--path', default='fused', help='fused | linked (linked: the joiners; with MSX_STAMPS_PRODUCERS and a -DMSX_STAMPS=2 build, the producers)')
     args = ap.parse_args()
     import torch
     from bench import build_workload
@@ -41,7 +41,7 @@ def main():
     lp = torch.empty(n, dtype=torch.float64, device=dev)
     st = torch.empty(n, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
-    eng.ctx.set_path({'split': _lib.PATH_SPLIT, 'linked': _lib.PATH_LINKED}.get(args.path, _lib.PATH_FUSED))
+    eng.ctx.set_path({'linked': _lib.PATH_LINKED}.get(args.path, _lib.PATH_FUSED))
     for _ in range(20):
         eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), s, {'logpost': _lib.MODE_LOGPOST, 'loglike': _lib.MODE_LOGLIKE}[args.mode], args.block)
     torch.cuda.synchronize()
@@ -50,23 +50,6 @@ def main():
     fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     fn.restype = C.c_int
     assert fn(eng.ctx.h, n, out.ctypes.data) == 0
-    if args.path == 'split':
-        o = out.astype(np.int64)
-        tot = o[:, 7] - o[:, 0]
-        print('split path, stage 2 (median / chi^2 kernel), walkers {} block {}: median total {} cycles'.format(n, args.block or 'auto', int(np.median(tot))))
-        for nm, a, b in [('start -> phase A done', 0, 2), ('reduce q/minmax', 2, 3), ('median + chi2 pass', 3, 4), ('finish', 4, 7)]:
-            v = o[:, b] - o[:, a]
-            print('  {:24s} median {:8d} cycles  ({:5.1f} %)'.format(nm, int(np.median(v)), 100 * np.median(v) / np.median(tot)))
-        med = np.zeros((n, 8), dtype=np.uint64)
-        fm = eng.ctx.lib.msx_diag_read_med_stamps
-        fm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
-        fm.restype = C.c_int
-        assert fm(eng.ctx.h, n, med.ctypes.data) == 0
-        dm = np.diff(med[:, :5].astype(np.int64), axis=1)
-        for i, nm in enumerate(['(entry)', 'bin scan', 'chi2+gather pass+barrier', 'rank']):
-            print('    median/{:24s} median {:8d} cycles'.format(nm, int(np.median(dm[:, i]))))
-        print('  first start -> last end: {} cycles'.format(int(o[:, 7].max() - o[:, 0].min())))
-        return
     if args.path == 'linked' and os.environ.get('MSX_STAMPS_PRODUCERS'):  # library built with -DMSX_STAMPS=2
         o = out.astype(np.int64)
         order = [0, 1, 2, 3, 4, 7]

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Batch-size x workgroup-size x path (fused / split) sweep of the hot path: device time per batch from HIP events
-on the launch stream.  `--graph` replays each batch from a hipGraph (no host launch gaps between the split path's
-launches)."""
+"""Batch-size x workgroup-size x path (fused / linked) sweep of the hot path: device time per batch from HIP events
+on the launch stream.  `--graph` replays each batch from a hipGraph (no host launch gaps)."""
 import argparse
 import json
 import os
@@ -19,7 +18,7 @@ def main():
     ap.add_argument('--walkers', default='128,256,512,1024,2048,4096,16384')
     ap.add_argument('--blocks', default='256,512,1024')
     ap.add_argument('--iters', type=int, default=50)
-    ap.add_argument('--paths', default='fused,split')
+    ap.add_argument('--paths', default='fused')
     ap.add_argument('--graph', action='store_true')
     ap.add_argument('--spread', action='store_true', help='walkers uniform over the whole Teff range: every walker its own grid rows')
     args = ap.parse_args()
@@ -41,7 +40,7 @@ def main():
         lp = torch.empty(n, dtype=torch.float64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
         for path in args.paths.split(','):
-          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'split': _lib.PATH_SPLIT, 'wide': _lib.PATH_WIDE, 'linked': _lib.PATH_LINKED}[path])
+          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'linked': _lib.PATH_LINKED}[path])
           for B in [int(x) for x in args.blocks.split(',')]:
             def go(sp):
                 eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), sp, _lib.MODE_LOGPOST, B)
