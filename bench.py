@@ -454,44 +454,50 @@ def main():
             cur = ra.elapsed_time(rb)
             stable = stable + 1 if (prev is not None and abs(cur - prev) <= 0.007 * prev) else 0
             prev = cur
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
     gev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
-    t0 = time.perf_counter()
-    first_eager = 0
-    gev = []
-    if graph is not None:
-        for i in range(head):
+
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize on both sides; returns (seconds, graph-replay event pairs)."""
+        nonlocal nev
+        drain()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        first_eager = 0
+        gev_ = []
+        if graph is not None:
+            for i in range(head):
+                reuse_guard(i)
+                launch(i)
+            for _ in range((args.steps - head) // chunk):
+                if not use_gather:  # kernels only in the graph: a replay's elapsed time / chunk is the kernel time
+                    gev_.append(gev_pool[len(gev_)] if len(gev_) < len(gev_pool) else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                    gev_[-1][0].record(stream)
+                graph.replay()
+                if not use_gather:
+                    gev_[-1][1].record(stream)
+            first_eager = head + (args.steps - head) // chunk * chunk
+            nev = 0  # (N > 1: kernel timed separately below)
+        for i in range(first_eager, args.steps):
             reuse_guard(i)
+            g, k = divmod(i, ev_run)
+            if k == 0 and g < nev:
+                ev[g][0].record(stream)
             launch(i)
-        for _ in range((args.steps - head) // chunk):
-            if not use_gather:  # kernels only in the graph: a replay's elapsed time / chunk is the kernel time
-                gev.append(gev_pool[len(gev)] if len(gev) < len(gev_pool) else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-                gev[-1][0].record(stream)
-            graph.replay()
-            if not use_gather:
-                gev[-1][1].record(stream)
-        first_eager = head + (args.steps - head) // chunk * chunk
-        nev = 0  # (N > 1: kernel timed separately below)
-    for i in range(first_eager, args.steps):
-        reuse_guard(i)
-        g, k = divmod(i, ev_run)
-        if k == 0 and g < nev:
-            ev[g][0].record(stream)
-        launch(i)
-        if use_gather:
-            gather(i)
-        if k == ev_run - 1 and g < nev:
-            ev[g][1].record(stream)
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+            if use_gather:
+                gather(i)
+            if k == ev_run - 1 and g < nev:
+                ev[g][1].record(stream)
+        drain()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, gev_
+
+    dt, gev = timed_region()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -521,6 +527,45 @@ def main():
         kern_ms = e0.elapsed_time(e1) / ev_run
         kern_samples = ev_run
     bad = int((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item())
+    # ---- beside the headline: the SAME K steps without the device warm-up --------------------------------------
+    # (N = 1 only.)  The GPU is left idle for a second, the W warm-up steps are repeated and the timed region runs
+    # again, with no untimed launches in between: what a caller gets who evaluates one short burst now and then.
+    unramped = None
+    if world == 1 and not use_gather and os.environ.get('MSX_BENCH_NO_COLD') != '1':
+        time.sleep(1.0)
+        for i in range(args.warmup):
+            launch(i)
+        dt_cold, _ = timed_region()
+        unramped = {'ms_per_step': dt_cold / args.steps * 1e3, 'value': n * world * args.steps / dt_cold,
+                    'note': 'same {} steps after 1 s of idle + the {} warm-up steps, no untimed launches before the '
+                            'timed region'.format(args.steps, args.warmup)}
+    # ---- N > 1: where a step's time goes (an untimed, eager pass after the timed region) ------------------------
+    diag = None
+    if use_gather:
+        nd_ = 64
+        t_launch = t_gather = t_wait = 0.0
+        torch.cuda.synchronize(dev)
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d0.record(stream)
+        for i in range(nd_):
+            a = time.perf_counter()
+            reuse_guard(i)
+            b = time.perf_counter()
+            launch(i)
+            c_ = time.perf_counter()
+            gather(i)
+            d_ = time.perf_counter()
+            t_wait += b - a
+            t_launch += c_ - b
+            t_gather += d_ - c_
+        drain()
+        d1.record(stream)
+        torch.cuda.synchronize(dev)
+        diag = {'steps': nd_, 'host_us_per_step': {'wait_for_buffer': t_wait / nd_ * 1e6, 'kernel_issue': t_launch / nd_ * 1e6,
+                                                   'collective_issue': t_gather / nd_ * 1e6},
+                'stream_us_per_step_eager': d0.elapsed_time(d1) / nd_ * 1e3, 'kernel_alone_us': kern_ms * 1e3,
+                'note': 'eager loop (kernel -> all-gather, double-buffered), this rank; the timed region itself ran as: '
+                        + ('hipGraph replay' if graph is not None else 'eager loop')}
 
     if rank == 0:
         kern_s = kern_ms * 1e-3
@@ -629,6 +674,10 @@ def main():
             'roofline': roofline,
             'walker_error_statuses': bad, 'gather_verified': gather_ok,
         }
+        if unramped is not None:
+            out['unramped'] = unramped
+        if diag is not None:
+            out['multi_gpu_diag'] = diag
         out['cpu_baseline'] = None
         extra = {}
         if want_cpu:

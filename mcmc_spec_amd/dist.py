@@ -2,7 +2,8 @@
 
 Walkers are independent (no cross-walker term anywhere in mft6.py:1139-1205), so rank r evaluates the
 contiguous block ``[r*m, (r+1)*m)`` of the ``(n, ndim)`` coordinate array with ``m = ceil(n / G)`` and the
-log-probabilities are combined by ONE collective: ``all_gather_into_tensor`` of ``m`` float64 per rank
+log-probabilities -- and any rank-local failure, as a NaN payload -- are combined by ONE collective:
+``all_gather_into_tensor`` of ``m`` float64 per rank
 (backend ``nccl`` = RCCL over xGMI on the GPU box; ``gloo`` in the CPU tests).  The ragged tail is padded
 with copies of the last walker so no sentinel reaches the kernel; the pad is dropped after the gather.
 The staged grid/tables are replicated on every GPU.  Every rank must call with the same ``coords``
@@ -17,6 +18,21 @@ import numpy as np
 
 
 _ERR_CODES = [KeyError, IndexError, ValueError]   # the reference's conventions, in status order
+
+
+_QNAN = 0x7ff8000000000000
+
+
+def _nan_with_code(code):
+    """A quiet NaN whose low mantissa byte carries ``code`` (1..255), like the kernel's nan_with_status."""
+    return np.array([_QNAN | (int(code) & 0xff)], dtype=np.uint64).view(np.float64)[0]
+
+
+def _codes_of(v):
+    """Per element: the code a `_nan_with_code` NaN carries, 0 for anything else (numbers, -inf, a plain NaN)."""
+    b = np.ascontiguousarray(v, dtype=np.float64).view(np.uint64)
+    tagged = (b & np.uint64(0xfff8000000000000)) == np.uint64(_QNAN)
+    return np.where(tagged, (b & np.uint64(0xff)).astype(np.int64), 0)
 
 
 def shard_bounds(n, world, rank):
@@ -57,8 +73,10 @@ class ShardedLogProb:
             block = np.concatenate([block, pad], axis=0)
         # The local evaluator follows the reference's error conventions: it may RAISE (KeyError for a missing grid
         # node, IndexError, ValueError -- data-dependent, so possibly on one rank only).  A rank that raised before
-        # the collective would leave the others blocked in it, so the exception is held back, every rank learns the
-        # worst outcome through the same collective sequence, and then every rank raises the same exception.
+        # the collective would leave the others blocked in it, so the exception is held back and its class travels
+        # INSIDE the one collective there is, as the payload of the quiet NaN that fills the failing rank's block --
+        # the convention of the device path (csrc/logprob_kernel.h, nan_with_status) -- and every rank then raises
+        # the same exception.  (A log-probability is never NaN by itself: the engine returns -inf.)
         err, local = None, None
         try:
             local = np.asarray(self.local_eval(block, *args, **kwargs), dtype=float)
@@ -66,15 +84,13 @@ class ShardedLogProb:
                 raise ValueError('local_eval returned shape {} for a block of {} walkers'.format(local.shape, m))
         except Exception as exc:  # noqa: BLE001 - re-raised below, on every rank
             err = exc
-            local = np.full(m, np.nan)
-        code = 0 if err is None else (_ERR_CODES.index(type(err)) + 1 if type(err) in _ERR_CODES else len(_ERR_CODES) + 1)
-        flag = torch.tensor([code, self.rank if code else -1], dtype=torch.int64, device=self.device)
-        flags = torch.empty(2 * self.world, dtype=torch.int64, device=self.device)
-        self.dist.all_gather_into_tensor(flags, flag, group=self.group)
+            code = _ERR_CODES.index(type(err)) + 1 if type(err) in _ERR_CODES else len(_ERR_CODES) + 1
+            local = np.full(m, _nan_with_code(code))
         send = torch.from_numpy(np.ascontiguousarray(local)).to(self.device)
         recv = torch.empty(m * self.world, dtype=torch.float64, device=self.device)
-        self.dist.all_gather_into_tensor(recv, send, group=self.group)
-        codes = flags.cpu().numpy().reshape(self.world, 2)[:, 0]
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)   # the ONE collective of the evaluation
+        out = recv.cpu().numpy()
+        codes = _codes_of(out).reshape(self.world, m).max(axis=1)
         if codes.any():
             first = int(np.nonzero(codes)[0][0])           # the lowest failing rank decides, on every rank
             if first == self.rank:
@@ -82,7 +98,6 @@ class ShardedLogProb:
             c = int(codes[first])
             cls = _ERR_CODES[c - 1] if c <= len(_ERR_CODES) else RuntimeError
             raise cls('walker evaluation failed on rank {} ({}); raised on every rank'.format(first, cls.__name__))
-        out = recv.cpu().numpy()
         # rank r's valid entries are the first (hi_r - lo_r) of its block
         parts = []
         for r in range(self.world):

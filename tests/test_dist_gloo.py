@@ -96,6 +96,14 @@ def _worker_errors(rank, world, port, q):
         return block.sum(axis=1)
 
     f = ShardedLogProb(local_eval, device='cpu')
+    ncoll = [0]
+    real_gather = dist.all_gather_into_tensor
+
+    def counting_gather(*a, **k):
+        ncoll[0] += 1
+        return real_gather(*a, **k)
+
+    f.dist = type('D', (), {'all_gather_into_tensor': staticmethod(counting_gather)})()
     coords = np.arange(24, dtype=float).reshape(8, 3)
     log.append(('ok', f(coords).tolist()))
     bad = coords.copy()
@@ -106,6 +114,7 @@ def _worker_errors(rank, world, port, q):
     except KeyError as e:
         log.append(('KeyError', 'rank 1' in str(e) or rank == 1))
     log.append(('after', f(coords).tolist()))      # the group is still usable: nobody is stuck in a collective
+    log.append(('collectives', ncoll[0]))          # ONE per evaluation, failing or not: the error class rides in the NaN
 
     # (2) bench.py's graph capture: rank 1 fails to capture; nobody may replay (a replay holds collectives)
     replays = []
@@ -154,8 +163,9 @@ def test_world2_one_rank_failing_does_not_deadlock_the_other():
         assert log[0] == ('ok', want)
         assert log[1] == ('KeyError', True)            # same exception class on both ranks
         assert log[2] == ('after', want)
-        assert log[3] == ('capture', None, 0)          # nobody replayed
-        assert log[4] == ('capture2', 'graph', 1)
+        assert log[3] == ('collectives', 3)
+        assert log[4] == ('capture', None, 0)          # nobody replayed
+        assert log[5] == ('capture2', 'graph', 1)
 
 
 def _worker_chain(rank, world, port, q):
