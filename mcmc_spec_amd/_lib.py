@@ -19,8 +19,8 @@ MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
 W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR, W_HANDOVER = 0, 1, 2, 3, 4, 5
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
-PATH_AUTO, PATH_FUSED, PATH_LINKED = 0, 1, 4  # include/msx.h MSX_PATH_*
-HOOK_LINKED_FAULT = 1  # include/msx.h MSX_HOOK_*
+PATH_AUTO, PATH_FUSED, PATH_PAIR, PATH_LINKED = 0, 1, 2, 4  # include/msx.h MSX_PATH_*
+HOOK_LINKED_FAULT, HOOK_PAIR_THREADS = 1, 2  # include/msx.h MSX_HOOK_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)
@@ -116,6 +116,7 @@ def load():
         'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
         'msx_bytes_per_eval': (C.c_int, [vp, C.c_int64, _ip]),
         'msx_test_hook': (C.c_int, [vp, C.c_int32, C.c_int32]),
+        'msx_pair_stats': (C.c_int, [vp, _ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library skew, fail loudly
@@ -131,7 +132,7 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_logprob_batch_dev', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
-            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook']
+            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook', 'msx_pair_stats']
 
 
 def as_f64(a):
@@ -382,6 +383,12 @@ class Context:
         out = C.c_int64()
         self.check(self.lib.msx_bytes_per_eval(self.h, int(n), C.byref(out)))
         return out.value
+
+    def pair_stats(self):
+        """(pairs, singles) of the pair form's last launch (its planner's counts)."""
+        out = np.zeros(2, dtype=np.int64)
+        self.check(self.lib.msx_pair_stats(self.h, iptr(out)))
+        return int(out[0]), int(out[1])
 
     def test_hook(self, what, value):
         self.check(self.lib.msx_test_hook(self.h, int(what), int(value)))

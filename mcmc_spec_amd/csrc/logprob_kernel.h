@@ -13,6 +13,39 @@ __device__ __forceinline__ int status_of_nan(double v) {  // 0 for anything that
     return ((b & 0x7ff8000000000000ll) == 0x7ff8000000000000ll && (b >> 63) == 0) ? (int)(b & 0xff) : 0;
 }
 
+// ---- the walker's scalar arithmetic after the pixel loops, in ONE place: the fused kernel and the pair kernel
+// (pair_kernel.h) must give a walker the same bits, so both call these and nothing else ---------------------------
+// one pixel's contribution to the three fit sums of data / model against [1, u, u^2]      mft6.py:194-195
+__device__ __forceinline__ void fit_accumulate(double m, double flux, double u, double &q0, double &q1, double &q2) {
+    const double f = fast_div(flux, m);  // frac before the median scale, mft6.py:194
+    const double f1 = f * u, f2 = f * (u * u);
+    q0 += f; q1 += f1; q2 += f2;
+}
+// coefficients of the raw quadratic fit of data / model from the three fit sums (mft6.py:195; minv = inverse Gram matrix)
+__device__ __forceinline__ void fit_coefs(const DevProblem &P, const double (&q)[3], double &c0, double &c1, double &c2) {
+    c0 = P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2];
+    c1 = P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2];
+    c2 = P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2];
+}
+// one pixel's chi^2 term before the median's scale^2: (model - data / P(u))^2 / err^2      mft6.py:196,120
+__device__ __forceinline__ double chi_term(double c0, double c1, double c2, double u, double f, double e, double xv, bool live) {
+    const double poly = fma(fma(c2, u, c1), u, c0);
+    const double r = xv - fast_div(f, poly);
+    return live ? (r * r) * e : 0.0;
+}
+// the walker's value from its chi^2 sum (fused modes: before scale^2), the two medians and the recipe's scalars
+__device__ __forceinline__ double fused_total(const DevProblem &P, double chi_sum, double med_data, double med_model, int npix,
+                                              double chi_extra) {
+    const double scale = fast_div(med_data, med_model);  // mft6.py:1173
+    const double tot = chi_sum * (scale * scale);
+    const double iic = fast_div(tot, (double)npix);                // mft6.py:1179
+    return iic * (double)(P.nc + P.np) + chi_extra;                // mft6.py:1191
+}
+__device__ __forceinline__ double value_of_total(int mode, double total, double lp) {
+    if (mode == MSX_MODE_CHISQ) return total;                      // mft6.py:1198-1199
+    return isnan(total) ? -INFINITY : lp + (-0.5 * total);          // mft6.py:1202-1205, 1470
+}
+
 // Last lines of a walker (one lane): publish the value and, for the device-resident sampler, apply the
 // stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
 // like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
@@ -103,9 +136,7 @@ struct ChiElem {
         const double e[4] = {nv[SET][0].x, nv[SET][0].y, nv[SET][1].x, nv[SET][1].y};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double poly = fma(fma(c2, u[k], c1), u[k], c0);
-            const double r = xv[k] - fast_div(f[k], poly);  // (model - data/P); mft6.py:196,120 up to scale^2
-            acc[k & (VK - 1)] += p[k] < npix ? (r * r) * e[k] : 0.0;
+            acc[k & (VK - 1)] += chi_term(c0, c1, c2, u[k], f[k], e[k], xv[k], p[k] < npix);  // up to scale^2
         }
         // end of a segment of the canonical sum (8192 pixels), more pixels to come: fold it in.  (Uniform: every
         // thread of the workgroup walks the same trips.)
@@ -408,12 +439,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 // among the loop's loads makes every wait for a row a wait for everything in flight -- 28-30k cycles
                 // per segment instead of 21k)
                 model[pp[u]] = m;
-                const double f = fast_div(ff[u], m);  // frac before the median scale, mft6.py:194
-                const double f1 = f * uu[u], f2_ = f * (uu[u] * uu[u]);
                 constexpr int slot = sub * U;  // (+ u: both unrolled)
 #pragma unroll
                 for (int k = 0; k < vk; ++k)
-                    if (slot + u == k) { qa[k][0] += f; qa[k][1] += f1; qa[k][2] += f2_; }
+                    if (slot + u == k) fit_accumulate(m, ff[u], uu[u], qa[k][0], qa[k][1], qa[k][2]);
                 vmin = min_nc(vmin, m);
                 vmax = max_nc(vmax, m);
                 seen_nan = seen_nan || (m != m);
@@ -698,9 +727,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // so everything but the final scalar multiply is independent of the median and rides along the
     // median's first pass over the model vector (fused modes only; the optimiser modes keep phase C).
     const bool fused = !(mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT);
-    const double pc0 = P.minv[0] * q[0] + P.minv[1] * q[1] + P.minv[2] * q[2];
-    const double pc1 = P.minv[3] * q[0] + P.minv[4] * q[1] + P.minv[5] * q[2];
-    const double pc2 = P.minv[6] * q[0] + P.minv[7] * q[1] + P.minv[8] * q[2];
+    double pc0, pc1, pc2;
+    fit_coefs(P, q, pc0, pc1, pc2);
     constexpr bool kAhead = MAXT == 512 && !SH;
     ChiElem<MAXT, PF, false, kAhead> chi_elem{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, fused,
                                       &red[0][0][0], {}, {}, {}, 0.0};
@@ -793,7 +821,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // the chi^2 sum: wave 0 (whose lane 0 finishes the walker) combines the lanes' partials
     double tot = 0.0;
     if (wave == 0) tot = reduce_published<MAXT>(&red[0][0][0], lane);
-    if (fused) tot = (chi_elem.tot_run + tot) * (scale * scale);
+    // (fused modes: the median's scale^2 is applied in fused_total below; the optimiser modes' pass used the scaled model)
     if (opt_init) {
         dmin = S.kmin[0]; dmax = S.kmax[0];
         for (int x = 1; x < nw; ++x) {
@@ -808,12 +836,14 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     }
     if (late_side) __syncthreads();  // D.chi_extra, D.lp (waves 1 and 2)
     if (tid == 0) {
-        double iic = fast_div(tot, (double)npix);  // mft6.py:1179
-        if (opt_step || opt_init) iic = iic * 3;  // mft6.py:893,1015
-        const double total = iic * (double)(P.nc + P.np) + D.chi_extra;  // mft6.py:1191 / :904 / :1028
         double out;
-        if (mode == MSX_MODE_CHISQ || opt_step || opt_init) out = total;  // mft6.py:1198-1199
-        else out = isnan(total) ? -INFINITY : D.lp + (-0.5 * total);  // mft6.py:1202-1205, 1470
+        if (fused) {
+            const double total = fused_total(P, chi_elem.tot_run + tot, med_data, med_model, npix, D.chi_extra);
+            out = value_of_total(mode, total, D.lp);
+        } else {
+            const double iic = fast_div(tot, (double)npix) * 3;  // mft6.py:1179; :893,1015
+            out = iic * (double)(P.nc + P.np) + D.chi_extra;      // mft6.py:904 / :1028
+        }
         walker_done(P, D, wk, ndim, out, MSX_W_OK, logp, status);
         MSX_STAMP(P, wk, 15);
     }

@@ -361,22 +361,30 @@ __device__ __forceinline__ void hist_prefix_inplace(BlockScratch &S) {
     if (lane == kWave - 1) S.wave_tot[wave] = inc;
 }
 
-template <int BT, class Elem>
-__device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
-                                              BlockScratch &S, Elem &elem, double *med_out) {
-    constexpr int nw = BT >> 6;  // the workgroup size is a compile-time constant of every kernel variant
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
-    const bool need_two = (npix & 1) == 0;
+// The three pieces of logbin_median, separate so that the pair kernel (pair_kernel.h), whose model values sit in
+// registers, runs the same rank location and the same ranking around a pass of its own.
+struct LogbinSel {
+    unsigned int sel_p, nxt_p;  // PHYSICAL bins whose values are the candidates (nxt_p == sel_p: one bin)
+    unsigned int kk, cnt;       // ranks kk (and kk + 1 for even npix) among the cnt candidates are the middle values
+};
+// Can the early histogram locate the median, and where?  Every wave computes the answer for itself from the running
+// totals of hist_prefix_inplace (uniform result; no barrier).  false: not a positive vector spanning < 8 binades, or
+// more than kSelectFinish candidates -- the caller takes block_median.
+template <int BT>
+__device__ __forceinline__ bool logbin_applicable(unsigned long long kmin, unsigned long long kmax) {
     if (!(kmin > key_of(0.0)) || kmin == kmax) return false;
     const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
     const unsigned int hmax = (unsigned int)__double2hiint(val_of(kmax)) >> 12;
-    // the cycle of bins starts at min's bin; it must not lap itself
+    return hmax - hmin < (unsigned int)kLogBins;  // the cycle of bins starts at min's bin; it must not lap itself
+}
+template <int BT>
+__device__ __forceinline__ bool logbin_locate(int npix, unsigned long long kmin, const BlockScratch &S, LogbinSel *out) {
+    constexpr int nw = BT >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
+    const bool need_two = (npix & 1) == 0;
+    const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
     const unsigned int a = hmin & (unsigned int)(kLogBins - 1);
-    if (hmax - hmin >= (unsigned int)kLogBins) return false;
-    MED_STAMP(0);
-    MED_STAMP(1);
-    elem.prime();  // the pass's first loads travel while the rank is located
     // ---- locate rank k1 along the cycle from the running totals (hist_prefix_inplace) ---------------------------
     constexpr int PT = kLogBins / BT, blk = kWave * PT;  // counters per thread; bins per wave block
     unsigned int woff[nw + 1];  // values before wave block w
@@ -444,25 +452,20 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
             }
         }
     }
-    if (cnt > (unsigned int)kSelectFinish) return false;  // heavy duplication: the general path sorts it out
-    MED_STAMP(2);
-    // ---- one pass: chi^2 terms + the candidates (the values of the one or two bins above) ----------------------
-    pass_trips<BT>(model, npix, elem, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned int pb = logbin(xv[u]);
-            if (p[u] < npix && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
-        }
-    });
-    elem.flush(S);
-    __syncthreads();
-    MED_STAMP(3);
-    // ---- rank.  Up to 64 candidates (the usual case): wave 0 alone, in registers, and only wave 0 (whose lane 0
-    // finishes the walker) learns the median -- no further barrier.  More: the first waves through LDS.
+    out->sel_p = sel_p; out->nxt_p = nxt_p; out->kk = kk; out->cnt = cnt;
+    return cnt <= (unsigned int)kSelectFinish;  // (more: heavy duplication, the general path sorts it out)
+}
+// Rank the gathered candidates (S.cand[0 .. cnt), complete: a barrier has passed).  Up to 64 candidates (the usual
+// case): wave `rank_wave` alone, in registers, and only that wave learns the median -- no further barrier.  More: the
+// first waves through LDS, one barrier, every thread learns it.  All threads of the workgroup call it.
+template <int BT>
+__device__ __forceinline__ double logbin_rank(BlockScratch &S, const LogbinSel &Q, bool need_two, int rank_wave) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned int cnt = Q.cnt, kk = Q.kk;
     unsigned long long v1 = 0, v2 = 0;
     bool second = false;
     if (cnt <= (unsigned int)kWave) {
-        if (wave == 0) {
+        if (wave == rank_wave) {
             // one candidate per lane; the others arrive as LDS broadcast reads, eight per trip.  Counting the keys
             // below and not above a candidate pins its VALUE's rank interval [lt, le), which is all the median needs
             // (duplicates share a value), so no tie-break by slot.  Pad slots hold ~0 and rank last.
@@ -502,12 +505,38 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
         second = S.has_second != 0;
         if (second) v2 = S.sel_result[1];
     }
+    (void)second;  // (even npix: rank kk + 1 is among the candidates by construction)
+    return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+}
+
+template <int BT, class Elem>
+__device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
+                                              BlockScratch &S, Elem &elem, double *med_out) {
+    const bool need_two = (npix & 1) == 0;
+    if (!logbin_applicable<BT>(kmin, kmax)) return false;
+    MED_STAMP(0);
+    MED_STAMP(1);
+    elem.prime();  // the pass's first loads travel while the rank is located
+    LogbinSel Q;
+    if (!logbin_locate<BT>(npix, kmin, S, &Q)) return false;
+    const unsigned int sel_p = Q.sel_p, nxt_p = Q.nxt_p;
+    MED_STAMP(2);
+    // ---- one pass: chi^2 terms + the candidates (the values of the one or two bins above) ----------------------
+    pass_trips<BT>(model, npix, elem, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int pb = logbin(xv[u]);
+            if (p[u] < npix && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
+        }
+    });
+    elem.flush(S);
+    __syncthreads();
+    MED_STAMP(3);
+    *med_out = logbin_rank<BT>(S, Q, need_two, 0);
     MED_STAMP(4);
 #ifdef MSX_STAMPS
-    if (tid == 0) g_med_stamps[blockIdx.x * 8 + 6] = cnt;
+    if (threadIdx.x == 0) g_med_stamps[blockIdx.x * 8 + 6] = Q.cnt;
 #endif
-    (void)second;  // (even npix: rank kk + 1 is among the candidates by construction)
-    *med_out = need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
     return true;
 }
 

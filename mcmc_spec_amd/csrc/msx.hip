@@ -20,6 +20,7 @@
 //   recipe.h           phase 0: gates, isochrone, brackets, weights, prior and band terms
 //   median.h           exact median selects (block_median, logbin_median, radix fallback)
 //   logprob_kernel.h   the hot kernel and its variants (fused; linked = several workgroups per walker in one launch)
+//   pair_kernel.h      the pair form: two walkers of one grid cell per workgroup, one set of row loads
 //   staging_kernels.h  CCM89, pair gather, band integrals, broadening, resample, composite, stream copy
 //   msx.hip            host context + the C ABI of include/msx.h
 //
@@ -55,6 +56,7 @@
 #include "recipe.h"
 #include "median.h"
 #include "logprob_kernel.h"
+#include "pair_kernel.h"
 #include "staging_kernels.h"
 
 // ================================================================================================
@@ -115,7 +117,14 @@ struct msx_ctx {
     int32_t *d_seg_flag = nullptr;  // linked form: [scratch_rows] producers arrived (zero between launches), + the poison word
     int nseg = 1;                   // segments of the staged spectrum (8192 pixels each)
     int64_t scratch_rows = 0;       // 0 = neither form applies: launches are never cut into sub-batches
-    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _LINKED (msx_set_path)
+    int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _PAIR / _LINKED (msx_set_path)
+    // pair form (pair_kernel.h): binaries of <= 4096 pixels with the register-resident recipe
+    int64_t pair_rows = 0;          // scratch rows for its rare spill path = walkers per sub-batch (0: no pair form here)
+    int32_t pair_threads = 256;     // MSX_PAIR_THREADS: 256 (two workgroups per CU, 256 VGPRs) or 512 (two per CU, 128 VGPRs)
+    int64_t pair_min_walkers = INT64_MAX;  // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN)
+    int32_t *d_pair_plan = nullptr; // the planner's output (pair_kernel.h: header, pairs, singles)
+    unsigned long long *d_pair_slots = nullptr;  // ... and its list of leftover cards
+    bool pair_noplan = false;       // MSX_PAIR_NOPLAN=1: pair neighbours in the batch, no planner (experiments)
     int32_t linked = -1;            // MSX_LINKED: -1 = automatic (walkers x segments <= #CUs / 2), 0 never, 1 whenever possible
     bool linked_poisoned = false;   // a hand-over of the linked form timed out on this context (seen by a synchronous
                                     // entry point): MSX_PATH_AUTO takes the fused form until the problem is staged again
@@ -197,10 +206,11 @@ void free_problem(msx_ctx *c) {
     if (c->d_opt_med) (void)hipFree(c->d_opt_med);
     c->d_opt_flux = c->d_opt_med = nullptr;
     c->opt_chains = 0;
-    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag};
+    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_slots};
     for (void *p : sp)
         if (p) (void)hipFree(p);
     c->d_segparts = nullptr; c->d_seg_flag = nullptr; c->d_model_scratch = nullptr; c->scratch_rows = 0;
+    c->d_pair_plan = nullptr; c->d_pair_slots = nullptr; c->pair_rows = 0;
     c->linked_poisoned = false;
 }
 
@@ -357,6 +367,35 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     }
 #undef MSX_GO
 #undef MSX_LEAD_ARGS
+    HIP_TRY(c, hipGetLastError());
+    return MSX_OK;
+}
+
+// The pair form over A.n walkers (pair_kernel.h): the variant compiled for the smallest trip count that covers the
+// spectrum (256 threads: 3 / 4 / 8 element trips per lane = up to 1536 / 2048 / 4096 pixels; 512 threads: 2 / 4).
+int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
+    // 1. who shares a workgroup (MSX_PAIR_NOPLAN=1: neighbours in the batch, no planner -- experiments)
+    const int32_t *plan = c->pair_noplan ? nullptr : c->d_pair_plan;
+    if (plan) {
+        hipLaunchKernelGGL(pair_plan_kernel, dim3((unsigned)((A.n + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, A.s, A.theta,
+                           (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax,
+                           c->d_pair_plan, c->pair_rows, c->d_pair_slots);
+        HIP_TRY(c, hipGetLastError());
+    }
+    // 2. the planner's items: singles + pairs <= n (workgroups beyond the planner's count leave at once -- measured free)
+    const dim3 g((unsigned)std::max<int64_t>(1, plan ? A.n : (A.n + 1) / 2));
+    const int64_t ne = P.npair;
+#define MSX_PAIR_GO2(T_, NT_, RED_)                                                                                   \
+    hipLaunchKernelGGL((logprob_pair_kernel<T_, NT_, RED_>), g, dim3(T_), 0, A.s, A.theta, (const unsigned char *)c->d_recipe_block, \
+                       A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status, c->pair_rows)
+#define MSX_PAIR_GO(T_, NT_) do { if (P.use_av) MSX_PAIR_GO2(T_, NT_, true); else MSX_PAIR_GO2(T_, NT_, false); } while (0)
+    if (c->pair_threads == 512) {
+        if (ne <= 2 * 512) MSX_PAIR_GO(512, 2); else MSX_PAIR_GO(512, 4);
+    } else {
+        if (ne <= 3 * 256) MSX_PAIR_GO(256, 3); else if (ne <= 4 * 256) MSX_PAIR_GO(256, 4); else MSX_PAIR_GO(256, 8);
+    }
+#undef MSX_PAIR_GO
+#undef MSX_PAIR_GO2
     HIP_TRY(c, hipGetLastError());
     return MSX_OK;
 }
@@ -780,6 +819,22 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         }
     }
     c->linked_poisoned = false;
+    // the pair form: binaries of <= 4096 pixels (model values in registers), register-resident recipe.  Its spill path
+    // (vectors the early histogram cannot handle) wants one scratch row per walker of a sub-batch.
+    if (p->nspec == 2 && p->npix <= kPairMaxPix && c->recipe_fast && !p->no_spectrum) {
+        int64_t rows = 16384;
+        if (const char *e = getenv("MSX_PAIR_ROWS")) rows = std::max<int64_t>(2, atoll(e));
+        HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * rows * p->npix));
+        P.model_scratch = c->d_model_scratch;
+        const size_t plan_bytes = sizeof(int32_t) * (size_t)(kPairHdrInts + 3 * rows);
+        HIP_TRY(c, hipMalloc((void **)&c->d_pair_plan, plan_bytes));
+        HIP_TRY(c, hipMemset(c->d_pair_plan, 0, plan_bytes));
+        HIP_TRY(c, hipMalloc((void **)&c->d_pair_slots, sizeof(unsigned long long) * (size_t)rows));  // leftover cards
+        c->pair_rows = rows;
+        if (const char *e = getenv("MSX_PAIR_NOPLAN")) c->pair_noplan = e[0] == '1';
+        if (const char *e = getenv("MSX_PAIR_THREADS")) c->pair_threads = atoi(e) == 512 ? 512 : 256;
+        if (const char *e = getenv("MSX_PAIR_MIN")) c->pair_min_walkers = std::max<int64_t>(2, atoll(e));
+    }
 #ifdef MSX_STAMPS
     {   // diagnostic build only: per-walker shader-clock stamps
         unsigned long long *st = nullptr;
@@ -808,8 +863,8 @@ int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
 #endif
 
 int msx_set_path(msx_ctx *c, int32_t path) {
-    if (!c || (path != MSX_PATH_AUTO && path != MSX_PATH_FUSED && path != MSX_PATH_LINKED))
-        return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path (MSX_PATH_AUTO, _FUSED or _LINKED)");
+    if (!c || (path != MSX_PATH_AUTO && path != MSX_PATH_FUSED && path != MSX_PATH_LINKED && path != MSX_PATH_PAIR))
+        return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path (MSX_PATH_AUTO, _FUSED, _PAIR or _LINKED)");
     c->path = path;
     return MSX_OK;
 }
@@ -862,15 +917,28 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
             return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): a hand-over timed out on this context (MSX_W_HANDOVER); stage the problem again");
         linked = true;
     }
+    // pair (pair_kernel.h): many walkers -- two walkers of one grid cell per workgroup share one set of row loads
+    const bool can_pair = c->pair_rows > 0 && fast && !Pc.smp_on && Pc.nspec == 2 &&
+                          (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
+    bool pair = can_pair && n >= c->pair_min_walkers;
+    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_LINKED) pair = false;
+    if (c->path == MSX_PATH_PAIR) {
+        if (!can_pair) return fail(c, MSX_ERR_STATE, "msx_set_path(PAIR): needs a binary of <= 4096 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
+        pair = true;
+    }
     // sub-batches: the linked form's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
-    // hold scratch_rows walkers
-    const int64_t step = (linked || c->model_in_global) ? c->scratch_rows : n;
+    // hold scratch_rows walkers; the pair form's spill rows pair_rows
+    const int64_t step = pair ? c->pair_rows : (linked || c->model_in_global) ? c->scratch_rows : n;
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min<int64_t>(step, n - off);
         A.theta = d_theta + off * ndim; A.logp = d_logp + off; A.status = d_status + off; A.n = m;
         const DevProblem P = problem_at(Pc, off, mode, ndim);
         const int B = block_threads > 0 ? block_threads : pick_block(c, m, Pc.npix);
         int rc;
+        if (pair) {
+            if ((rc = launch_pair(c, P, A))) return rc;
+            continue;
+        }
         if (linked) {
             LaunchArgs A5 = A;
             A5.ng_mode_fast |= c->nseg << 24;
@@ -1530,11 +1598,28 @@ int msx_bytes_per_eval(msx_ctx *c, int64_t n, int64_t *requested_bytes) {
     return MSX_OK;
 }
 
+int msx_pair_stats(msx_ctx *c, int64_t *out2) {
+    if (!c || !out2) return MSX_ERR_INVALID;
+    if (!c->d_pair_plan) return fail(c, MSX_ERR_STATE, "msx_pair_stats: the staged problem has no pair form");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    int32_t h[2];
+    HIP_TRY(c, hipMemcpy(h, c->d_pair_plan, sizeof(h), hipMemcpyDeviceToHost));
+    out2[0] = h[0];
+    out2[1] = h[1];
+    return MSX_OK;
+}
+
 int msx_test_hook(msx_ctx *c, int32_t what, int32_t value) {
     if (!c) return MSX_ERR_INVALID;
     if (what == MSX_HOOK_LINKED_FAULT) {
         if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_test_hook: no problem staged");
         c->P.linked_fault = value != 0;
+        return MSX_OK;
+    }
+    if (what == MSX_HOOK_PAIR_THREADS) {
+        if (value != 256 && value != 512) return fail(c, MSX_ERR_INVALID, "msx_test_hook: pair threads are 256 or 512");
+        c->pair_threads = value;
         return MSX_OK;
     }
     return fail(c, MSX_ERR_INVALID, "msx_test_hook: unknown hook");

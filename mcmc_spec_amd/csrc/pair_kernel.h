@@ -1,0 +1,603 @@
+// pair_kernel.h -- part of the single translation unit msx.hip (included there, after logprob_kernel.h).
+// The PAIR form of the hot kernel: one workgroup evaluates TWO walkers of the same grid cell from ONE set of loads.
+//
+// Why.  With more than one walker per CU the fused kernel is bound by what a CU can pull through its L2 port (the
+// launch requests ~600 KB per walker) and every workgroup pulls the same few grid rows again: an MCMC
+// ensemble sits in a handful of grid cells.  Walkers of one cell read the SAME eight rows (the canonical corner
+// order, blend.h, makes the row list a function of the cell alone) and the same per-pixel statics; only their
+// weights differ.  Here a lane loads a table element once and runs two weight chains on it: row, static and chi^2-pass
+// requests per walker are halved.  Rows are not shared implicitly -- same-cell walkers run in lock-step in separate
+// workgroups get no L1 hits (measured) -- so the sharing has to be through registers.
+//
+// How it keeps a CU busy.  Two model vectors of 32 KB do not leave room in LDS for the two or three workgroups a CU
+// needs to overlap one workgroup's memory phase with another's latency chain.  But a lane only ever re-reads, in the
+// median's pass, the pixels it computed itself in phase A (phase A's element walk and pass_pixel() assign the same
+// pixels to a lane, for 256 and for 512 threads) -- so the model values stay in REGISTERS (npix / MAXT doubles per
+// lane and walker, spectra of up to 4096 pixels) and LDS holds only the walkers' small state.  The paths that need the
+// vector in memory (block_median: vectors the early histogram cannot handle) spill it to the walker's row of the
+// global scratch first; they are rare.
+//
+// Same bits.  Every per-walker operation is the fused kernel's own: the recipe (recipe.h), blend_accumulate /
+// blend_finish (blend.h), fit_accumulate, the canonical sum (wave_ops.h), logbin_locate / logbin_rank / block_median
+// (median.h), chi_term / fit_coefs / fused_total (logprob_kernel.h).  A walker's value does not depend on its partner,
+// nor on whether it was paired at all (tests/test_gpu_pair.py).
+//
+// Who is paired: pair_plan_kernel (below) groups the batch by grid cell and emits pairs {walker, partner} and singles;
+// walkers whose recipes turn out to differ after all (or whose partner fails) are evaluated one after the other by
+// the same workgroup.
+#ifndef MSX_PAIR_KERNEL_H
+#define MSX_PAIR_KERNEL_H
+// MSX_PAIR_EXP (measurement builds only, WRONG VALUES): bit 0 skips the fit sweep, bit 1 the chi^2 / candidates
+// sweep, bit 2 the reddening factor, bit 3 the histogram's atomics -- where a pair workgroup's time goes
+#ifndef MSX_PAIR_EXP
+#define MSX_PAIR_EXP 0
+#endif
+
+namespace {
+
+constexpr int kPairMaxPix = 4096;   // model values in registers: kPairMaxPix / MAXT doubles per lane and walker
+// The plan (pair_plan_kernel): int32 plan[kPairHdrInts + 3 cap]
+//   [0] pairs, [1] singles (final counts, read by the consumers); [2], [3] the same while the planner runs, [4] its
+//   finished workgroups, [5] leftover cards (all four back at zero when it ends); pairs {a, b} from [kPairHdrInts],
+//   singles from [kPairHdrInts + 2 cap]
+constexpr int kPairHdrInts = 8;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// NT = element trips per lane the variant is compiled for: the launcher takes the smallest one that covers the
+// spectrum (ceil(elements / MAXT) <= NT); lanes beyond the tables are predicated off.  A compile-time trip count
+// keeps the unrolled sweeps free of branches -- and of the register copies their merge points cost.
+// RED = the problem fits extinction (use_av): the sweep loads the H rows and the extinction curve; a walker at
+// A_V = 0 exactly still takes the unreddened value (blend_finish), it only pays for the loads.
+template <int MAXT, int NT, bool RED>
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 2 : 4)
+logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
+                    double gate_tmin, double gate_tmax, const int32_t *__restrict__ plan, DevProblem P,
+                    double *__restrict__ logp, int32_t *__restrict__ status, int64_t plan_cap) {
+    // (the leading 14 dwords arrive preloaded in SGPRs, as in logprob_kernel)
+    constexpr int NS = 2, ndim = 6, NC = 8, B = MAXT, nw = B >> 6;
+    static_assert(NT * MAXT * 2 <= kPairMaxPix, "model values per lane");
+    constexpr int vk = kMaxWaves / nw;          // canonical-sum slots per lane: 4 or 2
+    constexpr int G = MAXT == 256 ? NC : 4;     // corners per group of loads (512 threads: <= 128 VGPRs, a star at a time)
+    static_assert(MAXT == 256 || MAXT == 512, "256 or 512 threads");
+    const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
+    __shared__ WalkerDesc D[2];
+    __shared__ BlockScratch S[2];
+    __shared__ double red[2][3][nw][kWave];
+    __shared__ double e2tab[kExp2Tab];
+    const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
+    const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
+    RecipeRegs RR;
+    if (wave0 < 2 * NS) load_recipe_regs(RR, rblk, niso, nt, ng, lane0);
+    // ---- this workgroup's item ---------------------------------------------------------------------------------
+    int64_t wkv[2];
+    if (plan) {  // the planner's items: its singles first, then its pairs
+        const int2 cnt = *reinterpret_cast<const int2 *>(plan);  // {pairs, singles}
+        const int nsingle = cnt.y, b = (int)blockIdx.x - nsingle;
+        if (b >= cnt.x) return;
+        if (b < 0) {
+            wkv[0] = plan[kPairHdrInts + 2 * plan_cap + blockIdx.x];
+            wkv[1] = -1;
+        } else {
+            const int2 it = reinterpret_cast<const int2 *>(plan + kPairHdrInts)[b];
+            wkv[0] = it.x;
+            wkv[1] = it.y;
+        }
+    } else {  // no plan: neighbours in the batch
+        wkv[0] = 2 * (int64_t)blockIdx.x;
+        wkv[1] = wkv[0] + 1 < n ? wkv[0] + 1 : -1;
+        if (wkv[0] >= n) return;
+    }
+    const int npix = (int)P.npix;
+    const int ne = (int)P.npair;  // table elements, a multiple of 256; <= kPairMaxPix / 2 (checked by the host)
+
+    // ---- phase 0: the two recipes, one wave0 per (walker, star) ---------------------------------------------------
+    const int rslot = wave0 >> 1, rstar = wave0 & 1;
+    const int64_t rwk = wave0 < 2 * NS ? wkv[rslot] : -1;
+    double theta_lane = 0.0;
+    if (rwk >= 0 && lane0 < ndim) theta_lane = theta[rwk * ndim + lane0];
+    fill_exp2_table(e2tab, tid0 - (B - kWave));
+    if (tid0 < 2) { D[tid0].stat[0] = MSX_W_OK; D[tid0].stat[1] = MSX_W_OK; }
+    __syncthreads();  // (the defaults above, before the recipe waves' own stores)
+    if (rwk >= 0) {
+        double tv[ndim];
+#pragma unroll
+        for (int k = 0; k < ndim; ++k) tv[k] = readlane_f64(theta_lane, k);
+        recipe_part1_regs<NS>(P, gates, RR, niso, nt, ng, mode, theta_lane, tv, D[rslot], lane0, rwk, rstar);
+    }
+    __syncthreads();
+    int wst[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int w = D[s].stat[0];
+        w = (w == MSX_W_OK) ? D[s].stat[1] : w;                                                  // first star that failed ...
+        w = (w != MSX_W_REJECT && D[s].stat[1] == MSX_W_VALUEERROR) ? MSX_W_VALUEERROR : w;       // ... see logprob_kernel
+        wst[s] = wkv[s] < 0 ? -1 : w;
+        if (wst[s] > MSX_W_OK && tid0 == s * kWave) {  // rejected by the prior box, or an error status: final here
+            logp[wkv[s]] = (w > MSX_W_REJECT) ? nan_with_status(w) : -INFINITY;
+            status[wkv[s]] = w;
+        }
+    }
+    const bool act0 = wst[0] == MSX_W_OK, act1 = wst[1] == MSX_W_OK;
+    if (!act0 && !act1) return;
+    bool same = act0 && act1;
+    if (same) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) same = same && D[0].node[c] == D[1].node[c];
+    }
+    // {0, 1} together when both are live and read the same rows; else the live ones one after the other (below)
+    const bool need_two = (npix & 1) == 0;
+
+    // The evaluation proper, compiled twice: for two walkers (machinery slot 0 = walker sa, slot 1 = walker sb) and
+    // for one (the second slot's arithmetic, state and barriers' work compiled out).
+    auto body = [&](auto two_c, const int sa, const int sb) __attribute__((always_inline)) {
+        constexpr bool two = decltype(two_c)::value;
+        constexpr int NSLOT = two ? 2 : 1;
+        const int tid = tid0, lane = lane0, wave = wave0;
+        const int64_t wk0 = wkv[sa], wk1 = wkv[sb];
+        const WalkerDesc &Da = D[sa], &Db = D[sb];
+        for (int i = tid; i < kLogBins; i += B) { S[0].hist[i] = 0; if (two) S[1].hist[i] = 0; }
+        if (tid < 2) { S[tid].cand_n = 0; S[tid].has_second = 0; }
+        __syncthreads();
+
+        // ---- phase A: blend + redden + resample, two weight chains per loaded element ---------------------------
+        const double2 *rows_r[NC];
+        const float2 *rows_h[NC];
+        double wA[NC], wB[NC];
+        float wfA[NC], wfB[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(Da.node[c]) * ne;
+            rows_r[c] = P.r2 + off;
+            rows_h[c] = P.h2 + off;
+            wA[c] = uniform_f64(Da.w[c]);
+            wfA[c] = uniform_f32((float)wA[c]);
+            wB[c] = uniform_f64(Db.w[c]);
+            wfB[c] = uniform_f32((float)wB[c]);
+        }
+        const double redcA = uniform_f64(Da.redc), redcB = uniform_f64(Db.redc);
+        const bool reddenA = redcA != 0.0, reddenB = two && redcB != 0.0;
+        double2 m[2][NT];  // THE MODEL VECTORS: lane tid holds the pixels of elements tid + j B, j = 0 .. NT - 1
+        double qa[2][vk][3];
+        double vmin[2] = {INFINITY, INFINITY}, vmax[2] = {-INFINITY, -INFINITY};
+        bool seen_nan[2] = {false, false};
+        // what follows a pixel pair's model values (logprob_kernel's finish_elem, per walker)
+        auto finish_elem = [&](auto s_c, auto j_c, const double2 m2, const double2 f2, const double2 u2, const int ec,
+                               const bool live) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value, j = decltype(j_c)::value;
+            constexpr int kbase = MAXT == 256 ? 2 * (j & 1) : 0;
+            const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
+            const bool ok[2] = {live && pa < npix, live && pb < npix};
+            const double mm[2] = {m2.x, m2.y}, ff[2] = {f2.x, f2.y}, uu[2] = {u2.x, u2.y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (ok[u]) {
+                    fit_accumulate(mm[u], ff[u], uu[u], qa[s][kbase + u][0], qa[s][kbase + u][1], qa[s][kbase + u][2]);
+                    vmin[s] = min_nc(vmin[s], mm[u]);
+                    vmax[s] = max_nc(vmax[s], mm[u]);
+                    seen_nan[s] = seen_nan[s] || (mm[u] != mm[u]);
+                    if (!(MSX_PAIR_EXP & 8)) atomicAdd(&S[s].hist[logbin(mm[u])], 1u);
+                }
+            }
+        };
+        {
+            auto trip = [&](auto j_c) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_c)::value;
+                // (an opaque copy of the thread index per trip: the trip's offsets are formed HERE, not hoisted to the
+                // top of the unrolled sweep and parked in registers -- or spilled -- until the trip comes)
+                int tj = tid;
+                asm volatile("" : "+v"(tj));
+                const int e = j * B + tj;
+                const int ec = e < ne ? e : ne - 1;
+                const unsigned int o16 = (unsigned int)ec << 4, o8 = (unsigned int)ec << 3;
+                double2 kl2 = make_double2(0.0, 0.0);
+                float2 dk2 = make_float2(0.f, 0.f);
+                double sra[2] = {0.0, 0.0}, srb[2] = {0.0, 0.0};
+                float sha[2] = {0.f, 0.f}, shb[2] = {0.f, 0.f};
+#pragma unroll
+                for (int c0 = 0; c0 < NC; c0 += G) {
+                    double2 rr[G];
+                    float2 hh[G];
+#pragma unroll
+                    for (int c = 0; c < G; ++c) {
+                        rr[c] = ld_off(rows_r[c0 + c], o16);
+                        hh[c] = RED ? ld_off(rows_h[c0 + c], o8) : make_float2(0.f, 0.f);
+                    }
+                    if (c0 == 0 && RED) { kl2 = ld_off(P.kl2, o16); dk2 = ld_off(P.dk2, o8); }
+                    double ra[G], rb[G];
+                    float ha[G], hb[G];
+#pragma unroll
+                    for (int c = 0; c < G; ++c) { ra[c] = rr[c].x; rb[c] = rr[c].y; ha[c] = hh[c].x; hb[c] = hh[c].y; }
+                    blend_accumulate<G>(ra, ha, wA + c0, wfA + c0, RED, sra[0], sha[0]);
+                    blend_accumulate<G>(rb, hb, wA + c0, wfA + c0, RED, srb[0], shb[0]);
+                    if (two) {
+                        blend_accumulate<G>(ra, ha, wB + c0, wfB + c0, RED, sra[1], sha[1]);
+                        blend_accumulate<G>(rb, hb, wB + c0, wfB + c0, RED, srb[1], shb[1]);
+                    }
+                }
+                double2 m0, m1 = make_double2(0.0, 0.0);
+                constexpr bool kFin = RED && !(MSX_PAIR_EXP & 4);
+                m0.x = blend_finish(sra[0], sha[0], kl2.x, (double)dk2.x, redcA, kFin && reddenA, e2tab);
+                m0.y = blend_finish(srb[0], shb[0], kl2.y, (double)dk2.y, redcA, kFin && reddenA, e2tab);
+                if (two) {
+                    m1.x = blend_finish(sra[1], sha[1], kl2.x, (double)dk2.x, redcB, kFin && reddenB, e2tab);
+                    m1.y = blend_finish(srb[1], shb[1], kl2.y, (double)dk2.y, redcB, kFin && reddenB, e2tab);
+                }
+                m[0][j] = m0;
+                m[1][j] = m1;
+                // (the trips are unrolled for the static register indices of m[][]; without a fence the scheduler
+                // hoists the loads of ALL trips to the top and spills what it cannot hold)
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            static_for<0, NT>(trip);
+        }
+        // ... then ONE sweep over the registers for what follows the model values (the fit sums, the value range, the
+        // median's histogram): kept out of the blend loop, whose row loads want the registers -- 24 accumulators per
+        // walker pair and the data flux / u of the trip would push it into spilling
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+            for (int k = 0; k < vk; ++k) qa[s][k][0] = qa[s][k][1] = qa[s][k][2] = 0.0;
+        auto fit_trip = [&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value;
+            int tj = tid;
+            asm volatile("" : "+v"(tj));
+            const int e = j * B + tj;
+            const bool live = e < ne;
+            const int ec = live ? e : ne - 1;
+            const unsigned int o16 = (unsigned int)ec << 4;
+            const double2 f2v = ld_off(P.f2, o16), u2v = ld_off(P.u2, o16);
+            finish_elem(std::integral_constant<int, 0>{}, j_c, m[0][j], f2v, u2v, ec, live);
+            if (two) finish_elem(std::integral_constant<int, 1>{}, j_c, m[1][j], f2v, u2v, ec, live);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (!(MSX_PAIR_EXP & 1)) static_for<0, NT>(fit_trip);
+
+        // ---- the fit sums (canonical sum), running totals of the histograms, value ranges --------------------------
+        static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double a[vk];
+#pragma unroll
+                for (int k = 0; k < vk; ++k) a[k] = qa[s][k][i];
+                red[s][i][wave][lane] = lane_partial<vk>(a);
+            }
+        });
+        __syncthreads();
+        for (int idx = wave; idx < (two ? 6 : 3); idx += nw) {  // one wave per (walker, quantity)
+            const int s = idx >= 3 ? 1 : 0, i = idx - 3 * s;
+            const double v = reduce_published<MAXT>(&red[s][i][0][0], lane);
+            if (lane == 0) S[s].q[0][i] = v;
+        }
+        hist_prefix_inplace<MAXT>(S[0]);
+        if (two) hist_prefix_inplace<MAXT>(S[1]);
+        static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+            const double lo = wave_min_f64(vmin[s]), hi = wave_max_f64(vmax[s]);
+            const bool wave_nan = __ballot(seen_nan[s]) != 0ull;
+            if (lane == 0) {
+                S[s].kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
+                S[s].kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
+            }
+        });
+        __syncthreads();
+        double q[2][3], pc[2][3];
+        unsigned long long kmin[2], kmax[2];
+        bool bad[2], appl[2];
+        LogbinSel Q[2];
+        static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q[s][i] = S[s].q[0][i];
+            kmin[s] = S[s].kmin[0]; kmax[s] = S[s].kmax[0];
+            for (int x = 1; x < nw; ++x) {
+                kmin[s] = S[s].kmin[x] < kmin[s] ? S[s].kmin[x] : kmin[s];
+                kmax[s] = S[s].kmax[x] > kmax[s] ? S[s].kmax[x] : kmax[s];
+            }
+            // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
+            bad[s] = kmax[s] > key_of(INFINITY) || kmin[s] < key_of(-INFINITY);
+            fit_coefs(P, q[s], pc[s][0], pc[s][1], pc[s][2]);
+            appl[s] = !bad[s] && logbin_applicable<MAXT>(kmin[s], kmax[s]);
+            if (appl[s]) appl[s] = logbin_locate<MAXT>(npix, kmin[s], S[s], &Q[s]);
+        });
+
+        // ---- ONE pass over the registers: chi^2 terms of both walkers from one load of u, data flux and 1/err^2,
+        //      and the candidates of each median's bin(s) --------------------------------------------------------
+        double acc[2][vk];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+            for (int k = 0; k < vk; ++k) acc[s][k] = 0.0;
+        auto pass_trip = [&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value;
+            constexpr int kbase = MAXT == 256 ? 2 * (j & 1) : 0;
+            int tj = tid;
+            asm volatile("" : "+v"(tj));
+            const int e = j * B + tj;
+            const int ec = e < ne ? e : ne - 1;
+            const unsigned int o16 = (unsigned int)ec << 4;
+            const double2 nv = ld_off(P.iv2, o16), cu = ld_off(P.u2, o16), cf = ld_off(P.f2, o16);
+            const int pa = ((e >> 8) << 9) | (e & 255);  // (beyond the tables: >= npix)
+            const bool livep[2] = {e < ne && pa < npix, e < ne && pa + 256 < npix};
+            const double uu[2] = {cu.x, cu.y}, ff[2] = {cf.x, cf.y}, ee[2] = {nv.x, nv.y};
+            static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_c)::value;
+                const double xv[2] = {m[s][j].x, m[s][j].y};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[s][kbase + u] += chi_term(pc[s][0], pc[s][1], pc[s][2], uu[u], ff[u], ee[u], xv[u], livep[u]);
+                    const unsigned int pb = logbin(xv[u]);
+                    if (appl[s] && livep[u] && (pb == Q[s].sel_p || pb == Q[s].nxt_p))
+                        S[s].cand[atomicAdd(&S[s].cand_n, 1u)] = key_of(xv[u]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (!(MSX_PAIR_EXP & 2)) static_for<0, NT>(pass_trip);
+        red[0][0][wave][lane] = lane_partial<vk>(acc[0]);
+        if (two) red[1][0][wave][lane] = lane_partial<vk>(acc[1]);
+        __syncthreads();
+
+        // ---- rank (wave s ranks walker s's candidates), meanwhile the contrast / photometry and prior terms -------
+        double med[2] = {0.0, 0.0};
+        if (appl[0]) med[0] = logbin_rank<MAXT>(S[0], Q[0], need_two, 0);
+        if (two && appl[1]) med[1] = logbin_rank<MAXT>(S[1], Q[1], need_two, 1);
+        if (wave == 2) {
+            recipe_band_terms<NS>(P, mode, theta + wk0 * ndim, D[sa], lane);
+            recipe_prior_terms<NS>(P, mode, theta + wk0 * ndim, D[sa], lane);
+        }
+        if (wave == 3 && two) {
+            recipe_band_terms<NS>(P, mode, theta + wk1 * ndim, D[sb], lane);
+            recipe_prior_terms<NS>(P, mode, theta + wk1 * ndim, D[sb], lane);
+        }
+        // vectors the early histogram cannot handle (not positive, >= 8 binades, > 256 equal-bin candidates): the
+        // model values go to the walker's scratch row and block_median (linear bins, radix fallback) reads them there
+        static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+            if (bad[s] || appl[s]) return;  // (uniform)
+            double *row = P.model_scratch + (s == 0 ? wk0 : wk1) * (int64_t)npix;
+            auto spill = [&](auto j_c) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_c)::value;
+                const int e = j * B + tid;
+                const int pa = ((e >> 8) << 9) | (e & 255);
+                if (e < ne && pa < npix) row[pa] = m[s][j].x;
+                if (e < ne && pa + 256 < npix) row[pa + 256] = m[s][j].y;
+            };
+            static_for<0, NT>(spill);
+            for (int i = tid; i < kBins; i += B) S[s].hist[i] = 0;  // (block_median's entry condition)
+            __threadfence_block();
+            __syncthreads();
+            NoElem no_elem;
+            bool unused = false;
+            med[s] = block_median<MAXT>(row, npix, kmin[s], kmax[s], S[s], NoSide(), no_elem, &unused);
+        });
+        __syncthreads();  // D.chi_extra, D.lp (waves 2 and 3)
+
+        // ---- combine (wave s finishes walker s) ---------------------------------------------------------------------
+        static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+            if (wave != s) return;
+            const double tot = reduce_published<MAXT>(&red[s][0][0][0], lane);
+            if (lane == 0) {
+                const WalkerDesc &Dw = s == 0 ? D[sa] : D[sb];
+                const int64_t wk = s == 0 ? wk0 : wk1;
+                double out;
+                if (bad[s]) {
+                    out = mode == MSX_MODE_CHISQ ? NAN : -INFINITY;
+                } else {
+                    const double total = fused_total(P, tot, P.median_flux, med[s], npix, Dw.chi_extra);
+                    out = value_of_total(mode, total, Dw.lp);
+                }
+                logp[wk] = out;
+                status[wk] = MSX_W_OK;
+            }
+        });
+    };
+    if (same) {
+        body(std::true_type{}, 0, 1);
+    } else {
+        // the live ones one after the other -- two more inlined copies of the one-walker body, not a loop: as the body of
+        // a loop the compiler keeps the sweeps' unrolled state alive around the back edge and spills all of it
+        if (act0) body(std::false_type{}, 0, 0);
+        __syncthreads();  // a second evaluation re-uses the LDS state
+        if (act1) body(std::false_type{}, 1, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The planner: who shares a workgroup.  One thread per walker computes the walker's GRID CELL -- the eight sorted node
+// indices its recipe will read (isochrone logg, the two brackets per star: scalar restatements of recipe.h) -- hashed
+// to a 40-bit tag.  Partners are found without sorting the batch and without contended atomics, level by level:
+//   1. inside each WAVE, by ballots: the lanes of one tag pair up in lane order (no memory traffic at all);
+//   2. what a wave cannot place -- at most one walker per cell -- meets the other waves' leftovers inside the WORKGROUP:
+//      a short list of cards in LDS, 64 to a wave, the same ballots again, for a few rounds;
+//   3. what a workgroup cannot place -- at most one walker per cell -- is a single (16 workgroups of 1024 walkers x a
+//      handful of cells in a batch of 16,384: under 1 %; a global third level cost more than it placed).
+// Per workgroup: one global atomic add for its pairs, one for its singles.  Walkers the prior box rejects or whose
+// recipe will fail are singles from the start.  Pairs and singles are ONE list of items for
+// logprob_pair_kernel (singles first: a lone walker's workgroup is the longest, it starts at once).  Who meets whom
+// depends on the batch order only; values depend on neither: a walker's bits are its own (see the header of this
+// file).  And a cell mis-computed here costs time, not correctness: the pair kernel compares the real recipes and
+// evaluates walkers that differ one after the other.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanSortMax = 2048;  // capacity of the workgroup's card list (1024 walkers: at most 1024 cards)
+
+// The lanes of one tag, in lane order: ranks 0 and 1 are a pair, 2 and 3, ...; the odd one out of a tag is `leftover`.
+// Ballots only.  partner_lane = the lane this (even-rank) lane pairs with, or -1.
+__device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane, int *partner_lane, bool *leftover) {
+    *partner_lane = -1;
+    *leftover = false;
+    unsigned long long rem = __ballot(tag != 0ull);
+    while (rem != 0ull) {  // (uniform: one trip per distinct cell in the wave)
+        const int leader = __ffsll((long long)rem) - 1;
+        const unsigned long long ltag = readlane_u64(tag, leader);
+        const unsigned long long grp = __ballot(tag == ltag) & rem;
+        if ((grp >> lane) & 1ull) {
+            const int r = __popcll(grp & ((1ull << lane) - 1ull));
+            if ((r & 1) == 0) {
+                const unsigned long long nxt = lane < 63 ? (grp & ~((2ull << lane) - 1ull)) : 0ull;
+                if (nxt != 0ull) *partner_lane = __ffsll((long long)nxt) - 1; else *leftover = true;
+            }
+        }
+        rem &= ~grp;
+    }
+}
+
+__global__ void __launch_bounds__(kPlanThreads)
+pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
+                 double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, int64_t cap, unsigned long long *__restrict__ cards) {
+    constexpr int NS = 2, ndim = 6;
+    __shared__ double s_isot[4 * kWave], s_isog[4 * kWave], s_teff[kWave], s_logg[32];
+    __shared__ unsigned long long s_cards[kPlanSortMax];
+    __shared__ int2 s_pairs[kPlanSortMax / 2];
+    __shared__ unsigned long long s_left[kPlanSortMax];
+    __shared__ int s_nc, s_np, s_nl, s_ns, s_basep, s_basel;
+    const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
+    const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
+    const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
+    const int tid = threadIdx.x, lane = tid & 63;
+    int2 *pairs = reinterpret_cast<int2 *>(plan + kPairHdrInts);
+    int32_t *singles = plan + kPairHdrInts + 2 * cap;
+    {
+        const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT), *g_isog = reinterpret_cast<const double *>(rblk + kRbIsoG);
+        const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
+        if (tid < niso) { s_isot[tid] = g_isot[tid]; s_isog[tid] = g_isog[tid]; }
+        if (tid < nt) s_teff[tid] = g_teff[tid];
+        if (tid < ng) s_logg[tid] = g_logg[tid];
+        if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kPlanThreads + tid;
+    unsigned long long tag = 0ull;  // 0: not to be paired
+    const bool mine = i < n;
+    if (mine) {
+        double t[ndim];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < ndim; ++k) { t[k] = theta[i * ndim + k]; ok = ok && isfinite(t[k]); }
+        if (ok && mode == MSX_MODE_LOGPOST) ok = prior_gates<NS>(gates, t);
+        int node[NS * 4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double x = t[s];
+            if (!ok || !(x >= s_isot[0]) || !(x <= s_isot[niso - 1])) { ok = false; continue; }
+            int lo = 0, hi = niso;  // last j with isot[j] <= x
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_isot[mid] <= x) lo = mid; else hi = mid; }
+            double lg = s_isog[lo];
+            if (lo + 1 < niso) lg = (s_isog[lo + 1] - s_isog[lo]) / (s_isot[lo + 1] - s_isot[lo]) * (x - s_isot[lo]) + s_isog[lo];
+            int t1, t2, g1, g2;
+            if (bracket_nodes(s_teff, nt, x, &t1, &t2) != MSX_W_OK || bracket_nodes(s_logg, ng, lg, &g1, &g2) != MSX_W_OK) { ok = false; continue; }
+            int a = t1 * ng + g1, b = t1 * ng + g2, c_ = t2 * ng + g1, d = t2 * ng + g2, tmp;
+#define MSX_SW(x_, y_) if (x_ > y_) { tmp = x_; x_ = y_; y_ = tmp; }
+            MSX_SW(a, b) MSX_SW(c_, d) MSX_SW(a, c_) MSX_SW(b, d) MSX_SW(b, c_)
+#undef MSX_SW
+            node[4 * s] = a; node[4 * s + 1] = b; node[4 * s + 2] = c_; node[4 * s + 3] = d;
+        }
+        if (ok) {
+            unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) {
+                h ^= (unsigned long long)(unsigned int)node[c] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+                h *= 0xBF58476D1CE4E5B9ull;
+                h ^= h >> 31;
+            }
+            tag = (h >> 24) | 1ull;  // 40 bits, never zero
+        }
+    }
+#if defined(MSX_PLAN_EXP) && MSX_PLAN_EXP == 1
+    if (tag == 12345ull) plan[7] = 1;
+    return;
+#endif
+    // ---- 1. partners inside the wave ----------------------------------------------------------------------------------
+    int partner_lane;
+    bool leftover;
+    plan_wave_pairs(tag, lane, &partner_lane, &leftover);
+    const int partner_walker = __shfl((int)i, partner_lane >= 0 ? partner_lane : lane);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    {   // the wave's pairs, leftover cards and singles into the workgroup's lists (one LDS atomic each per wave)
+        const unsigned long long bp = __ballot(partner_lane >= 0), bl = __ballot(leftover), bs = __ballot(mine && tag == 0ull);
+        int basep = 0, basel = 0, bases = 0;
+        if (lane == 0) {
+            if (bp) basep = atomicAdd(&s_np, __popcll(bp));
+            if (bl) basel = atomicAdd(&s_nc, __popcll(bl));
+            if (bs) bases = atomicAdd(&s_ns, __popcll(bs));
+        }
+        basep = __builtin_amdgcn_readfirstlane(basep);
+        basel = __builtin_amdgcn_readfirstlane(basel);
+        bases = __builtin_amdgcn_readfirstlane(bases);
+        // (a workgroup's 1024 walkers: at most 512 wave-level pairs, 1024 cards, 1024 singles)
+        if (partner_lane >= 0) s_pairs[basep + __popcll(bp & below)] = make_int2((int)i, partner_walker);
+        if (leftover) s_cards[basel + __popcll(bl & below)] = (tag << 24) | (unsigned long long)(i + 1);
+        if (mine && tag == 0ull) s_left[bases + __popcll(bs & below)] = (unsigned long long)(i + 1);  // (singles: walker + 1, no tag)
+    }
+    __syncthreads();
+#if defined(MSX_PLAN_EXP) && MSX_PLAN_EXP == 2
+    return;
+#endif
+    // ---- 2. the waves' leftovers meet inside the workgroup: the same ballots over the card list, 64 cards per wave, in
+    //      rounds (128 cards -> at most one per cell and wave -> one wave -> at most one per cell) -------------------------
+    int nc = s_nc;
+    const int nsingle = s_ns;
+    unsigned long long *src = s_cards, *dst = s_cards + kPlanSortMax / 2;
+    for (int round = 0; round < 4 && nc > 1; ++round) {  // (uniform)
+        if (tid == 0) s_nl = 0;
+        __syncthreads();
+        const int k = tid;  // (nc <= 1024 = the workgroup)
+        const unsigned long long cd = k < nc ? src[k] : 0ull;
+        int pl;
+        bool lo;
+        plan_wave_pairs(cd >> 24, lane, &pl, &lo);
+        const unsigned long long other = __shfl(cd, pl >= 0 ? pl : lane);
+        const unsigned long long bp = __ballot(pl >= 0), bl = __ballot(lo);
+        int basep = 0, basel = 0;
+        if (lane == 0) {
+            if (bp) basep = atomicAdd(&s_np, __popcll(bp));
+            if (bl) basel = atomicAdd(&s_nl, __popcll(bl));
+        }
+        basep = __builtin_amdgcn_readfirstlane(basep);
+        basel = __builtin_amdgcn_readfirstlane(basel);
+        if (pl >= 0) s_pairs[basep + __popcll(bp & below)] = make_int2((int)(cd & 0xffffffull) - 1, (int)(other & 0xffffffull) - 1);
+        if (lo) dst[basel + __popcll(bl & below)] = cd;
+        __syncthreads();
+        const int left = s_nl;
+        if (left == nc) break;  // nothing met (every card its own cell, or one card per wave): the rest are singles
+        nc = left;
+        unsigned long long *t_ = src; src = dst; dst = t_;
+    }
+    __syncthreads();
+    for (int k = tid; k < nc; k += kPlanThreads) s_left[nsingle + k] = src[k];
+    if (tid == 0) s_nl = nc;
+    __syncthreads();
+    // ---- the workgroup's lists to global memory: one atomic add per list.  What the workgroup could not place -- at
+    //      most one walker per cell -- is a single: 16 workgroups x a handful of cells in 16,384 walkers. ---------------
+    const int np = s_np, nl = s_nl;
+    if (tid == 0) s_basep = np ? atomicAdd(&plan[2], np) : 0;
+    if (tid == 1) s_basel = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;
+    __syncthreads();
+    for (int k = tid; k < np; k += kPlanThreads) pairs[s_basep + k] = s_pairs[k];
+    for (int k = tid; k < nsingle + nl; k += kPlanThreads) singles[s_basel + k] = (int)(s_left[k] & 0xffffffull) - 1;
+    // ---- the last workgroup to finish publishes the counts and leaves the working counters at zero for the next launch
+    // (the ticket is taken after this workgroup's own adds have RETURNED -- their results placed the stores above)
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = atomicAdd(&plan[4], 1);
+        if (ticket == (int)gridDim.x - 1) {
+            plan[0] = atomicExch(&plan[2], 0);
+            plan[1] = atomicExch(&plan[3], 0);
+            atomicExch(&plan[4], 0);
+        }
+    }
+}
+
+}  // namespace
+
+#endif  // MSX_PAIR_KERNEL_H

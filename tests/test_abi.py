@@ -91,8 +91,9 @@ def test_python_constants_mirror_the_header():
              'MSX_W_INDEXERROR': _lib.W_INDEXERROR, 'MSX_W_VALUEERROR': _lib.W_VALUEERROR, 'MSX_W_HANDOVER': _lib.W_HANDOVER,
              'MSX_MODE_LOGLIKE': _lib.MODE_LOGLIKE, 'MSX_MODE_LOGPOST': _lib.MODE_LOGPOST, 'MSX_MODE_CHISQ': _lib.MODE_CHISQ,
              'MSX_MODE_LOGPRIOR': _lib.MODE_LOGPRIOR, 'MSX_BLOCK_512_SHARED': _lib.BLOCK_512_SHARED,
-             'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_LINKED': _lib.PATH_LINKED,
-             'MSX_HOOK_LINKED_FAULT': _lib.HOOK_LINKED_FAULT,
+             'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_PAIR': _lib.PATH_PAIR,
+             'MSX_PATH_LINKED': _lib.PATH_LINKED,
+             'MSX_HOOK_LINKED_FAULT': _lib.HOOK_LINKED_FAULT, 'MSX_HOOK_PAIR_THREADS': _lib.HOOK_PAIR_THREADS,
              'MSX_MAX_SPEC': _lib.MAX_SPEC, 'MSX_MAX_BANDS': _lib.MAX_BANDS, 'MSX_MAX_DIM': _lib.MAX_DIM}
     for name, val in pairs.items():
         assert defs[name] == val, name

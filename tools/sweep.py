@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--paths', default='fused')
     ap.add_argument('--graph', action='store_true')
+    ap.add_argument('--sort-cells', action='store_true', help='order the batch by Teff cell: neighbours mostly share their grid rows (what the pair form\'s planner arranges)')
     ap.add_argument('--spread', action='store_true', help='walkers uniform over the whole Teff range: every walker its own grid rows')
     args = ap.parse_args()
     import torch
@@ -36,11 +37,13 @@ def main():
         thn = synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])
         if args.spread:
             thn[:, 0:2] = np.random.default_rng(1).uniform(W['tmin'] + 1, W['tmax'] - 1, size=(n, 2))
-        th = torch.from_numpy(thn).to(dev)
+        if args.sort_cells:
+            thn = thn[np.lexsort((thn[:, 1] // 100, thn[:, 0] // 100))]
+        th = torch.from_numpy(np.ascontiguousarray(thn)).to(dev)
         lp = torch.empty(n, dtype=torch.float64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
         for path in args.paths.split(','):
-          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'linked': _lib.PATH_LINKED}[path])
+          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'linked': _lib.PATH_LINKED, 'pair': _lib.PATH_PAIR}[path])
           for B in [int(x) for x in args.blocks.split(',')]:
             def go(sp):
                 eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), sp, _lib.MODE_LOGPOST, B)
@@ -67,7 +70,10 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / (iters * reps)
-            row = dict(walkers=n, npix=args.npix, path=path, block=B, batch_us=ms * 1e3, evals_per_s=n / (ms * 1e-3),
+            extra = {}
+            if path == 'pair':
+                extra['pairs_singles'] = eng.ctx.pair_stats()
+            row = dict(extra, walkers=n, npix=args.npix, path=path, block=B, batch_us=ms * 1e3, evals_per_s=n / (ms * 1e-3),
                        alg_GBps=n * b_alg / (ms * 1e-3) / 1e9, graph=bool(args.graph))
             rows.append(row)
             print(json.dumps(row), flush=True)
