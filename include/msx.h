@@ -255,15 +255,14 @@ int msx_stream_copy_gbps(msx_ctx *ctx, int64_t bytes, int32_t iters, double *gbp
  * 132 instead of 148 bytes per pixel of a binary)                                                                  */
 int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
 
-/* the planner's counts for the pair form's last launch (a sub-batch): out2[0] = pairs, out2[1] = singles; synchronises */
+/* the planner's counts for the pair form's last launch (a sub-batch): out2[0] = pairs, out2[1] = walkers evaluated alone;
+ * synchronises */
 int msx_pair_stats(msx_ctx *ctx, int64_t *out2);
 
 /* ---- test hooks (used by tests/ only) ------------------------------------------------------------ */
 /* MSX_HOOK_LINKED_FAULT: value != 0 makes the producers of the linked form skip their signal, so that every joiner
  * runs into its bounded wait; takes effect at the next launch, without restaging                                  */
 #define MSX_HOOK_LINKED_FAULT 1
-/* MSX_HOOK_PAIR_THREADS: value = 256 | 512, the workgroup size of the pair form's next launches (same bits)   */
-#define MSX_HOOK_PAIR_THREADS 2
 int msx_test_hook(msx_ctx *ctx, int32_t what, int32_t value);
 
 #ifdef __cplusplus

@@ -83,6 +83,7 @@ struct DevProblem {
     int32_t *seg_flag;         // [rows] linked form: producers that have published their segment (the joiner resets it)
     int32_t *linked_poison;    // linked form: != 0 once a hand-over has timed out on this context -- every later linked
                                // launch fails all its walkers with MSX_W_HANDOVER until msx_stage_problem clears it
+    const struct PairRec *pair_rec;  // pair form: [rows] the planner's recipes
     int32_t linked_fault;      // test hook (msx_test_hook / MSX_LINKED_FAULT=1): producers skip the increment, joiners must time out
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
@@ -140,6 +141,15 @@ constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPr
 constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the linked form
 constexpr int kSegBins = 2048;      // (= kLogBins, median.h)
 constexpr unsigned long long kHandoverTicks = 2000000ull;  // linked path: a joiner gives up after 20 ms of the 100 MHz wall clock
+
+// pair form: a walker's recipe as the planner (one thread per walker) leaves it for the pair kernel
+struct alignas(16) PairRec {
+    double w[kMaxCorners > 8 ? 8 : kMaxCorners];  // bilinear weight x (R/d)^2 per corner, canonical (sorted-node) order
+    double redc;                                  // exp2 coefficient of the reddening; 0: none
+    int32_t node[8];
+    int32_t status, pad;
+};
+static_assert(sizeof(PairRec) == 112, "PairRec layout");
 
 // linked form: what a producer leaves per (walker, segment) for the walker's joiner
 struct alignas(16) SegPart {

@@ -120,11 +120,16 @@ struct msx_ctx {
     int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _PAIR / _LINKED (msx_set_path)
     // pair form (pair_kernel.h): binaries of <= 4096 pixels with the register-resident recipe
     int64_t pair_rows = 0;          // scratch rows for its rare spill path = walkers per sub-batch (0: no pair form here)
-    int32_t pair_threads = 256;     // MSX_PAIR_THREADS: 256 (two workgroups per CU, 256 VGPRs) or 512 (two per CU, 128 VGPRs)
-    int64_t pair_min_walkers = INT64_MAX;  // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN)
+    // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN; 0 = never).  Measured at 4096 px
+    // (profiles/r3_pair_sweep.txt): 2,048 walkers 74.0 us against 69.8 fused (the planner's launch costs more than the
+    // shared loads save), 4,096: 111.8 against 121.2, 8,192: 188.7 against 225.1, 16,384: 344.8 against 438.3.
+    int64_t pair_min_walkers = 4096;
     int32_t *d_pair_plan = nullptr; // the planner's output (pair_kernel.h: header, pairs, singles)
-    unsigned long long *d_pair_slots = nullptr;  // ... and its list of leftover cards
-    bool pair_noplan = false;       // MSX_PAIR_NOPLAN=1: pair neighbours in the batch, no planner (experiments)
+    PairRec *d_pair_rec = nullptr;  // ... and its recipes, one per walker of a sub-batch
+    // {pairs, singles} of the planner's last run, written by the device into host memory and read here WITHOUT waiting
+    // for it (so possibly a launch or two old): MSX_PATH_AUTO's only evidence of whether pairing pays (pair_worth_it)
+    int32_t *h_pair_stats = nullptr;
+    int64_t pair_auto_launches = 0;
     int32_t linked = -1;            // MSX_LINKED: -1 = automatic (walkers x segments <= #CUs / 2), 0 never, 1 whenever possible
     bool linked_poisoned = false;   // a hand-over of the linked form timed out on this context (seen by a synchronous
                                     // entry point): MSX_PATH_AUTO takes the fused form until the problem is staged again
@@ -206,11 +211,13 @@ void free_problem(msx_ctx *c) {
     if (c->d_opt_med) (void)hipFree(c->d_opt_med);
     c->d_opt_flux = c->d_opt_med = nullptr;
     c->opt_chains = 0;
-    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_slots};
+    if (c->h_pair_stats) (void)hipHostFree(c->h_pair_stats);
+    c->h_pair_stats = nullptr;
+    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_rec};
     for (void *p : sp)
         if (p) (void)hipFree(p);
     c->d_segparts = nullptr; c->d_seg_flag = nullptr; c->d_model_scratch = nullptr; c->scratch_rows = 0;
-    c->d_pair_plan = nullptr; c->d_pair_slots = nullptr; c->pair_rows = 0;
+    c->d_pair_plan = nullptr; c->d_pair_rec = nullptr; c->pair_rows = 0;
     c->linked_poisoned = false;
 }
 
@@ -371,29 +378,40 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     return MSX_OK;
 }
 
+// Does MSX_PATH_AUTO take the pair form for the next large batch?  A walker the planner cannot pair costs the pair kernel
+// a whole workgroup (two per CU: 0.042 us per item at 16,384 walkers) where the fused kernel runs three per CU (0.027 us
+// per walker), so pairing pays while singles < 0.75 pairs -- an ensemble in a handful of grid cells, the normal state of
+// a chain -- and does not for one spread over the grid (burn-in from a wide start: 16,384 walkers 521 us against 440).
+// The evidence is the planner's count of its last run, which the device leaves in host memory; it is read without
+// synchronising, so it may lag.  While it says "spread" the fused kernel runs, and every 32nd qualifying launch goes
+// through the pair form anyway to look again.  (The choice is frozen into a captured hipGraph like any launch
+// parameter.)  Values never depend on it.
+bool pair_worth_it(msx_ctx *c) {
+    const int32_t np = ((volatile int32_t *)c->h_pair_stats)[0], ns = ((volatile int32_t *)c->h_pair_stats)[1];
+    const bool pays = 4 * (int64_t)ns < 3 * (int64_t)np;
+    return pays || (++c->pair_auto_launches % 32) == 0;
+}
+
 // The pair form over A.n walkers (pair_kernel.h): the variant compiled for the smallest trip count that covers the
-// spectrum (256 threads: 3 / 4 / 8 element trips per lane = up to 1536 / 2048 / 4096 pixels; 512 threads: 2 / 4).
+// spectrum (2 / 4 element trips per lane = up to 2048 / 4096 pixels).
 int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
-    // 1. who shares a workgroup (MSX_PAIR_NOPLAN=1: neighbours in the batch, no planner -- experiments)
-    const int32_t *plan = c->pair_noplan ? nullptr : c->d_pair_plan;
-    if (plan) {
-        hipLaunchKernelGGL(pair_plan_kernel, dim3((unsigned)((A.n + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, A.s, A.theta,
-                           (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax,
-                           c->d_pair_plan, c->pair_rows, c->d_pair_slots);
-        HIP_TRY(c, hipGetLastError());
-    }
-    // 2. the planner's items: singles + pairs <= n (workgroups beyond the planner's count leave at once -- measured free)
-    const dim3 g((unsigned)std::max<int64_t>(1, plan ? A.n : (A.n + 1) / 2));
+    // 1. the planner: every walker's recipe (one thread per walker), final values of the rejected / failed ones, and
+    //    who shares a workgroup
+    const int32_t *plan = c->d_pair_plan;
+    hipLaunchKernelGGL(pair_plan_kernel, dim3((unsigned)((A.n + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, A.s, A.theta,
+                       (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax,
+                       c->d_pair_plan, c->pair_rows, c->d_pair_rec, A.logp, A.status, c->h_pair_stats);
+    HIP_TRY(c, hipGetLastError());
+    // 2. the planner's items: singles + pairs <= n workgroups; those beyond the planner's count leave after one load
+    const dim3 g((unsigned)A.n);
     const int64_t ne = P.npair;
 #define MSX_PAIR_GO2(T_, NT_, RED_)                                                                                   \
     hipLaunchKernelGGL((logprob_pair_kernel<T_, NT_, RED_>), g, dim3(T_), 0, A.s, A.theta, (const unsigned char *)c->d_recipe_block, \
                        A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status, c->pair_rows)
 #define MSX_PAIR_GO(T_, NT_) do { if (P.use_av) MSX_PAIR_GO2(T_, NT_, true); else MSX_PAIR_GO2(T_, NT_, false); } while (0)
-    if (c->pair_threads == 512) {
-        if (ne <= 2 * 512) MSX_PAIR_GO(512, 2); else MSX_PAIR_GO(512, 4);
-    } else {
-        if (ne <= 3 * 256) MSX_PAIR_GO(256, 3); else if (ne <= 4 * 256) MSX_PAIR_GO(256, 4); else MSX_PAIR_GO(256, 8);
-    }
+    // (512 threads, two workgroups per CU at <= 128 VGPRs: 16 waves per CU.  The 256-thread variants -- two per CU at
+    // 256 VGPRs, 8 waves -- measured 411.8 us against 344.8 at 16,384 walkers and are not built.)
+    if (ne <= 2 * 512) MSX_PAIR_GO(512, 2); else MSX_PAIR_GO(512, 4);
 #undef MSX_PAIR_GO
 #undef MSX_PAIR_GO2
     HIP_TRY(c, hipGetLastError());
@@ -829,11 +847,13 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         const size_t plan_bytes = sizeof(int32_t) * (size_t)(kPairHdrInts + 3 * rows);
         HIP_TRY(c, hipMalloc((void **)&c->d_pair_plan, plan_bytes));
         HIP_TRY(c, hipMemset(c->d_pair_plan, 0, plan_bytes));
-        HIP_TRY(c, hipMalloc((void **)&c->d_pair_slots, sizeof(unsigned long long) * (size_t)rows));  // leftover cards
+        HIP_TRY(c, hipMalloc((void **)&c->d_pair_rec, sizeof(PairRec) * (size_t)rows));
+        P.pair_rec = c->d_pair_rec;
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_pair_stats, 2 * sizeof(int32_t), hipHostMallocDefault));
+        c->h_pair_stats[0] = 1; c->h_pair_stats[1] = 0;  // (nothing known yet: try)
+        c->pair_auto_launches = 0;
         c->pair_rows = rows;
-        if (const char *e = getenv("MSX_PAIR_NOPLAN")) c->pair_noplan = e[0] == '1';
-        if (const char *e = getenv("MSX_PAIR_THREADS")) c->pair_threads = atoi(e) == 512 ? 512 : 256;
-        if (const char *e = getenv("MSX_PAIR_MIN")) c->pair_min_walkers = std::max<int64_t>(2, atoll(e));
+        if (const char *e = getenv("MSX_PAIR_MIN")) c->pair_min_walkers = atoll(e) > 0 ? std::max<int64_t>(2, atoll(e)) : INT64_MAX;
     }
 #ifdef MSX_STAMPS
     {   // diagnostic build only: per-walker shader-clock stamps
@@ -920,7 +940,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // pair (pair_kernel.h): many walkers -- two walkers of one grid cell per workgroup share one set of row loads
     const bool can_pair = c->pair_rows > 0 && fast && !Pc.smp_on && Pc.nspec == 2 &&
                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool pair = can_pair && n >= c->pair_min_walkers;
+    bool pair = can_pair && n >= c->pair_min_walkers && pair_worth_it(c);
     if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_LINKED) pair = false;
     if (c->path == MSX_PATH_PAIR) {
         if (!can_pair) return fail(c, MSX_ERR_STATE, "msx_set_path(PAIR): needs a binary of <= 4096 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
@@ -1615,11 +1635,6 @@ int msx_test_hook(msx_ctx *c, int32_t what, int32_t value) {
     if (what == MSX_HOOK_LINKED_FAULT) {
         if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_test_hook: no problem staged");
         c->P.linked_fault = value != 0;
-        return MSX_OK;
-    }
-    if (what == MSX_HOOK_PAIR_THREADS) {
-        if (value != 256 && value != 512) return fail(c, MSX_ERR_INVALID, "msx_test_hook: pair threads are 256 or 512");
-        c->pair_threads = value;
         return MSX_OK;
     }
     return fail(c, MSX_ERR_INVALID, "msx_test_hook: unknown hook");

@@ -37,9 +37,9 @@ namespace {
 
 constexpr int kPairMaxPix = 4096;   // model values in registers: kPairMaxPix / MAXT doubles per lane and walker
 // The plan (pair_plan_kernel): int32 plan[kPairHdrInts + 3 cap]
-//   [0] pairs, [1] singles (final counts, read by the consumers); [2], [3] the same while the planner runs, [4] its
-//   finished workgroups, [5] leftover cards (all four back at zero when it ends); pairs {a, b} from [kPairHdrInts],
-//   singles from [kPairHdrInts + 2 cap]
+//   [0] pairs, [1] singles: the pair kernel's items (final counts); [2], [3] the same while the planner runs, [4] its
+//   finished workgroups (all three back at zero when it ends); pairs {a, b} from [kPairHdrInts], singles from
+//   [kPairHdrInts + 2 cap]
 constexpr int kPairHdrInts = 8;
 
 template <int I, int N, class F>
@@ -62,23 +62,22 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
                     double *__restrict__ logp, int32_t *__restrict__ status, int64_t plan_cap) {
     // (the leading 14 dwords arrive preloaded in SGPRs, as in logprob_kernel)
     constexpr int NS = 2, ndim = 6, NC = 8, B = MAXT, nw = B >> 6;
+    (void)rblk; (void)niso_nt; (void)n; (void)gate_tmin; (void)gate_tmax;
     static_assert(NT * MAXT * 2 <= kPairMaxPix, "model values per lane");
     constexpr int vk = kMaxWaves / nw;          // canonical-sum slots per lane: 4 or 2
     constexpr int G = MAXT == 256 ? NC : 4;     // corners per group of loads (512 threads: <= 128 VGPRs, a star at a time)
     static_assert(MAXT == 256 || MAXT == 512, "256 or 512 threads");
-    const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
     __shared__ WalkerDesc D[2];
     __shared__ BlockScratch S[2];
     __shared__ double red[2][3][nw][kWave];
     __shared__ double e2tab[kExp2Tab];
-    const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
-    const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
+    struct WalkerLoc { double pc[3]; unsigned long long kmin, kmax; LogbinSel Q; int bad, appl; };
+    __shared__ WalkerLoc Loc[2];
+    const int mode = (ng_mode_fast >> 8) & 0xff;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
-    RecipeRegs RR;
-    if (wave0 < 2 * NS) load_recipe_regs(RR, rblk, niso, nt, ng, lane0);
-    // ---- this workgroup's item ---------------------------------------------------------------------------------
+    // ---- this workgroup's item: the planner's singles first, then its pairs -------------------------------------
     int64_t wkv[2];
-    if (plan) {  // the planner's items: its singles first, then its pairs
+    {
         const int2 cnt = *reinterpret_cast<const int2 *>(plan);  // {pairs, singles}
         const int nsingle = cnt.y, b = (int)blockIdx.x - nsingle;
         if (b >= cnt.x) return;
@@ -90,44 +89,22 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             wkv[0] = it.x;
             wkv[1] = it.y;
         }
-    } else {  // no plan: neighbours in the batch
-        wkv[0] = 2 * (int64_t)blockIdx.x;
-        wkv[1] = wkv[0] + 1 < n ? wkv[0] + 1 : -1;
-        if (wkv[0] >= n) return;
     }
     const int npix = (int)P.npix;
     const int ne = (int)P.npair;  // table elements, a multiple of 256; <= kPairMaxPix / 2 (checked by the host)
 
-    // ---- phase 0: the two recipes, one wave0 per (walker, star) ---------------------------------------------------
-    const int rslot = wave0 >> 1, rstar = wave0 & 1;
-    const int64_t rwk = wave0 < 2 * NS ? wkv[rslot] : -1;
-    double theta_lane = 0.0;
-    if (rwk >= 0 && lane0 < ndim) theta_lane = theta[rwk * ndim + lane0];
+    // ---- phase 0: the walkers' recipes are the planner's (recipe_scalar2: every walker on the list is live) --------
+    if (wave0 < 2 && lane0 < NC) {
+        const int64_t wk = wkv[wave0] >= 0 ? wkv[wave0] : wkv[0];
+        const PairRec *R = P.pair_rec + wk;
+        D[wave0].node[lane0] = R->node[lane0];
+        D[wave0].w[lane0] = R->w[lane0];
+        if (lane0 == 0) D[wave0].redc = R->redc;
+    }
     fill_exp2_table(e2tab, tid0 - (B - kWave));
-    if (tid0 < 2) { D[tid0].stat[0] = MSX_W_OK; D[tid0].stat[1] = MSX_W_OK; }
-    __syncthreads();  // (the defaults above, before the recipe waves' own stores)
-    if (rwk >= 0) {
-        double tv[ndim];
-#pragma unroll
-        for (int k = 0; k < ndim; ++k) tv[k] = readlane_f64(theta_lane, k);
-        recipe_part1_regs<NS>(P, gates, RR, niso, nt, ng, mode, theta_lane, tv, D[rslot], lane0, rwk, rstar);
-    }
     __syncthreads();
-    int wst[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        int w = D[s].stat[0];
-        w = (w == MSX_W_OK) ? D[s].stat[1] : w;                                                  // first star that failed ...
-        w = (w != MSX_W_REJECT && D[s].stat[1] == MSX_W_VALUEERROR) ? MSX_W_VALUEERROR : w;       // ... see logprob_kernel
-        wst[s] = wkv[s] < 0 ? -1 : w;
-        if (wst[s] > MSX_W_OK && tid0 == s * kWave) {  // rejected by the prior box, or an error status: final here
-            logp[wkv[s]] = (w > MSX_W_REJECT) ? nan_with_status(w) : -INFINITY;
-            status[wkv[s]] = w;
-        }
-    }
-    const bool act0 = wst[0] == MSX_W_OK, act1 = wst[1] == MSX_W_OK;
-    if (!act0 && !act1) return;
-    bool same = act0 && act1;
+    const bool act0 = true, act1 = wkv[1] >= 0;
+    bool same = act1;
     if (same) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) same = same && D[0].node[c] == D[1].node[c];
@@ -289,24 +266,44 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             }
         });
         __syncthreads();
-        double q[2][3], pc[2][3];
+        // wave s works out walker s's fit coefficients, value range and the median's bin(s) and leaves them in LDS for
+        // the others (the fused kernel lets every wave locate the rank for itself to save a barrier: with many workgroups
+        // in flight the ~120 instructions per wave cost more than the barrier)
+        static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+            if (wave != s) return;
+            double q[3], c0, c1, c2;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q[i] = S[s].q[0][i];
+            unsigned long long k0 = S[s].kmin[0], k1 = S[s].kmax[0];
+            for (int x = 1; x < nw; ++x) {
+                k0 = S[s].kmin[x] < k0 ? S[s].kmin[x] : k0;
+                k1 = S[s].kmax[x] > k1 ? S[s].kmax[x] : k1;
+            }
+            // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
+            const bool bd = k1 > key_of(INFINITY) || k0 < key_of(-INFINITY);
+            fit_coefs(P, q, c0, c1, c2);
+            LogbinSel Qs = {0u, 0u, 0u, 0u};
+            bool ap = !bd && logbin_applicable<MAXT>(k0, k1);
+            if (ap) ap = logbin_locate<MAXT>(npix, k0, S[s], &Qs);
+            if (lane == 0) {
+                Loc[s].pc[0] = c0; Loc[s].pc[1] = c1; Loc[s].pc[2] = c2;
+                Loc[s].kmin = k0; Loc[s].kmax = k1;
+                Loc[s].Q = Qs;
+                Loc[s].bad = bd; Loc[s].appl = ap;
+            }
+        });
+        __syncthreads();
+        double pc[2][3];
         unsigned long long kmin[2], kmax[2];
         bool bad[2], appl[2];
         LogbinSel Q[2];
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
             constexpr int s = decltype(s_c)::value;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) q[s][i] = S[s].q[0][i];
-            kmin[s] = S[s].kmin[0]; kmax[s] = S[s].kmax[0];
-            for (int x = 1; x < nw; ++x) {
-                kmin[s] = S[s].kmin[x] < kmin[s] ? S[s].kmin[x] : kmin[s];
-                kmax[s] = S[s].kmax[x] > kmax[s] ? S[s].kmax[x] : kmax[s];
-            }
-            // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
-            bad[s] = kmax[s] > key_of(INFINITY) || kmin[s] < key_of(-INFINITY);
-            fit_coefs(P, q[s], pc[s][0], pc[s][1], pc[s][2]);
-            appl[s] = !bad[s] && logbin_applicable<MAXT>(kmin[s], kmax[s]);
-            if (appl[s]) appl[s] = logbin_locate<MAXT>(npix, kmin[s], S[s], &Q[s]);
+            pc[s][0] = Loc[s].pc[0]; pc[s][1] = Loc[s].pc[1]; pc[s][2] = Loc[s].pc[2];
+            kmin[s] = Loc[s].kmin; kmax[s] = Loc[s].kmax;
+            Q[s] = Loc[s].Q;
+            bad[s] = Loc[s].bad != 0; appl[s] = Loc[s].appl != 0;
         });
 
         // ---- ONE pass over the registers: chi^2 terms of both walkers from one load of u, data flux and 1/err^2,
@@ -429,6 +426,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
 // evaluates walkers that differ one after the other.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPlanThreads = 1024;
+constexpr int kPlanCells = 12;
 constexpr int kPlanSortMax = 2048;  // capacity of the workgroup's card list (1024 walkers: at most 1024 cards)
 
 // The lanes of one tag, in lane order: ranks 0 and 1 are a pair, 2 and 3, ...; the odd one out of a tag is `leftover`.
@@ -437,7 +435,9 @@ __device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane
     *partner_lane = -1;
     *leftover = false;
     unsigned long long rem = __ballot(tag != 0ull);
-    while (rem != 0ull) {  // (uniform: one trip per distinct cell in the wave)
+    // (uniform: one trip per distinct cell in the wave -- up to kPlanCells of them: a wave with more is part of an
+    // ensemble spread over the grid, where there is little to pair and no point in 64 trips; the rest stay unplaced)
+    for (int trip = 0; rem != 0ull && trip < kPlanCells; ++trip) {
         const int leader = __ffsll((long long)rem) - 1;
         const unsigned long long ltag = readlane_u64(tag, leader);
         const unsigned long long grp = __ballot(tag == ltag) & rem;
@@ -450,13 +450,16 @@ __device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane
         }
         rem &= ~grp;
     }
+    if ((rem >> lane) & 1ull) *leftover = true;
 }
 
 __global__ void __launch_bounds__(kPlanThreads)
 pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
-                 double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, int64_t cap, unsigned long long *__restrict__ cards) {
+                 double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, int64_t cap, PairRec *__restrict__ rec,
+                 double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats) {
     constexpr int NS = 2, ndim = 6;
     __shared__ double s_isot[4 * kWave], s_isog[4 * kWave], s_teff[kWave], s_logg[32];
+    __shared__ unsigned int s_pmask[kWave];
     __shared__ unsigned long long s_cards[kPlanSortMax];
     __shared__ int2 s_pairs[kPlanSortMax / 2];
     __shared__ unsigned long long s_left[kPlanSortMax];
@@ -471,38 +474,32 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT), *g_isog = reinterpret_cast<const double *>(rblk + kRbIsoG);
         const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
         if (tid < niso) { s_isot[tid] = g_isot[tid]; s_isog[tid] = g_isog[tid]; }
-        if (tid < nt) s_teff[tid] = g_teff[tid];
+        if (tid < nt) { s_teff[tid] = g_teff[tid]; s_pmask[tid] = reinterpret_cast<const unsigned int *>(rblk + kRbPresent)[tid]; }
         if (tid < ng) s_logg[tid] = g_logg[tid];
         if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
     }
-    __syncthreads();
+    // (the walker's coordinates are requested before the barrier that publishes the tables: one memory round trip, not two)
     const int64_t i = (int64_t)blockIdx.x * kPlanThreads + tid;
-    unsigned long long tag = 0ull;  // 0: not to be paired
     const bool mine = i < n;
+    double t[ndim];
+#pragma unroll
+    for (int k = 0; k < ndim; ++k) t[k] = mine ? theta[i * ndim + k] : 0.0;
+    __syncthreads();
+    unsigned long long tag = 0ull;  // 0: nothing left to evaluate (rejected by the prior box, or an error status)
     if (mine) {
-        double t[ndim];
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < ndim; ++k) { t[k] = theta[i * ndim + k]; ok = ok && isfinite(t[k]); }
-        if (ok && mode == MSX_MODE_LOGPOST) ok = prior_gates<NS>(gates, t);
+        const ScalarTabs T = {s_isot, s_isog, s_teff, s_logg, s_pmask, niso, nt, ng};
         int node[NS * 4];
+        double w[NS * 4], redc;
+        const int st = recipe_scalar2(gates, T, mode, t, node, w, &redc);
+        if (st != MSX_W_OK) {  // final here, like the fused kernel's first lines
+            logp[i] = (st > MSX_W_REJECT) ? nan_with_status(st) : -INFINITY;
+            status[i] = st;
+        } else {
+            PairRec *R = rec + i;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const double x = t[s];
-            if (!ok || !(x >= s_isot[0]) || !(x <= s_isot[niso - 1])) { ok = false; continue; }
-            int lo = 0, hi = niso;  // last j with isot[j] <= x
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_isot[mid] <= x) lo = mid; else hi = mid; }
-            double lg = s_isog[lo];
-            if (lo + 1 < niso) lg = (s_isog[lo + 1] - s_isog[lo]) / (s_isot[lo + 1] - s_isot[lo]) * (x - s_isot[lo]) + s_isog[lo];
-            int t1, t2, g1, g2;
-            if (bracket_nodes(s_teff, nt, x, &t1, &t2) != MSX_W_OK || bracket_nodes(s_logg, ng, lg, &g1, &g2) != MSX_W_OK) { ok = false; continue; }
-            int a = t1 * ng + g1, b = t1 * ng + g2, c_ = t2 * ng + g1, d = t2 * ng + g2, tmp;
-#define MSX_SW(x_, y_) if (x_ > y_) { tmp = x_; x_ = y_; y_ = tmp; }
-            MSX_SW(a, b) MSX_SW(c_, d) MSX_SW(a, c_) MSX_SW(b, d) MSX_SW(b, c_)
-#undef MSX_SW
-            node[4 * s] = a; node[4 * s + 1] = b; node[4 * s + 2] = c_; node[4 * s + 3] = d;
-        }
-        if (ok) {
+            for (int c = 0; c < NS * 4; ++c) { R->w[c] = w[c]; R->node[c] = node[c]; }
+            R->redc = redc;
+            R->status = MSX_W_OK;
             unsigned long long h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
             for (int c = 0; c < NS * 4; ++c) {
@@ -523,8 +520,9 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     plan_wave_pairs(tag, lane, &partner_lane, &leftover);
     const int partner_walker = __shfl((int)i, partner_lane >= 0 ? partner_lane : lane);
     const unsigned long long below = (1ull << lane) - 1ull;
+
     {   // the wave's pairs, leftover cards and singles into the workgroup's lists (one LDS atomic each per wave)
-        const unsigned long long bp = __ballot(partner_lane >= 0), bl = __ballot(leftover), bs = __ballot(mine && tag == 0ull);
+        const unsigned long long bp = __ballot(partner_lane >= 0), bl = __ballot(leftover), bs = 0ull;  // (no singles at this level)
         int basep = 0, basel = 0, bases = 0;
         if (lane == 0) {
             if (bp) basep = atomicAdd(&s_np, __popcll(bp));
@@ -537,7 +535,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         // (a workgroup's 1024 walkers: at most 512 wave-level pairs, 1024 cards, 1024 singles)
         if (partner_lane >= 0) s_pairs[basep + __popcll(bp & below)] = make_int2((int)i, partner_walker);
         if (leftover) s_cards[basel + __popcll(bl & below)] = (tag << 24) | (unsigned long long)(i + 1);
-        if (mine && tag == 0ull) s_left[bases + __popcll(bs & below)] = (unsigned long long)(i + 1);  // (singles: walker + 1, no tag)
+        (void)bases;
     }
     __syncthreads();
 #if defined(MSX_PLAN_EXP) && MSX_PLAN_EXP == 2
@@ -548,7 +546,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     int nc = s_nc;
     const int nsingle = s_ns;
     unsigned long long *src = s_cards, *dst = s_cards + kPlanSortMax / 2;
-    for (int round = 0; round < 4 && nc > 1; ++round) {  // (uniform)
+    for (int round = 0; round < 3 && nc > 1; ++round) {  // (uniform)
         if (tid == 0) s_nl = 0;
         __syncthreads();
         const int k = tid;  // (nc <= 1024 = the workgroup)
@@ -591,8 +589,15 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     if (tid == 0) {
         const int ticket = atomicAdd(&plan[4], 1);
         if (ticket == (int)gridDim.x - 1) {
-            plan[0] = atomicExch(&plan[2], 0);
-            plan[1] = atomicExch(&plan[3], 0);
+            const int np_all = atomicExch(&plan[2], 0), ns_all = atomicExch(&plan[3], 0);
+            plan[0] = np_all;
+            plan[1] = ns_all;
+            // ... and tells the host, which decides from it what the NEXT launches take (msx.hip, pair_worth_it): a word
+            // of host memory, written and forgotten
+            if (host_stats) {
+                __hip_atomic_store(host_stats, np_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_stats + 1, ns_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             atomicExch(&plan[4], 0);
         }
     }

@@ -440,7 +440,7 @@ __device__ __forceinline__ double iso_interp_lanes(const RecipeRegs &R, double x
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool h = R.isot[k] <= x && x < R.isot_n[k];
-        const double val = R.slope[k] * (x - R.isot[k]) + R.isog[k];
+        const double val = fma(R.slope[k], x - R.isot[k], R.isog[k]);  // (explicit: recipe_scalar must form the same bits)
         v = h ? val : v;
         hit = hit || h;
     }
@@ -607,6 +607,94 @@ __device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const Gat
         }
     }
     MSX_STAMP(P, wk, 11);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same recipe by ONE THREAD (pair_kernel.h's planner: one thread per walker, where throughput counts and the
+// walker's start-up latency does not): the tables in LDS, binary searches where the wave form ballots.  Operation for
+// operation the arithmetic of recipe_part1_regs -- the same expressions in the same order, so the same bits: a
+// walker's weights do not depend on which form computed them (tests/test_gpu_pair.py compares whole batches).
+// ------------------------------------------------------------------------------------------------
+struct ScalarTabs {
+    const double *isot, *isog, *teff, *logg;  // LDS copies of the recipe block
+    const unsigned int *pmask;
+    int niso, nt, ng;
+};
+// lane_bracket for the interval [nodes[l], nodes[l + 1]) that holds v (nodes[n] = +inf), l by binary search; below the
+// first node the wrap of recipe_part1_regs.  (v is finite: non-finite coordinates are rejected before, and a logg is
+// only used when its Teff lies inside the isochrone.)
+__device__ __forceinline__ int scalar_bracket(const double *nodes, int n, double v, int *i1, int *i2, double *e1, double *e2) {
+    if (!(v >= nodes[0])) {
+        *i1 = 0; *i2 = n - 1; *e1 = nodes[0]; *e2 = nodes[n - 1];
+        return MSX_W_OK;
+    }
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (nodes[mid] <= v) lo = mid; else hi = mid;
+    }
+    const double nl = nodes[lo], nn = lo + 1 < n ? nodes[lo + 1] : INFINITY;
+    const bool up = fabs(nn - v) < fabs(nl - v);
+    const bool eq = nl == v;
+    *i1 = up ? lo + 1 : lo;
+    *i2 = (up || eq) ? lo : lo + 1;
+    *e1 = up ? nn : nl;
+    *e2 = (up || eq) ? nl : nn;
+    return (!up && !eq && lo + 1 >= n) ? MSX_W_INDEXERROR : MSX_W_OK;
+}
+// One binary's recipe: node[8] (canonical order per star), w[8], redc; returns the walker's status (MSX_W_*), combined
+// over the two stars like logprob_kernel does.
+__device__ __forceinline__ int recipe_scalar2(const GateArgs &G, const ScalarTabs &T, int mode, const double (&t)[6],
+                                              int (&node)[8], double (&w)[8], double *redc) {
+    constexpr int NS = 2;
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) alive = alive && isfinite(t[k]);
+    if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) alive = prior_gates<NS>(G, t);
+    int stat[NS];
+#pragma unroll
+    for (int star = 0; star < NS; ++star) {
+        const double ts = t[star];
+        const double rs = star == 0 ? t[NS + 1] : t[NS + 1] * t[NS + 1 + star];
+        const double plx = t[2 * NS + 1];
+        const double q = fast_div(rs * kRsunCm, fast_div(1.0, plx) * kPcCm);  // mft6.py:690-691,700
+        const double sc = q * q;
+        int i1, i2, g1, g2;
+        double te1, te2, ge1, ge2;
+        const int st_t = scalar_bracket(T.teff, T.nt, ts, &i1, &i2, &te1, &te2);
+        const double bw = (i1 == i2) ? 0.0 : fast_div(ts - te1, te2 - te1);
+        int st = MSX_W_OK;
+        const bool in_iso = (ts >= T.isot[0]) && (ts <= T.isot[T.niso - 1]);
+        if (!in_iso) st = MSX_W_VALUEERROR;
+        double lg = T.isog[0];
+        if (in_iso) {
+            int lo = 0, hi = T.niso;  // the last i with isot[i] <= ts
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (T.isot[mid] <= ts) lo = mid; else hi = mid;
+            }
+            const double slope = lo + 1 < T.niso ? (T.isog[lo + 1] - T.isog[lo]) / (T.isot[lo + 1] - T.isot[lo]) : 0.0;
+            lg = fma(slope, ts - T.isot[lo], T.isog[lo]);  // mft6.py:1149
+        }
+        const int st_g = scalar_bracket(T.logg, T.ng, lg, &g1, &g2, &ge1, &ge2);
+        const double a = (g1 == g2) ? 0.0 : fast_div(lg - ge1, ge2 - ge1);
+        if (st == MSX_W_OK) st = st_t;
+        if (st == MSX_W_OK) st = st_g;
+        const unsigned int mA = T.pmask[i1], mB = T.pmask[i2];
+        const bool have = (((mA >> g1) & (mA >> g2) & (mB >> g1) & (mB >> g2)) & 1u) != 0u;
+        if (st == MSX_W_OK && !have) st = MSX_W_KEYERROR;
+        int nd[4] = {i1 * T.ng + g1, i1 * T.ng + g2, i2 * T.ng + g1, i2 * T.ng + g2};
+        double ww[4] = {(1.0 - bw) * (1.0 - a) * sc, (1.0 - bw) * a * sc, bw * (1.0 - a) * sc, bw * a * sc};
+        sort4_by_node(nd, ww);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { node[4 * star + c] = nd[c]; w[4 * star + c] = ww[c]; }
+        stat[star] = !alive ? MSX_W_REJECT : st;
+    }
+    *redc = redden_rule(mode, G.use_av, t[NS]) ? -0.4 * kLog2Of10 * t[NS] : 0.0;
+    int wst = stat[0];
+    wst = (wst == MSX_W_OK) ? stat[1] : wst;
+    wst = (wst != MSX_W_REJECT && stat[1] == MSX_W_VALUEERROR) ? MSX_W_VALUEERROR : wst;
+    return wst;
 }
 
 // Part 2 (off the critical path): the Gaussian prior terms (f1) and the contrast / photometry chi^2

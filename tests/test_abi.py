@@ -93,7 +93,7 @@ def test_python_constants_mirror_the_header():
              'MSX_MODE_LOGPRIOR': _lib.MODE_LOGPRIOR, 'MSX_BLOCK_512_SHARED': _lib.BLOCK_512_SHARED,
              'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_PAIR': _lib.PATH_PAIR,
              'MSX_PATH_LINKED': _lib.PATH_LINKED,
-             'MSX_HOOK_LINKED_FAULT': _lib.HOOK_LINKED_FAULT, 'MSX_HOOK_PAIR_THREADS': _lib.HOOK_PAIR_THREADS,
+             'MSX_HOOK_LINKED_FAULT': _lib.HOOK_LINKED_FAULT,
              'MSX_MAX_SPEC': _lib.MAX_SPEC, 'MSX_MAX_BANDS': _lib.MAX_BANDS, 'MSX_MAX_DIM': _lib.MAX_DIM}
     for name, val in pairs.items():
         assert defs[name] == val, name

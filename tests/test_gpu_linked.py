@@ -85,8 +85,8 @@ def test_linked_three_segments_against_the_oracle():
     e1.ctx.set_path(_lib.PATH_LINKED)
     with pytest.raises(_lib.MsxError):
         e1.loglikelihood(c.theta[:4])
-    with pytest.raises(_lib.MsxError):   # the split / wide forms of rounds 1-2 are gone
-        e1.ctx.set_path(2)
+    with pytest.raises(_lib.MsxError):   # the wide form of rounds 1-2 is gone (and 2, once the split form, is now the pair form)
+        e1.ctx.set_path(3)
 
 
 def _config4_engine():

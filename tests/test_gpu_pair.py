@@ -16,14 +16,12 @@ TIGHT = 1e-9
 
 
 def forms(eng, fn, *a, **k):
-    """fused, pair with 256 threads, pair with 512 threads"""
+    """fused, pair"""
     from mcmc_spec_amd import _lib
     eng.ctx.set_path(_lib.PATH_FUSED)
     out = [fn(*a, **k)]
     eng.ctx.set_path(_lib.PATH_PAIR)
-    for t in (256, 512):
-        eng.ctx.test_hook(_lib.HOOK_PAIR_THREADS, t)
-        out.append(fn(*a, **k))
+    out.append(fn(*a, **k))
     eng.ctx.set_path(_lib.PATH_AUTO)
     return out
 
@@ -65,16 +63,29 @@ def test_pair_values_do_not_depend_on_the_partner():
     f = outs[0]
     from mcmc_spec_amd import _lib
     eng.ctx.set_path(_lib.PATH_PAIR)
-    for t in (256, 512):
-        eng.ctx.test_hook(_lib.HOOK_PAIR_THREADS, t)
-        perm = rng.permutation(len(th))
-        assert np.array_equal(eng.logposterior(th[perm]), f[perm])
-        order = np.lexsort((th[:, 1] // 100, th[:, 0] // 100))     # neighbours in the batch mostly share their cell
-        assert np.array_equal(eng.logposterior(th[order]), f[order])
-        for n in (1, 2, 3, 8, 9):
-            assert np.array_equal(eng.logposterior(th[:n]), f[:n]), n
-        dup = np.repeat(th[:40], 2, axis=0)                       # every pair: the same walker twice
-        assert np.array_equal(eng.logposterior(dup), np.repeat(f[:40], 2))
+    perm = rng.permutation(len(th))
+    assert np.array_equal(eng.logposterior(th[perm]), f[perm])
+    order = np.lexsort((th[:, 1] // 100, th[:, 0] // 100))     # neighbours in the batch mostly share their cell
+    assert np.array_equal(eng.logposterior(th[order]), f[order])
+    npairs, nsingles = eng.ctx.pair_stats()
+    assert 2 * npairs + nsingles == np.isfinite(f).sum() and npairs > 300   # every live walker exactly once
+    for n in (1, 2, 3, 8, 9):
+        assert np.array_equal(eng.logposterior(th[:n]), f[:n]), n
+    dup = np.repeat(th[:40], 2, axis=0)                       # every pair: the same walker twice
+    assert np.array_equal(eng.logposterior(dup), np.repeat(f[:40], 2))
+    spread = th.copy()                                        # spread over the whole grid: 144 cell combinations
+    spread[:, 0] = rng.uniform(3001.0, 4199.0, len(th))
+    spread[:, 1] = rng.uniform(3001.0, 4199.0, len(th))
+    want = eng.logposterior(spread)
+    few = eng.ctx.pair_stats()
+    one_each = spread[:140].copy()                            # every walker a cell of its own: nothing to pair
+    one_each[:, 0] = 3005.0 + 100.0 * (np.arange(140) % 12)
+    one_each[:, 1] = 3005.0 + 100.0 * (np.arange(140) // 12)
+    want1 = eng.logposterior(one_each)
+    assert eng.ctx.pair_stats() == (0, int(np.isfinite(want1).sum()))
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    assert np.array_equal(eng.logposterior(spread), want) and few[0] < npairs
+    assert np.array_equal(eng.logposterior(one_each), want1)
 
 
 def test_pair_error_statuses_and_problems_without_a_pair_form():
@@ -174,3 +185,33 @@ def test_pair_median_exits(shape):
         want = np.array([orc.loglikelihood(list(t), fr, 2, data, err, r, specs, ctm, ptm, 6000.0, 8800.0, matrix)
                          for t in th[:3]])
         assert rel_err(outs[1][:3], want).max() < TIGHT, (shape, npix)
+
+
+def test_auto_choice_never_changes_values():
+    """MSX_PATH_AUTO takes the pair form from 4,096 walkers on while the planner's last count says pairing pays, the
+    fused kernel while it says the ensemble is spread over the grid, and looks again every 32nd launch: whatever it takes,
+    in whatever order the two kinds of batches arrive, the values are the fused kernel's."""
+    import bench
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    W = bench.build_workload(eng, 1194, False)
+    n = 4200
+    near = synth.draw_walkers(n, seed=21, tmin=W['tmin'], tmax=W['tmax'])
+    far = near.copy()
+    far[:, 0:2] = np.random.default_rng(5).uniform(W['tmin'] + 1, W['tmax'] - 1, size=(n, 2))
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    want_near, want_far = eng.logposterior(near), eng.logposterior(far)
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    assert np.array_equal(eng.logposterior(near), want_near)
+    p, s = eng.ctx.pair_stats()
+    assert 2 * p + s == n and 4 * s < 3 * p                   # the pair form ran, and it paid
+    assert np.array_equal(eng.logposterior(far), want_far)    # still the pair form (the count came from `near`) ...
+    p, s = eng.ctx.pair_stats()
+    assert 2 * p + s == np.isfinite(want_far).sum() and 4 * s >= 3 * p   # ... which now says: spread
+    for _ in range(40):                                       # the fused kernel, with a look through the pair form in between
+        assert np.array_equal(eng.logposterior(far), want_far)
+    for _ in range(40):                                       # back to an ensemble in a few cells: found at the next look
+        assert np.array_equal(eng.logposterior(near), want_near)
+    p, s = eng.ctx.pair_stats()
+    assert 4 * s < 3 * p

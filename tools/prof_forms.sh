@@ -11,7 +11,7 @@ for cs in ${cases//,/ }; do
   npix=${cs%%:*}; n=${cs##*:}
   extra=""; [ "$npix" = "16384" ] && extra="--phot"
   for path in ${PATHS:-fused}; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $out/${npix}_${n}_$path -o kt -- python3 $root/tools/sweep.py --npix $npix $extra --walkers $n --blocks 0 --paths $path --iters 20 > $out/${npix}_${n}_$path.json 2> $out/${npix}_${n}_$path.err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/${npix}_${n}_$path -o kt -- python3 $root/tools/sweep.py --npix $npix $extra --walkers $n --blocks 0 --paths $path --iters 20 ${SWEEP_EXTRA:-} > $out/${npix}_${n}_$path.json 2> $out/${npix}_${n}_$path.err
     f=$(find $out/${npix}_${n}_$path -name '*kernel_stats.csv' | head -1)
     echo "== npix $npix walkers $n path $path"; cat $out/${npix}_${n}_$path.json
     [ -n "$f" ] && python3 - "$f" <<'PY'
