@@ -146,10 +146,11 @@ constexpr unsigned long long kHandoverTicks = 2000000ull;  // linked path: a joi
 struct alignas(16) PairRec {
     double w[kMaxCorners > 8 ? 8 : kMaxCorners];  // bilinear weight x (R/d)^2 per corner, canonical (sorted-node) order
     double redc;                                  // exp2 coefficient of the reddening; 0: none
+    double lp, chi_extra;                         // the Gaussian prior terms; icontrast + iphot
     int32_t node[8];
     int32_t status, pad;
 };
-static_assert(sizeof(PairRec) == 112, "PairRec layout");
+static_assert(sizeof(PairRec) == 128, "PairRec layout");
 
 // linked form: what a producer leaves per (walker, segment) for the walker's joiner
 struct alignas(16) SegPart {

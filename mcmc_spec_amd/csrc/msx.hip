@@ -400,7 +400,7 @@ int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
     const int32_t *plan = c->d_pair_plan;
     hipLaunchKernelGGL(pair_plan_kernel, dim3((unsigned)((A.n + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, A.s, A.theta,
                        (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax,
-                       c->d_pair_plan, c->pair_rows, c->d_pair_rec, A.logp, A.status, c->h_pair_stats);
+                       c->d_pair_plan, c->pair_rows, c->d_pair_rec, A.logp, A.status, c->h_pair_stats, P);
     HIP_TRY(c, hipGetLastError());
     // 2. the planner's items: singles + pairs <= n workgroups; those beyond the planner's count leave after one load
     const dim3 g((unsigned)A.n);

@@ -71,7 +71,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
     __shared__ BlockScratch S[2];
     __shared__ double red[2][3][nw][kWave];
     __shared__ double e2tab[kExp2Tab];
-    struct WalkerLoc { double pc[3]; unsigned long long kmin, kmax; LogbinSel Q; int bad, appl; };
+    struct WalkerLoc { double pc[3]; unsigned long long kmin, kmax; LogbinSel Q; int bad, appl; unsigned int fsel, fspan; };
     __shared__ WalkerLoc Loc[2];
     const int mode = (ng_mode_fast >> 8) & 0xff;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
@@ -99,9 +99,11 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         const PairRec *R = P.pair_rec + wk;
         D[wave0].node[lane0] = R->node[lane0];
         D[wave0].w[lane0] = R->w[lane0];
-        if (lane0 == 0) D[wave0].redc = R->redc;
+        if (lane0 == 0) { D[wave0].redc = R->redc; D[wave0].lp = R->lp; D[wave0].chi_extra = R->chi_extra; }
     }
     fill_exp2_table(e2tab, tid0 - (B - kWave));
+    for (int i = tid0; i < kLogBins; i += B) { S[0].hist[i] = 0; S[1].hist[i] = 0; }
+    if (tid0 < 2) { S[tid0].cand_n = 0; S[tid0].has_second = 0; }
     __syncthreads();
     const bool act0 = true, act1 = wkv[1] >= 0;
     bool same = act1;
@@ -114,15 +116,17 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
 
     // The evaluation proper, compiled twice: for two walkers (machinery slot 0 = walker sa, slot 1 = walker sb) and
     // for one (the second slot's arithmetic, state and barriers' work compiled out).
-    auto body = [&](auto two_c, const int sa, const int sb) __attribute__((always_inline)) {
+    auto body = [&](auto two_c, const int sa, const int sb, const bool again) __attribute__((always_inline)) {
         constexpr bool two = decltype(two_c)::value;
         constexpr int NSLOT = two ? 2 : 1;
         const int tid = tid0, lane = lane0, wave = wave0;
         const int64_t wk0 = wkv[sa], wk1 = wkv[sb];
         const WalkerDesc &Da = D[sa], &Db = D[sb];
-        for (int i = tid; i < kLogBins; i += B) { S[0].hist[i] = 0; if (two) S[1].hist[i] = 0; }
-        if (tid < 2) { S[tid].cand_n = 0; S[tid].has_second = 0; }
-        __syncthreads();
+        if (again) {  // (a second evaluation by this workgroup: the LDS state of the first is stale)
+            for (int i = tid; i < kLogBins; i += B) S[0].hist[i] = 0;
+            if (tid == 0) { S[0].cand_n = 0; S[0].has_second = 0; }
+            __syncthreads();
+        }
 
         // ---- phase A: blend + redden + resample, two weight chains per loaded element ---------------------------
         const double2 *rows_r[NC];
@@ -291,6 +295,16 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
                 Loc[s].kmin = k0; Loc[s].kmax = k1;
                 Loc[s].Q = Qs;
                 Loc[s].bad = bd; Loc[s].appl = ap;
+                // The candidates' test as ONE range check.  The vector is positive and spans < 8 binades, so the
+                // UNMASKED bin number F(x) = hi32(x) >> 12 is monotone in x and unique per physical bin:
+                // F(bin p) = F(min) + ((p - F(min)) mod 2048).  nxt_p is the next NON-EMPTY bin after sel_p: a value
+                // lies in one of the two iff F(sel) <= F(x) <= F(nxt) -- there is nothing in between.
+                const unsigned int fmin = (unsigned int)__double2hiint(val_of(k0)) >> 12;
+                const unsigned int fsel = fmin + ((Qs.sel_p - fmin) & (unsigned int)(kLogBins - 1));
+                const unsigned int fnxt = fmin + ((Qs.nxt_p - fmin) & (unsigned int)(kLogBins - 1));
+                Loc[s].fsel = ap ? fsel : 1u;
+                Loc[s].fspan = ap ? fnxt - fsel : 0u;   // (not applicable: F(x) - 1 <= 0 never holds for a positive x ... and
+                                                         //  `appl` gates the test anyway)
             }
         });
         __syncthreads();
@@ -298,12 +312,14 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         unsigned long long kmin[2], kmax[2];
         bool bad[2], appl[2];
         LogbinSel Q[2];
+        unsigned int fsel[2], fspan[2];
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
             constexpr int s = decltype(s_c)::value;
             pc[s][0] = Loc[s].pc[0]; pc[s][1] = Loc[s].pc[1]; pc[s][2] = Loc[s].pc[2];
             kmin[s] = Loc[s].kmin; kmax[s] = Loc[s].kmax;
             Q[s] = Loc[s].Q;
             bad[s] = Loc[s].bad != 0; appl[s] = Loc[s].appl != 0;
+            fsel[s] = Loc[s].fsel; fspan[s] = Loc[s].fspan;
         });
 
         // ---- ONE pass over the registers: chi^2 terms of both walkers from one load of u, data flux and 1/err^2,
@@ -331,8 +347,8 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     acc[s][kbase + u] += chi_term(pc[s][0], pc[s][1], pc[s][2], uu[u], ff[u], ee[u], xv[u], livep[u]);
-                    const unsigned int pb = logbin(xv[u]);
-                    if (appl[s] && livep[u] && (pb == Q[s].sel_p || pb == Q[s].nxt_p))
+                    const unsigned int fx = (unsigned int)__double2hiint(xv[u]) >> 12;
+                    if (appl[s] && livep[u] && fx - fsel[s] <= fspan[s])
                         S[s].cand[atomicAdd(&S[s].cand_n, 1u)] = key_of(xv[u]);
                 }
             });
@@ -343,18 +359,10 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         if (two) red[1][0][wave][lane] = lane_partial<vk>(acc[1]);
         __syncthreads();
 
-        // ---- rank (wave s ranks walker s's candidates), meanwhile the contrast / photometry and prior terms -------
+        // ---- rank: wave s ranks walker s's candidates ------------------------------------------------------------------
         double med[2] = {0.0, 0.0};
         if (appl[0]) med[0] = logbin_rank<MAXT>(S[0], Q[0], need_two, 0);
         if (two && appl[1]) med[1] = logbin_rank<MAXT>(S[1], Q[1], need_two, 1);
-        if (wave == 2) {
-            recipe_band_terms<NS>(P, mode, theta + wk0 * ndim, D[sa], lane);
-            recipe_prior_terms<NS>(P, mode, theta + wk0 * ndim, D[sa], lane);
-        }
-        if (wave == 3 && two) {
-            recipe_band_terms<NS>(P, mode, theta + wk1 * ndim, D[sb], lane);
-            recipe_prior_terms<NS>(P, mode, theta + wk1 * ndim, D[sb], lane);
-        }
         // vectors the early histogram cannot handle (not positive, >= 8 binades, > 256 equal-bin candidates): the
         // model values go to the walker's scratch row and block_median (linear bins, radix fallback) reads them there
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
@@ -376,7 +384,8 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             bool unused = false;
             med[s] = block_median<MAXT>(row, npix, kmin[s], kmax[s], S[s], NoSide(), no_elem, &unused);
         });
-        __syncthreads();  // D.chi_extra, D.lp (waves 2 and 3)
+        // (no barrier: wave s has its walker's median in registers and the chi^2 partials were published before the pass's
+        // barrier; the other waves are done)
 
         // ---- combine (wave s finishes walker s) ---------------------------------------------------------------------
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
@@ -399,13 +408,13 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         });
     };
     if (same) {
-        body(std::true_type{}, 0, 1);
+        body(std::true_type{}, 0, 1, false);
     } else {
         // the live ones one after the other -- two more inlined copies of the one-walker body, not a loop: as the body of
         // a loop the compiler keeps the sweeps' unrolled state alive around the back edge and spills all of it
-        if (act0) body(std::false_type{}, 0, 0);
+        if (act0) body(std::false_type{}, 0, 0, false);
         __syncthreads();  // a second evaluation re-uses the LDS state
-        if (act1) body(std::false_type{}, 1, 1);
+        if (act1) body(std::false_type{}, 1, 1, true);
     }
 }
 
@@ -416,8 +425,10 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
 //   1. inside each WAVE, by ballots: the lanes of one tag pair up in lane order (no memory traffic at all);
 //   2. what a wave cannot place -- at most one walker per cell -- meets the other waves' leftovers inside the WORKGROUP:
 //      a short list of cards in LDS, 64 to a wave, the same ballots again, for a few rounds;
-//   3. what a workgroup cannot place -- at most one walker per cell -- is a single (16 workgroups of 1024 walkers x a
-//      handful of cells in a batch of 16,384: under 1 %; a global third level cost more than it placed).
+//   3. what a workgroup cannot place -- at most one walker per cell -- is a single (64 workgroups of 256 walkers x a
+//      handful of cells in a batch of 16,384: 232 singles, 1.4 %; a global third level cost more than it placed, and
+//      workgroups of 512 / 1024 walkers -- 124 / 72 singles -- spend longer planning than their pairs save: the planner
+//      is a chain of dependent steps per thread, 341.1 / 346.0 us per batch against 340.2).
 // Per workgroup: one global atomic add for its pairs, one for its singles.  Walkers the prior box rejects or whose
 // recipe will fail are singles from the start.  Pairs and singles are ONE list of items for
 // logprob_pair_kernel (singles first: a lone walker's workgroup is the longest, it starts at once).  Who meets whom
@@ -425,7 +436,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
 // file).  And a cell mis-computed here costs time, not correctness: the pair kernel compares the real recipes and
 // evaluates walkers that differ one after the other.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPlanThreads = 1024;
+constexpr int kPlanThreads = 256;
 constexpr int kPlanCells = 12;
 constexpr int kPlanSortMax = 2048;  // capacity of the workgroup's card list (1024 walkers: at most 1024 cards)
 
@@ -456,9 +467,10 @@ __device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane
 __global__ void __launch_bounds__(kPlanThreads)
 pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
                  double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, int64_t cap, PairRec *__restrict__ rec,
-                 double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats) {
+                 double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats, DevProblem P) {
     constexpr int NS = 2, ndim = 6;
-    __shared__ double s_isot[4 * kWave], s_isog[4 * kWave], s_teff[kWave], s_logg[32];
+    __shared__ double s_isot[4 * kWave], s_isog[4 * kWave], s_isol[4 * kWave], s_teff[kWave], s_logg[32];
+    __shared__ double s_ave[2 * kWave], s_avm[2 * kWave], s_avs[2 * kWave];
     __shared__ unsigned int s_pmask[kWave];
     __shared__ unsigned long long s_cards[kPlanSortMax];
     __shared__ int2 s_pairs[kPlanSortMax / 2];
@@ -473,7 +485,9 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     {
         const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT), *g_isog = reinterpret_cast<const double *>(rblk + kRbIsoG);
         const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
-        if (tid < niso) { s_isot[tid] = g_isot[tid]; s_isog[tid] = g_isog[tid]; }
+        if (tid < niso) { s_isot[tid] = g_isot[tid]; s_isog[tid] = g_isog[tid]; s_isol[tid] = P.iso_l[tid]; }
+        if (tid < P.nav + 1) s_ave[tid] = P.av_edges[tid];
+        if (tid < P.nav) { s_avm[tid] = P.av_mu[tid]; s_avs[tid] = P.av_sig[tid]; }
         if (tid < nt) { s_teff[tid] = g_teff[tid]; s_pmask[tid] = reinterpret_cast<const unsigned int *>(rblk + kRbPresent)[tid]; }
         if (tid < ng) s_logg[tid] = g_logg[tid];
         if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
@@ -500,6 +514,12 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
             for (int c = 0; c < NS * 4; ++c) { R->w[c] = w[c]; R->node[c] = node[c]; }
             R->redc = redc;
             R->status = MSX_W_OK;
+            // what only the walker's last line reads: the Gaussian prior terms (f1) and the contrast / photometry
+            // chi^2 (A5/A6) -- here and not by two waves of the pair kernel, whose workgroup would wait for their table
+            // round trips after its median is long done
+            const ScalarPriorTabs TP = {s_isot, s_isol, s_ave, s_avm, s_avs};
+            R->lp = prior_terms_scalar2(P, TP, mode, t);
+            R->chi_extra = band_terms_scalar2(P, mode, t, node, w);
             unsigned long long h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
             for (int c = 0; c < NS * 4; ++c) {
@@ -549,7 +569,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     for (int round = 0; round < 3 && nc > 1; ++round) {  // (uniform)
         if (tid == 0) s_nl = 0;
         __syncthreads();
-        const int k = tid;  // (nc <= 1024 = the workgroup)
+        const int k = tid;  // (nc <= kPlanThreads)
         const unsigned long long cd = k < nc ? src[k] : 0ull;
         int pl;
         bool lo;
@@ -576,7 +596,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     if (tid == 0) s_nl = nc;
     __syncthreads();
     // ---- the workgroup's lists to global memory: one atomic add per list.  What the workgroup could not place -- at
-    //      most one walker per cell -- is a single: 16 workgroups x a handful of cells in 16,384 walkers. ---------------
+    //      most one walker per cell -- is a single. --------------------------------------------------------------------
     const int np = s_np, nl = s_nl;
     if (tid == 0) s_basep = np ? atomicAdd(&plan[2], np) : 0;
     if (tid == 1) s_basel = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;

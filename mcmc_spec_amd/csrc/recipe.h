@@ -362,6 +362,62 @@ __device__ __forceinline__ double pick2(const double (&r)[2], int idx) {  // idx
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// ---- the arithmetic of the prior and band terms, in ONE place: the wave forms below (tables in registers, lanes) and
+// the one-thread forms of the pair form's planner (tables in LDS, loops) fetch their operands differently and then call
+// these, so that a walker's terms have the same bits whichever form computed them -------------------------------------
+__device__ __forceinline__ double interp_segment(double x0, double y0, double x1, double y1, double x) {  // np.interp, x0 <= x < x1
+    if (x0 == x) return y0;
+    const double slope = (y1 - y0) / (x1 - x0);
+    return fma(slope, x - x0, y0);
+}
+__device__ __forceinline__ double gauss_term(double lp, double x, double mean, double sig) {  // lp - 0.5 ((x - mean) / sig)^2
+    const double z = (x - mean) / sig;
+    return lp + -0.5 * (z * z);
+}
+__device__ __forceinline__ double model_radius(double lum, double teff) {  // get_radius, mft6.py:66-85 (Stefan-Boltzmann)
+    const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
+    const double t2 = teff * teff;
+    return sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+}
+__device__ __forceinline__ double radius_term(double lp, double rad, double target) {  // mft6.py:1262-1269
+    const double z = (rad - target) / (0.02 * target);
+    return lp + -0.5 * (z * z);
+}
+// magnitude of one "job" of the band terms: job < nc NS = (contrast filter f, star s), else photometric band f
+template <int NS>
+__device__ __forceinline__ double band_job_value(const DevProblem &P, const int *node, const double *w, int job) {
+    const int nb = P.nc + P.np;
+    if (job < P.nc * NS) {
+        const int f = job / NS, s = job - f * NS;
+        double m = 0.0;
+        for (int c = 0; c < 4; ++c) m += w[4 * s + c] * P.band_tab[(int64_t)node[4 * s + c] * nb + f];
+        return -2.5 * log10(m);  // mft6.py:733
+    }
+    const int f = job - P.nc * NS;
+    double flux = 0.0;
+    for (int c = 0; c < NS * 4; ++c) flux += w[c] * P.band_tab[(int64_t)node[c] * nb + P.nc + f];
+    return -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+}
+// icontrast + iphot from the jobs' magnitudes (val(k) = magnitude of job k)
+template <int NS, class V>
+__device__ __forceinline__ double band_chi(const DevProblem &P, bool redden, double a_v, V val) {
+    double chi = 0.0;
+    for (int f = 0; f < P.nc; ++f) {
+        int sec = 1;
+        if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
+        const double con = val(f * NS + sec) - val(f * NS);  // mft6.py:741
+        const double z = con - P.cmag[f];
+        chi += (z * z) * P.civar[f];  // mft6.py:120,1182
+    }
+    for (int f = 0; f < P.np; ++f) {
+        const double mag = val(P.nc * NS + f);
+        const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
+        const double z = mred - P.pmag[f];
+        chi += (z * z) * P.pivar[f];  // mft6.py:1188
+    }
+    return chi;
+}
+
 // np.interp on a register-resident table (search by count; the radius prior's luminosity lookup); caller checked the range
 __device__ __forceinline__ double iso_interp_regs(const double (&xs)[4], const double (&ys)[4], int n, double x) {
     int cnt = 0;
@@ -369,10 +425,7 @@ __device__ __forceinline__ double iso_interp_regs(const double (&xs)[4], const d
     for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(xs[k] <= x));  // pads are +inf
     const int j = uni(cnt) - 1;
     if (j >= n - 1) return pick4(ys, n - 1);
-    const double x0 = pick4(xs, j), y0 = pick4(ys, j);
-    if (x0 == x) return y0;
-    const double slope = (pick4(ys, j + 1) - y0) / (pick4(xs, j + 1) - x0);
-    return slope * (x - x0) + y0;
+    return interp_segment(pick4(xs, j), pick4(ys, j), pick4(xs, j + 1), pick4(ys, j + 1), x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,16 +780,12 @@ __device__ __forceinline__ void recipe_prior_terms(const DevProblem &P, int mode
             b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
             double sig = pick2(avs, b);
             if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
-            const double z = (a_v - pick2(avm, b)) / sig;
-            lp += -0.5 * (z * z);
+            lp = gauss_term(lp, a_v, pick2(avm, b), sig);
         }
         if (P.has_prior) {
 #pragma clang loop unroll(full)
             for (int k = 0; k < 2 * NS + 2; ++k) {
-                if (P.pmean[k] != 0.0) {  // mft6.py:1258
-                    const double z = (t[k] - P.pmean[k]) / P.psig[k];
-                    lp += -0.5 * (z * z);
-                }
+                if (P.pmean[k] != 0.0) lp = gauss_term(lp, t[k], P.pmean[k], P.psig[k]);  // mft6.py:1258
             }
         }
         if (P.rad_prior) {  // mft6.py:1262-1269
@@ -753,17 +802,10 @@ __device__ __forceinline__ void recipe_prior_terms(const DevProblem &P, int mode
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (!(t[s] >= iso_lo) || !(t[s] <= iso_hi)) { st = MSX_W_VALUEERROR; mr[s] = 1.0; continue; }
-                const double lum = iso_interp_regs(isot, isol, P.niso, t[s]);
-                const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
-                const double t2 = t[s] * t[s];
-                mr[s] = sqrt(lum * lsun / (4 * M_PI * sigma_sb * (t2 * t2))) / kRsunCm;  // mft6.py:83
+                mr[s] = model_radius(iso_interp_regs(isot, isol, P.niso, t[s]), t[s]);
             }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double target = (s == 0) ? mr[0] : mr[s] / mr[0];
-                const double z = (rad[s] - target) / (0.02 * target);
-                lp += -0.5 * (z * z);
-            }
+            for (int s = 0; s < NS; ++s) lp = radius_term(lp, rad[s], (s == 0) ? mr[0] : mr[s] / mr[0]);
         }
     }
     if (lane == 0) {
@@ -777,37 +819,67 @@ __device__ __forceinline__ void recipe_band_terms(const DevProblem &P, int mode,
                                   int lane) {
     const double a_v = th[NS];
     const bool redden = redden_rule(mode, P.use_av, a_v);
-    const int nb = P.nc + P.np;
     const int njobs = P.nc * NS + P.np;
     double val = 0.0;
-    if (lane < njobs) {  // one (filter, star) or one photometric band per lane
-        if (lane < P.nc * NS) {
-            const int f = lane / NS, s = lane - f * NS;
-            double m = 0.0;
-            for (int c = 0; c < 4; ++c) m += D.w[4 * s + c] * P.band_tab[(int64_t)D.node[4 * s + c] * nb + f];
-            val = -2.5 * log10(m);  // mft6.py:733
-        } else {
-            const int f = lane - P.nc * NS;
-            double flux = 0.0;
-            for (int c = 0; c < NS * 4; ++c) flux += D.w[c] * P.band_tab[(int64_t)D.node[c] * nb + P.nc + f];
-            val = -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
+    if (lane < njobs) val = band_job_value<NS>(P, D.node, D.w, lane);  // one (filter, star) or one photometric band per lane
+    const double chi = band_chi<NS>(P, redden, a_v, [&](int k) __attribute__((always_inline)) { return readlane_f64(val, k); });
+    if (lane == 0) D.chi_extra = chi;
+}
+
+// ---- the one-thread forms (pair_kernel.h's planner) ---------------------------------------------------------------------
+struct ScalarPriorTabs {
+    const double *isot, *isol;               // isochrone Teff, luminosity (LDS)
+    const double *av_edges, *av_mu, *av_sig;  // the A_V(distance) table (LDS)
+};
+// the Gaussian prior terms (f1) of a binary in LOGPOST mode: recipe_prior_terms by one thread
+__device__ __forceinline__ double prior_terms_scalar2(const DevProblem &P, const ScalarPriorTabs &T, int mode, const double (&t)[6]) {
+    constexpr int NS = 2;
+    const double a_v = t[NS], plx = t[2 * NS + 1];
+    const double *rad = &t[NS + 1];
+    double lp = 0.0;
+    if (!(mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) return lp;
+    if (P.use_av && P.nav > 0) {
+        const double d = 1.0 / plx;  // pc, mft6.py:1233
+        int lo = -1, hi = P.nav + 1;  // b = #{edges <= d} - 1
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.av_edges[mid] <= d) lo = mid; else hi = mid; }
+        int b = lo;
+        b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
+        double sig = T.av_sig[b];
+        if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
+        lp = gauss_term(lp, a_v, T.av_mu[b], sig);
+    }
+    if (P.has_prior) {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < 2 * NS + 2; ++k) {
+            if (P.pmean[k] != 0.0) lp = gauss_term(lp, t[k], P.pmean[k], P.psig[k]);  // mft6.py:1258
         }
     }
-    double chi = 0.0;
-    for (int f = 0; f < P.nc; ++f) {
-        int sec = 1;
-        if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
-        const double con = readlane_f64(val, f * NS + sec) - readlane_f64(val, f * NS);  // mft6.py:741
-        const double z = con - P.cmag[f];
-        chi += (z * z) * P.civar[f];  // mft6.py:120,1182
+    if (P.rad_prior) {  // mft6.py:1262-1269 (a Teff outside the isochrone has failed the walker already)
+        double mr[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!(t[s] >= T.isot[0]) || !(t[s] <= T.isot[P.niso - 1])) { mr[s] = 1.0; continue; }
+            int lo = -1, hi = P.niso;  // j = #{isot <= x} - 1
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.isot[mid] <= t[s]) lo = mid; else hi = mid; }
+            const int j = lo;
+            const double lum = j >= P.niso - 1 ? T.isol[P.niso - 1] : interp_segment(T.isot[j], T.isol[j], T.isot[j + 1], T.isol[j + 1], t[s]);
+            mr[s] = model_radius(lum, t[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) lp = radius_term(lp, rad[s], (s == 0) ? mr[0] : mr[s] / mr[0]);
     }
-    for (int f = 0; f < P.np; ++f) {
-        const double mag = readlane_f64(val, P.nc * NS + f);
-        const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
-        const double z = mred - P.pmag[f];
-        chi += (z * z) * P.pivar[f];  // mft6.py:1188
-    }
-    if (lane == 0) D.chi_extra = chi;
+    return lp;
+}
+// icontrast + iphot of a binary: recipe_band_terms by one thread
+__device__ __forceinline__ double band_terms_scalar2(const DevProblem &P, int mode, const double (&t)[6], const int (&node)[8],
+                                                     const double (&w)[8]) {
+    constexpr int NS = 2;
+    const double a_v = t[NS];
+    const bool redden = redden_rule(mode, P.use_av, a_v);
+    const int njobs = P.nc * NS + P.np;
+    double val[MSX_MAX_BANDS * NS + MSX_MAX_BANDS];
+    for (int k = 0; k < njobs; ++k) val[k] = band_job_value<NS>(P, node, w, k);
+    return band_chi<NS>(P, redden, a_v, [&](int k) __attribute__((always_inline)) { return val[k]; });
 }
 
 }  // namespace
