@@ -83,7 +83,8 @@ struct DevProblem {
     int32_t *seg_flag;         // [rows] linked form: producers that have published their segment (the joiner resets it)
     int32_t *linked_poison;    // linked form: != 0 once a hand-over has timed out on this context -- every later linked
                                // launch fails all its walkers with MSX_W_HANDOVER until msx_stage_problem clears it
-    const struct PairRec *pair_rec;  // pair form: [rows] the planner's recipes
+    const struct PairItem *pair_items;   // pair form: [rows / 2] the planner's pairs, recipes included
+    const struct PairRec *pair_singles;  // ... and [rows] its singles
     int32_t linked_fault;      // test hook (msx_test_hook / MSX_LINKED_FAULT=1): producers skip the increment, joiners must time out
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
@@ -148,9 +149,10 @@ struct alignas(16) PairRec {
     double redc;                                  // exp2 coefficient of the reddening; 0: none
     double lp, chi_extra;                         // the Gaussian prior terms; icontrast + iphot
     int32_t node[8];
-    int32_t status, pad;
+    int32_t walker, pad;                          // index in the (sub-)batch
 };
 static_assert(sizeof(PairRec) == 128, "PairRec layout");
+struct alignas(16) PairItem { PairRec r[2]; };    // two walkers of one grid cell
 
 // linked form: what a producer leaves per (walker, segment) for the walker's joiner
 struct alignas(16) SegPart {

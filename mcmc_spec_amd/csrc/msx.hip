@@ -125,7 +125,8 @@ struct msx_ctx {
     // shared loads save), 4,096: 111.8 against 121.2, 8,192: 188.7 against 225.1, 16,384: 344.8 against 438.3.
     int64_t pair_min_walkers = 4096;
     int32_t *d_pair_plan = nullptr; // the planner's output (pair_kernel.h: header, pairs, singles)
-    PairRec *d_pair_rec = nullptr;  // ... and its recipes, one per walker of a sub-batch
+    PairItem *d_pair_items = nullptr;   // ... and its items: the pairs' recipes, [pair_rows / 2]
+    PairRec *d_pair_singles = nullptr;  // ... the singles', [pair_rows]
     // {pairs, singles} of the planner's last run, written by the device into host memory and read here WITHOUT waiting
     // for it (so possibly a launch or two old): MSX_PATH_AUTO's only evidence of whether pairing pays (pair_worth_it)
     int32_t *h_pair_stats = nullptr;
@@ -213,11 +214,11 @@ void free_problem(msx_ctx *c) {
     c->opt_chains = 0;
     if (c->h_pair_stats) (void)hipHostFree(c->h_pair_stats);
     c->h_pair_stats = nullptr;
-    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_rec};
+    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_items, c->d_pair_singles};
     for (void *p : sp)
         if (p) (void)hipFree(p);
     c->d_segparts = nullptr; c->d_seg_flag = nullptr; c->d_model_scratch = nullptr; c->scratch_rows = 0;
-    c->d_pair_plan = nullptr; c->d_pair_rec = nullptr; c->pair_rows = 0;
+    c->d_pair_plan = nullptr; c->d_pair_items = nullptr; c->d_pair_singles = nullptr; c->pair_rows = 0;
     c->linked_poisoned = false;
 }
 
@@ -400,14 +401,14 @@ int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
     const int32_t *plan = c->d_pair_plan;
     hipLaunchKernelGGL(pair_plan_kernel, dim3((unsigned)((A.n + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, A.s, A.theta,
                        (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax,
-                       c->d_pair_plan, c->pair_rows, c->d_pair_rec, A.logp, A.status, c->h_pair_stats, P);
+                       c->d_pair_plan, c->d_pair_items, c->d_pair_singles, A.logp, A.status, c->h_pair_stats, P);
     HIP_TRY(c, hipGetLastError());
     // 2. the planner's items: singles + pairs <= n workgroups; those beyond the planner's count leave after one load
     const dim3 g((unsigned)A.n);
     const int64_t ne = P.npair;
 #define MSX_PAIR_GO2(T_, NT_, RED_)                                                                                   \
     hipLaunchKernelGGL((logprob_pair_kernel<T_, NT_, RED_>), g, dim3(T_), 0, A.s, A.theta, (const unsigned char *)c->d_recipe_block, \
-                       A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status, c->pair_rows)
+                       A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status)
 #define MSX_PAIR_GO(T_, NT_) do { if (P.use_av) MSX_PAIR_GO2(T_, NT_, true); else MSX_PAIR_GO2(T_, NT_, false); } while (0)
     // (512 threads, two workgroups per CU at <= 128 VGPRs: 16 waves per CU.  The 256-thread variants -- two per CU at
     // 256 VGPRs, 8 waves -- measured 411.8 us against 344.8 at 16,384 walkers and are not built.)
@@ -844,11 +845,13 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         if (const char *e = getenv("MSX_PAIR_ROWS")) rows = std::max<int64_t>(2, atoll(e));
         HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * rows * p->npix));
         P.model_scratch = c->d_model_scratch;
-        const size_t plan_bytes = sizeof(int32_t) * (size_t)(kPairHdrInts + 3 * rows);
+        const size_t plan_bytes = sizeof(int32_t) * (size_t)kPairHdrInts;
         HIP_TRY(c, hipMalloc((void **)&c->d_pair_plan, plan_bytes));
         HIP_TRY(c, hipMemset(c->d_pair_plan, 0, plan_bytes));
-        HIP_TRY(c, hipMalloc((void **)&c->d_pair_rec, sizeof(PairRec) * (size_t)rows));
-        P.pair_rec = c->d_pair_rec;
+        HIP_TRY(c, hipMalloc((void **)&c->d_pair_items, sizeof(PairItem) * (size_t)((rows + 1) / 2)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_pair_singles, sizeof(PairRec) * (size_t)rows));
+        P.pair_items = c->d_pair_items;
+        P.pair_singles = c->d_pair_singles;
         HIP_TRY(c, hipHostMalloc((void **)&c->h_pair_stats, 2 * sizeof(int32_t), hipHostMallocDefault));
         c->h_pair_stats[0] = 1; c->h_pair_stats[1] = 0;  // (nothing known yet: try)
         c->pair_auto_launches = 0;

@@ -36,10 +36,10 @@
 namespace {
 
 constexpr int kPairMaxPix = 4096;   // model values in registers: kPairMaxPix / MAXT doubles per lane and walker
-// The plan (pair_plan_kernel): int32 plan[kPairHdrInts + 3 cap]
+// The plan (pair_plan_kernel): int32 plan[kPairHdrInts]
 //   [0] pairs, [1] singles: the pair kernel's items (final counts); [2], [3] the same while the planner runs, [4] its
-//   finished workgroups (all three back at zero when it ends); pairs {a, b} from [kPairHdrInts], singles from
-//   [kPairHdrInts + 2 cap]
+//   finished workgroups (all three back at zero when it ends).  The items themselves -- the walkers' recipes, so that a
+//   workgroup of the pair kernel is two dependent loads from its weights -- are P.pair_items[] and P.pair_singles[].
 constexpr int kPairHdrInts = 8;
 
 template <int I, int N, class F>
@@ -59,7 +59,7 @@ template <int MAXT, int NT, bool RED>
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 2 : 4)
 logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
                     double gate_tmin, double gate_tmax, const int32_t *__restrict__ plan, DevProblem P,
-                    double *__restrict__ logp, int32_t *__restrict__ status, int64_t plan_cap) {
+                    double *__restrict__ logp, int32_t *__restrict__ status) {
     // (the leading 14 dwords arrive preloaded in SGPRs, as in logprob_kernel)
     constexpr int NS = 2, ndim = 6, NC = 8, B = MAXT, nw = B >> 6;
     (void)rblk; (void)niso_nt; (void)n; (void)gate_tmin; (void)gate_tmax;
@@ -76,36 +76,32 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
     const int mode = (ng_mode_fast >> 8) & 0xff;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
     // ---- this workgroup's item: the planner's singles first, then its pairs -------------------------------------
-    int64_t wkv[2];
+    const PairRec *rec[2];
+    bool is_pair;
     {
         const int2 cnt = *reinterpret_cast<const int2 *>(plan);  // {pairs, singles}
         const int nsingle = cnt.y, b = (int)blockIdx.x - nsingle;
         if (b >= cnt.x) return;
-        if (b < 0) {
-            wkv[0] = plan[kPairHdrInts + 2 * plan_cap + blockIdx.x];
-            wkv[1] = -1;
-        } else {
-            const int2 it = reinterpret_cast<const int2 *>(plan + kPairHdrInts)[b];
-            wkv[0] = it.x;
-            wkv[1] = it.y;
-        }
+        is_pair = b >= 0;
+        rec[0] = is_pair ? &P.pair_items[b].r[0] : P.pair_singles + blockIdx.x;
+        rec[1] = is_pair ? &P.pair_items[b].r[1] : rec[0];
     }
     const int npix = (int)P.npix;
     const int ne = (int)P.npair;  // table elements, a multiple of 256; <= kPairMaxPix / 2 (checked by the host)
 
     // ---- phase 0: the walkers' recipes are the planner's (recipe_scalar2: every walker on the list is live) --------
     if (wave0 < 2 && lane0 < NC) {
-        const int64_t wk = wkv[wave0] >= 0 ? wkv[wave0] : wkv[0];
-        const PairRec *R = P.pair_rec + wk;
+        const PairRec *R = rec[wave0];
         D[wave0].node[lane0] = R->node[lane0];
         D[wave0].w[lane0] = R->w[lane0];
-        if (lane0 == 0) { D[wave0].redc = R->redc; D[wave0].lp = R->lp; D[wave0].chi_extra = R->chi_extra; }
+        if (lane0 == 0) { D[wave0].redc = R->redc; D[wave0].lp = R->lp; D[wave0].chi_extra = R->chi_extra; D[wave0].ncorner = R->walker; }
     }
     fill_exp2_table(e2tab, tid0 - (B - kWave));
     for (int i = tid0; i < kLogBins; i += B) { S[0].hist[i] = 0; S[1].hist[i] = 0; }
     if (tid0 < 2) { S[tid0].cand_n = 0; S[tid0].has_second = 0; }
     __syncthreads();
-    const bool act0 = true, act1 = wkv[1] >= 0;
+    const int64_t wkv[2] = {D[0].ncorner, is_pair ? D[1].ncorner : -1};  // (the walkers' indices travel in an unused field)
+    const bool act0 = true, act1 = is_pair;
     bool same = act1;
     if (same) {
 #pragma unroll
@@ -466,8 +462,8 @@ __device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane
 
 __global__ void __launch_bounds__(kPlanThreads)
 pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restrict__ rblk, int niso_nt, int ng_mode_fast, int64_t n,
-                 double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, int64_t cap, PairRec *__restrict__ rec,
-                 double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats, DevProblem P) {
+                 double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, PairItem *__restrict__ pair_items,
+                 PairRec *__restrict__ single_items, double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats, DevProblem P) {
     constexpr int NS = 2, ndim = 6;
     __shared__ double s_isot[4 * kWave], s_isog[4 * kWave], s_isol[4 * kWave], s_teff[kWave], s_logg[32];
     __shared__ double s_ave[2 * kWave], s_avm[2 * kWave], s_avs[2 * kWave];
@@ -480,8 +476,8 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
     const int tid = threadIdx.x, lane = tid & 63;
-    int2 *pairs = reinterpret_cast<int2 *>(plan + kPairHdrInts);
-    int32_t *singles = plan + kPairHdrInts + 2 * cap;
+    __shared__ int s_where[kPlanThreads];  // where this thread's walker goes: 2 (pair index) + slot, or -2 - (single index)
+    s_where[tid] = -1;
     {
         const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT), *g_isog = reinterpret_cast<const double *>(rblk + kRbIsoG);
         const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
@@ -500,6 +496,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     for (int k = 0; k < ndim; ++k) t[k] = mine ? theta[i * ndim + k] : 0.0;
     __syncthreads();
     unsigned long long tag = 0ull;  // 0: nothing left to evaluate (rejected by the prior box, or an error status)
+    PairRec mrec;
     if (mine) {
         const ScalarTabs T = {s_isot, s_isog, s_teff, s_logg, s_pmask, niso, nt, ng};
         int node[NS * 4];
@@ -509,11 +506,12 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
             logp[i] = (st > MSX_W_REJECT) ? nan_with_status(st) : -INFINITY;
             status[i] = st;
         } else {
-            PairRec *R = rec + i;
+            PairRec *R = &mrec;
 #pragma unroll
             for (int c = 0; c < NS * 4; ++c) { R->w[c] = w[c]; R->node[c] = node[c]; }
             R->redc = redc;
-            R->status = MSX_W_OK;
+            R->walker = (int32_t)i;
+            R->pad = 0;
             // what only the walker's last line reads: the Gaussian prior terms (f1) and the contrast / photometry
             // chi^2 (A5/A6) -- here and not by two waves of the pair kernel, whose workgroup would wait for their table
             // round trips after its median is long done
@@ -601,8 +599,19 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     if (tid == 0) s_basep = np ? atomicAdd(&plan[2], np) : 0;
     if (tid == 1) s_basel = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;
     __syncthreads();
-    for (int k = tid; k < np; k += kPlanThreads) pairs[s_basep + k] = s_pairs[k];
-    for (int k = tid; k < nsingle + nl; k += kPlanThreads) singles[s_basel + k] = (int)(s_left[k] & 0xffffffull) - 1;
+    // every walker's recipe goes where its workgroup will look for it
+    const int base = blockIdx.x * kPlanThreads;
+    for (int k = tid; k < np; k += kPlanThreads) {
+        s_where[s_pairs[k].x - base] = (s_basep + k) << 1;
+        s_where[s_pairs[k].y - base] = ((s_basep + k) << 1) | 1;
+    }
+    for (int k = tid; k < nsingle + nl; k += kPlanThreads) s_where[(int)(s_left[k] & 0xffffffull) - 1 - base] = -2 - (s_basel + k);
+    __syncthreads();
+    if (tag != 0ull) {
+        const int wh = s_where[tid];
+        PairRec *dst = wh >= 0 ? &pair_items[wh >> 1].r[wh & 1] : single_items + (-2 - wh);
+        *dst = mrec;
+    }
     // ---- the last workgroup to finish publishes the counts and leaves the working counters at zero for the next launch
     // (the ticket is taken after this workgroup's own adds have RETURNED -- their results placed the stores above)
     __syncthreads();
