@@ -605,7 +605,7 @@ def main():
         # contract's HBM figure is kept, labelled, in `hbm_contract`; it is NOT a bound on this design and exceeds 1.
         achieved = n * req / kern_s / 1e9
         traffic, traffic_src = None, None
-        tj = load_profile('r2_logprob_traffic.json') or load_profile('r1_logprob_traffic.json')
+        tj = load_profile('r3_logprob_traffic.json') or load_profile('r2_logprob_traffic.json')
         if tj and tj.get('config') == {'walkers': n, 'npix': args.npix, 'phot': bool(args.phot)}:
             traffic = tj.get('hbm_bytes_per_launch')
             traffic_src = 'profiles/ (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)'
@@ -637,7 +637,7 @@ def main():
                         'fraction of a bound and exceeds 1; measured HBM traffic is the figure beside it'}
         copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
         roofline['measured_stream_copy_GBps'] = copy_gbps
-        vj = load_profile('r2_valu.json')
+        vj = load_profile('r3_valu.json') or load_profile('r2_valu.json')
         issue_peak = 1024 * 2.4e9 / 4.0   # FP64 wave-instructions per second: 1024 SIMDs, one per 4 clocks, 2.4 GHz
         valu_by_regime = {}
         if vj:
@@ -647,7 +647,7 @@ def main():
             if v:
                 roofline['valu'] = {'insts_per_eval': v, 'wave_insts_per_s': v * n / kern_s, 'issue_peak_per_s': issue_peak,
                                     'issue_frac': v * n / kern_s / issue_peak,
-                                    'source': 'profiles/r2_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) x this run\'s kernel time; '
+                                    'source': 'profiles/r3_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) x this run\'s kernel time; '
                                               'peak = 1024 SIMDs x 2.4 GHz / 4 clocks per FP64 wave-instruction'}
         workload = ('BASELINE config 5: KOI targets ({} px each after the (0.55, 0.90) um crop), one independent problem per '
                     'GPU, {} walkers per launch, logposterior with 2 contrast terms; {}'.format(
@@ -698,7 +698,10 @@ def main():
                 req_m = eng.ctx.bytes_per_eval(m)
                 row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6, 'requested_bytes_per_eval': req_m,
                        'requested_GBps': m * req_m / us / 1e3, 'frac_of_l2_peak': m * req_m / us / 1e3 / L2_PEAK_GBPS}
-                vi = valu_by_regime.get((args.npix, 3072)) if m > 1024 else None   # the 256-thread variant's count
+                row['form'] = 'pair (planner + two walkers of one grid cell per workgroup)' if m >= 4096 and args.npix <= 4096 else 'fused'
+                # VALU wave-instructions per evaluation: profiles/r3_sq_*_pair_vs_fused.json (16,384 walkers: fused
+                # 256-thread variant 9,028, pair kernel 8,741)
+                vi = (8741 if row['form'] != 'fused' else 9028) if (m > 1024 and args.npix == 4096) else None
                 if vi:
                     row['valu_issue_frac'] = vi * m / (us * 1e-6) / issue_peak
                 sweep.append(row)

@@ -409,7 +409,10 @@ int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
 #define MSX_PAIR_GO2(T_, NT_, RED_)                                                                                   \
     hipLaunchKernelGGL((logprob_pair_kernel<T_, NT_, RED_>), g, dim3(T_), 0, A.s, A.theta, (const unsigned char *)c->d_recipe_block, \
                        A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status)
-#define MSX_PAIR_GO(T_, NT_) do { if (P.use_av) MSX_PAIR_GO2(T_, NT_, true); else MSX_PAIR_GO2(T_, NT_, false); } while (0)
+    // (always the variant that loads the extinction terms: a problem staged without extinction -- every walker at
+    // redc = 0 -- takes the unreddened values from it all the same and pays for the H rows; the variant without them
+    // spilled registers at 4096 pixels and is not built)
+#define MSX_PAIR_GO(T_, NT_) MSX_PAIR_GO2(T_, NT_, true)
     // (512 threads, two workgroups per CU at <= 128 VGPRs: 16 waves per CU.  The 256-thread variants -- two per CU at
     // 256 VGPRs, 8 waves -- measured 411.8 us against 344.8 at 16,384 walkers and are not built.)
     if (ne <= 2 * 512) MSX_PAIR_GO(512, 2); else MSX_PAIR_GO(512, 4);
@@ -1618,6 +1621,10 @@ int msx_bytes_per_eval(msx_ctx *c, int64_t n, int64_t *requested_bytes) {
     //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
     const bool pf = pick_block(c, n, npix) == 512 && takes_pf(c, n);
     *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
+    // the pair form (MSX_PATH_AUTO from pair_min_walkers on, for an ensemble that pairs): two walkers per set of loads --
+    // rows, extinction terms, the fit sweep's data flux / u, the pass's three vectors -- + the planner's record
+    if (c->pair_rows > 0 && c->P.nspec == 2 && n >= c->pair_min_walkers && c->path != MSX_PATH_FUSED && c->path != MSX_PATH_LINKED)
+        *requested_bytes = npix * (12 * 8 + 12 + 16 + 24) / 2 + (int64_t)sizeof(PairRec) + 8 * 6 + 12;
     return MSX_OK;
 }
 

@@ -876,10 +876,8 @@ __device__ __forceinline__ double band_terms_scalar2(const DevProblem &P, int mo
     constexpr int NS = 2;
     const double a_v = t[NS];
     const bool redden = redden_rule(mode, P.use_av, a_v);
-    const int njobs = P.nc * NS + P.np;
-    double val[MSX_MAX_BANDS * NS + MSX_MAX_BANDS];
-    for (int k = 0; k < njobs; ++k) val[k] = band_job_value<NS>(P, node, w, k);
-    return band_chi<NS>(P, redden, a_v, [&](int k) __attribute__((always_inline)) { return val[k]; });
+    // (band_chi asks for every job's magnitude exactly once: computed on demand, no array)
+    return band_chi<NS>(P, redden, a_v, [&](int k) __attribute__((always_inline)) { return band_job_value<NS>(P, node, w, k); });
 }
 
 }  // namespace

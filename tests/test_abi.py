@@ -71,13 +71,13 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
     lines = out.stderr.splitlines()
     seen = 0
     for i, ln in enumerate(lines):
-        if 'Function Name' in ln and 'logprob_kernel' in ln:
+        if 'Function Name' in ln and ('logprob_kernel' in ln or 'logprob_pair_kernel' in ln or 'pair_plan_kernel' in ln):
             block = '\n'.join(lines[i:i + 14])
             m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', block)
             capped = 'Li256E' in ln or 'Li512ELb0ELb1E' in ln   # 256 threads, or 512 with SH (shared CU)
             assert m and int(m.group(1)) <= (64 if capped else 0), block
             seen += 1
-    assert seen >= 12   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; linked
+    assert seen >= 15   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; linked; pair + planner
 
 
 def test_python_constants_mirror_the_header():

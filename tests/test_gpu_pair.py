@@ -42,6 +42,24 @@ def test_pair_matches_reference_golden_and_fused_bits():
     assert same_bits(outs) and np.isinf(outs[0]).sum() == 8
 
 
+def test_pair_problem_staged_without_extinction():
+    """`a=False` (mft6.py:1161): no walker is reddened; the pair kernel's only variant loads the extinction terms and
+    must still return the unreddened values, bit for bit."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    c = golden_case('B')
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega), use_av=False)
+    th = np.repeat(c.theta, 3, axis=0)
+    outs = forms(eng, eng.loglikelihood, th)
+    assert same_bits(outs) and np.all(np.isfinite(outs[0]))
+    want = np.array([common.orc.loglikelihood(list(t), c.fr, 2, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma,
+                                              c.matrix, bandlib=c.bandlib, av=False) for t in c.theta[:4]])
+    assert rel_err(outs[1][:12:3], want).max() < TIGHT
+
+
 def test_pair_values_do_not_depend_on_the_partner():
     """Many walkers in few grid cells, then the same walkers shuffled, duplicated, with an odd count, in tiny batches:
     identical bits every time.  Includes a Teff exactly on a node (duplicated corners with weight 0), A_V = 0 (the

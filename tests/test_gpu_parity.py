@@ -892,8 +892,10 @@ def test_resampled_tables_stay_at_rounding_level_under_heavy_extinction():
     print('resampled tables, A_V in {0, 0.3, 1, 3}: max relative deviation from the oracle', e.max())
     assert e.max() < 1e-11
     # 12 bytes per node-pixel are in use; a workgroup with a CU to itself keeps u and the data flux in LDS for the chi^2 pass
-    assert eng.ctx.bytes_per_eval(100000) == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12
+    assert eng.ctx.bytes_per_eval(1000) == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12
     assert eng.ctx.bytes_per_eval(64) == 700 * (12 * 8 + 12 + 16 + 8) + 8 * 6 + 12
+    # ... and from 4,096 walkers on two walkers of one grid cell share every load (+ the planner's 128-byte record)
+    assert eng.ctx.bytes_per_eval(100000) == 700 * (12 * 8 + 12 + 16 + 24) // 2 + 128 + 8 * 6 + 12
 
 
 def test_fuzzed_problems_against_the_oracle():
