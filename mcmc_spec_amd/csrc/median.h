@@ -377,13 +377,13 @@ __device__ __forceinline__ bool logbin_applicable(unsigned long long kmin, unsig
     const unsigned int hmax = (unsigned int)__double2hiint(val_of(kmax)) >> 12;
     return hmax - hmin < (unsigned int)kLogBins;  // the cycle of bins starts at min's bin; it must not lap itself
 }
+// (hmin = the unmasked bin number of the vector's minimum, hi32(min) >> 12)
 template <int BT>
-__device__ __forceinline__ bool logbin_locate(int npix, unsigned long long kmin, const BlockScratch &S, LogbinSel *out) {
+__device__ __forceinline__ bool logbin_locate_h(int npix, unsigned int hmin, const BlockScratch &S, LogbinSel *out) {
     constexpr int nw = BT >> 6;
     const int lane = threadIdx.x & 63;
     const unsigned int k1 = (unsigned int)((npix - 1) >> 1);
     const bool need_two = (npix & 1) == 0;
-    const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
     const unsigned int a = hmin & (unsigned int)(kLogBins - 1);
     // ---- locate rank k1 along the cycle from the running totals (hist_prefix_inplace) ---------------------------
     constexpr int PT = kLogBins / BT, blk = kWave * PT;  // counters per thread; bins per wave block
@@ -454,6 +454,10 @@ __device__ __forceinline__ bool logbin_locate(int npix, unsigned long long kmin,
     }
     out->sel_p = sel_p; out->nxt_p = nxt_p; out->kk = kk; out->cnt = cnt;
     return cnt <= (unsigned int)kSelectFinish;  // (more: heavy duplication, the general path sorts it out)
+}
+template <int BT>
+__device__ __forceinline__ bool logbin_locate(int npix, unsigned long long kmin, const BlockScratch &S, LogbinSel *out) {
+    return logbin_locate_h<BT>(npix, (unsigned int)__double2hiint(val_of(kmin)) >> 12, S, out);
 }
 // Rank the gathered candidates (S.cand[0 .. cnt), complete: a barrier has passed).  Up to 64 candidates (the usual
 // case): wave `rank_wave` alone, in registers, and only that wave learns the median -- no further barrier.  More: the

@@ -71,7 +71,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
     __shared__ BlockScratch S[2];
     __shared__ double red[2][3][nw][kWave];
     __shared__ double e2tab[kExp2Tab];
-    struct WalkerLoc { double pc[3]; unsigned long long kmin, kmax; LogbinSel Q; int bad, appl; unsigned int fsel, fspan; };
+    struct WalkerLoc { double pc[3]; LogbinSel Q; int appl; unsigned int fsel, fspan; };
     __shared__ WalkerLoc Loc[2];
     const int mode = (ng_mode_fast >> 8) & 0xff;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
@@ -143,8 +143,12 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         const bool reddenA = redcA != 0.0, reddenB = two && redcB != 0.0;
         double2 m[2][NT];  // THE MODEL VECTORS: lane tid holds the pixels of elements tid + j B, j = 0 .. NT - 1
         double qa[2][vk][3];
-        double vmin[2] = {INFINITY, INFINITY}, vmax[2] = {-INFINITY, -INFINITY};
-        bool seen_nan[2] = {false, false};
+        // The value range as the range of the UNMASKED bin number F(x) = hi32(x) >> 12 -- a by-product of the histogram's
+        // bin, two integer instructions per pixel, one DPP instruction per reduction step where float64 min / max /
+        // NaN flags take five times that.  It decides everything the early-histogram median needs (all values
+        // positive normal numbers: F in [1, 0x7ff00); span < 8 binades: F_max - F_min < 2048; the bin of the minimum);
+        // the exact float64 range is worked out only on the path that needs it (below).
+        unsigned int fmin[2] = {~0u, ~0u}, fmax[2] = {0u, 0u};
         // what follows a pixel pair's model values (logprob_kernel's finish_elem, per walker)
         auto finish_elem = [&](auto s_c, auto j_c, const double2 m2, const double2 f2, const double2 u2, const int ec,
                                const bool live) __attribute__((always_inline)) {
@@ -157,10 +161,10 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             for (int u = 0; u < 2; ++u) {
                 if (ok[u]) {
                     fit_accumulate(mm[u], ff[u], uu[u], qa[s][kbase + u][0], qa[s][kbase + u][1], qa[s][kbase + u][2]);
-                    vmin[s] = min_nc(vmin[s], mm[u]);
-                    vmax[s] = max_nc(vmax[s], mm[u]);
-                    seen_nan[s] = seen_nan[s] || (mm[u] != mm[u]);
-                    if (!(MSX_PAIR_EXP & 8)) atomicAdd(&S[s].hist[logbin(mm[u])], 1u);
+                    const unsigned int fx = (unsigned int)__double2hiint(mm[u]) >> 12;
+                    fmin[s] = fx < fmin[s] ? fx : fmin[s];
+                    fmax[s] = fx > fmax[s] ? fx : fmax[s];
+                    if (!(MSX_PAIR_EXP & 8)) atomicAdd(&S[s].hist[fx & (unsigned int)(kLogBins - 1)], 1u);
                 }
             }
         };
@@ -258,12 +262,8 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         if (two) hist_prefix_inplace<MAXT>(S[1]);
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
             constexpr int s = decltype(s_c)::value;
-            const double lo = wave_min_f64(vmin[s]), hi = wave_max_f64(vmax[s]);
-            const bool wave_nan = __ballot(seen_nan[s]) != 0ull;
-            if (lane == 0) {
-                S[s].kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
-                S[s].kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
-            }
+            const unsigned int lo = wave_min_u32(fmin[s]), hi = wave_max_u32(fmax[s]);
+            if (lane == 0) { S[s].kmin[wave] = lo; S[s].kmax[wave] = hi; }  // (a wave with no live pixel: ~0 / 0, the neutral pair)
         });
         __syncthreads();
         // wave s works out walker s's fit coefficients, value range and the median's bin(s) and leaves them in LDS for
@@ -275,29 +275,27 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             double q[3], c0, c1, c2;
 #pragma unroll
             for (int i = 0; i < 3; ++i) q[i] = S[s].q[0][i];
-            unsigned long long k0 = S[s].kmin[0], k1 = S[s].kmax[0];
+            unsigned int f0 = (unsigned int)S[s].kmin[0], f1 = (unsigned int)S[s].kmax[0];
             for (int x = 1; x < nw; ++x) {
-                k0 = S[s].kmin[x] < k0 ? S[s].kmin[x] : k0;
-                k1 = S[s].kmax[x] > k1 ? S[s].kmax[x] : k1;
+                f0 = (unsigned int)S[s].kmin[x] < f0 ? (unsigned int)S[s].kmin[x] : f0;
+                f1 = (unsigned int)S[s].kmax[x] > f1 ? (unsigned int)S[s].kmax[x] : f1;
             }
-            // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
-            const bool bd = k1 > key_of(INFINITY) || k0 < key_of(-INFINITY);
             fit_coefs(P, q, c0, c1, c2);
             LogbinSel Qs = {0u, 0u, 0u, 0u};
-            bool ap = !bd && logbin_applicable<MAXT>(k0, k1);
-            if (ap) ap = logbin_locate<MAXT>(npix, k0, S[s], &Qs);
+            // positive normal numbers only (zeros and subnormals: F = 0; infinities, NaNs, negatives: F >= 0x7ff00),
+            // spanning less than the histogram's cycle; then the rank from the running totals
+            bool ap = f0 >= 1u && f1 < 0x7ff00u && f1 - f0 < (unsigned int)kLogBins;
+            if (ap) ap = logbin_locate_h<MAXT>(npix, f0, S[s], &Qs);
             if (lane == 0) {
                 Loc[s].pc[0] = c0; Loc[s].pc[1] = c1; Loc[s].pc[2] = c2;
-                Loc[s].kmin = k0; Loc[s].kmax = k1;
                 Loc[s].Q = Qs;
-                Loc[s].bad = bd; Loc[s].appl = ap;
+                Loc[s].appl = ap;
                 // The candidates' test as ONE range check.  The vector is positive and spans < 8 binades, so the
                 // UNMASKED bin number F(x) = hi32(x) >> 12 is monotone in x and unique per physical bin:
                 // F(bin p) = F(min) + ((p - F(min)) mod 2048).  nxt_p is the next NON-EMPTY bin after sel_p: a value
                 // lies in one of the two iff F(sel) <= F(x) <= F(nxt) -- there is nothing in between.
-                const unsigned int fmin = (unsigned int)__double2hiint(val_of(k0)) >> 12;
-                const unsigned int fsel = fmin + ((Qs.sel_p - fmin) & (unsigned int)(kLogBins - 1));
-                const unsigned int fnxt = fmin + ((Qs.nxt_p - fmin) & (unsigned int)(kLogBins - 1));
+                const unsigned int fsel = f0 + ((Qs.sel_p - f0) & (unsigned int)(kLogBins - 1));
+                const unsigned int fnxt = f0 + ((Qs.nxt_p - f0) & (unsigned int)(kLogBins - 1));
                 Loc[s].fsel = ap ? fsel : 1u;
                 Loc[s].fspan = ap ? fnxt - fsel : 0u;   // (not applicable: F(x) - 1 <= 0 never holds for a positive x ... and
                                                          //  `appl` gates the test anyway)
@@ -305,16 +303,14 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         });
         __syncthreads();
         double pc[2][3];
-        unsigned long long kmin[2], kmax[2];
-        bool bad[2], appl[2];
+        bool bad[2] = {false, false}, appl[2];
         LogbinSel Q[2];
         unsigned int fsel[2], fspan[2];
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
             constexpr int s = decltype(s_c)::value;
             pc[s][0] = Loc[s].pc[0]; pc[s][1] = Loc[s].pc[1]; pc[s][2] = Loc[s].pc[2];
-            kmin[s] = Loc[s].kmin; kmax[s] = Loc[s].kmax;
             Q[s] = Loc[s].Q;
-            bad[s] = Loc[s].bad != 0; appl[s] = Loc[s].appl != 0;
+            appl[s] = Loc[s].appl != 0;
             fsel[s] = Loc[s].fsel; fspan[s] = Loc[s].fspan;
         });
 
@@ -363,7 +359,41 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
         // model values go to the walker's scratch row and block_median (linear bins, radix fallback) reads them there
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
             constexpr int s = decltype(s_c)::value;
-            if (bad[s] || appl[s]) return;  // (uniform)
+            if (appl[s]) return;  // (uniform)
+            // the exact value range first (order-preserving keys; a NaN anywhere counts as above +inf), like the fused kernel
+            double vlo = INFINITY, vhi = -INFINITY;
+            bool nan_here = false;
+            static_for<0, NT>([&](auto j_c) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_c)::value;
+                const int e = j * B + tid;
+                const int pa = ((e >> 8) << 9) | (e & 255);
+                const double xv[2] = {m[s][j].x, m[s][j].y};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (e < ne && pa + 256 * u < npix) {
+                        vlo = min_nc(vlo, xv[u]);
+                        vhi = max_nc(vhi, xv[u]);
+                        nan_here = nan_here || (xv[u] != xv[u]);
+                    }
+                }
+            });
+            {
+                const double lo = wave_min_f64(vlo), hi = wave_max_f64(vhi);
+                const bool wave_nan = __ballot(nan_here) != 0ull;
+                if (lane == 0) {
+                    S[s].kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
+                    S[s].kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
+                }
+            }
+            __syncthreads();
+            unsigned long long kmin = S[s].kmin[0], kmax = S[s].kmax[0];
+            for (int x = 1; x < nw; ++x) {
+                kmin = S[s].kmin[x] < kmin ? S[s].kmin[x] : kmin;
+                kmax = S[s].kmax[x] > kmax ? S[s].kmax[x] : kmax;
+            }
+            // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
+            bad[s] = kmax > key_of(INFINITY) || kmin < key_of(-INFINITY);
+            if (bad[s]) return;  // (uniform)
             double *row = P.model_scratch + (s == 0 ? wk0 : wk1) * (int64_t)npix;
             auto spill = [&](auto j_c) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_c)::value;
@@ -378,7 +408,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             __syncthreads();
             NoElem no_elem;
             bool unused = false;
-            med[s] = block_median<MAXT>(row, npix, kmin[s], kmax[s], S[s], NoSide(), no_elem, &unused);
+            med[s] = block_median<MAXT>(row, npix, kmin, kmax, S[s], NoSide(), no_elem, &unused);
         });
         // (no barrier: wave s has its walker's median in registers and the chi^2 partials were published before the pass's
         // barrier; the other waves are done)

@@ -79,6 +79,29 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     const unsigned long long ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
 }
+// (32-bit: ONE DPP-operand instruction per step)
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+    unsigned int t;
+    t = (unsigned int)dpp_i32<kDppQuadSwap1>((int)v); v = t < v ? t : v;
+    t = (unsigned int)dpp_i32<kDppQuadSwap2>((int)v); v = t < v ? t : v;
+    t = (unsigned int)dpp_i32<kDppRowRor4>((int)v); v = t < v ? t : v;
+    t = (unsigned int)dpp_i32<kDppRowRor8>((int)v); v = t < v ? t : v;
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+    unsigned int t;
+    t = (unsigned int)dpp_i32<kDppQuadSwap1>((int)v); v = t > v ? t : v;
+    t = (unsigned int)dpp_i32<kDppQuadSwap2>((int)v); v = t > v ? t : v;
+    t = (unsigned int)dpp_i32<kDppRowRor4>((int)v); v = t > v ? t : v;
+    t = (unsigned int)dpp_i32<kDppRowRor8>((int)v); v = t > v ? t : v;
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
 __device__ __forceinline__ double wave_min_f64(double v) {  // fmin / fmax: a NaN operand is ignored (callers flag NaNs apart)
     v = fmin(v, dpp_f64<kDppQuadSwap1>(v));
     v = fmin(v, dpp_f64<kDppQuadSwap2>(v));
