@@ -412,9 +412,9 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // what lets the linked form give each segment to a workgroup of its own.
     constexpr int vk = kMaxWaves / (MAXT / kWave);  // slots per lane: 4 or 2
     double q[3];
-    unsigned long long kmin = ~0ull, kmax = 0ull;
-    double vmin = INFINITY, vmax = -INFINITY;  // value range of the model vector; NaNs are flagged apart
-    bool seen_nan = false;
+    // value range of the model vector, as the range of the unmasked histogram bin number F(m) = hi32(m) >> 12 (median.h,
+    // frange_applicable); the exact float64 range is worked out only where block_median needs it
+    unsigned int fmin_ = ~0u, fmax_ = 0u;
     constexpr int SUB = vk / U;  // elements per lane and outer trip: 2 (256 threads) or 1
     double qrun = 0.0;  // waves 0..2: their fit sum over the segments so far
     for (int seg = seg_lo; seg < seg_hi; ++seg) {
@@ -443,10 +443,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
 #pragma unroll
                 for (int k = 0; k < vk; ++k)
                     if (slot + u == k) fit_accumulate(m, ff[u], uu[u], qa[k][0], qa[k][1], qa[k][2]);
-                vmin = min_nc(vmin, m);
-                vmax = max_nc(vmax, m);
-                seen_nan = seen_nan || (m != m);
-                if (early) atomicAdd(&S.hist[logbin(m)], 1u);
+                const unsigned int fx = (unsigned int)__double2hiint(m) >> 12;
+                fmin_ = fx < fmin_ ? fx : fmin_;
+                fmax_ = fx > fmax_ ? fx : fmax_;
+                if (early) atomicAdd(&S.hist[fx & (unsigned int)(kLogBins - 1)], 1u);
             }
         }
       };
@@ -657,14 +657,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // the early histogram is complete (the segment loop's barrier): its running totals, published by the barrier below
     if (early && !producer) hist_prefix_inplace<MAXT>(S);
     {
-        // value range: order-preserving keys, a NaN anywhere counts as above +inf
-        const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
-        const bool wave_nan = __ballot(seen_nan) != 0ull;
+        const unsigned int lo = wave_min_u32(fmin_), hi = wave_max_u32(fmax_);
         if (lane == 0) {
-            // (a wave whose pixels were all beyond the spectrum's end reports the empty range)
-            // (fmin / fmax do not order -0 and +0: a zero bound stands for both)
-            S.kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
-            S.kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
+            // (a wave whose pixels were all beyond the spectrum's end reports the empty range: ~0 / 0)
+            S.kmin[wave] = lo;
+            S.kmax[wave] = hi;
             if (wave < 3) S.q[0][wave] = qrun;
         }
         const int nother = (LK && !producer) ? nsegs - 1 : 0;  // segments blended elsewhere
@@ -675,18 +672,18 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) q[i] = S.q[0][i];
-        kmin = S.kmin[0]; kmax = S.kmax[0];
+        fmin_ = (unsigned int)S.kmin[0]; fmax_ = (unsigned int)S.kmax[0];
         const int nr = nw + nother;
         for (int x = 1; x < nr; ++x) {
-            kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
-            kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
+            fmin_ = (unsigned int)S.kmin[x] < fmin_ ? (unsigned int)S.kmin[x] : fmin_;
+            fmax_ = (unsigned int)S.kmax[x] > fmax_ ? (unsigned int)S.kmax[x] : fmax_;
         }
     }
     if (producer) {
         // the segment's partials, for the joiner
         SegPart *sp = P.segparts + wk * nseg_all + myseg;
         for (int b = tid; b < kLogBins; b += B) sp->hist[b] = S.hist[b];
-        if (tid == 0) { sp->q[0] = q[0]; sp->q[1] = q[1]; sp->q[2] = q[2]; sp->kmin = kmin; sp->kmax = kmax; }
+        if (tid == 0) { sp->q[0] = q[0]; sp->q[1] = q[1]; sp->q[2] = q[2]; sp->kmin = fmin_; sp->kmax = fmax_; }
         // EVERY wave first waits until its own stores (model values, histogram counters) have been acknowledged by the
         // XCD's L2 -- s_waitcnt vmcnt(0), no cache operation; written out because the compiler's workgroup-scope
         // release fence omits the wait (waves of one workgroup share their L1) -- and only then joins the barrier: a wave's wait covers its own stores only, and a CU's requests to different L2 channels are not
@@ -705,15 +702,6 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         return;
     }
     MSX_STAMP(P, wk, 3);
-    // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
-    if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
-        if (tid == 0) {
-            const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
-            if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
-            walker_done(P, D, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
-        }
-        return;
-    }
 
     // ---- phase B: exact median (np.median, mft6.py:1173) -----------------------------------------------
     // wave 2 computes the contrast / photometry terms inside the median's scan stage (fast recipe only)
@@ -738,7 +726,9 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     if (early) {
         ChiElem<MAXT, PF, true, kAhead> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
                                          &red[0][0][0], {}, {}, {}, 0.0};
-        solved = logbin_median<MAXT>(model, npix, kmin, kmax, S, chi_fast, &med_model);
+        // positive normal values spanning < 8 binades (anything else -- zeros, negatives, infinities, NaNs, huge ranges --
+        // takes block_median below); > 256 equal-bin candidates come back unsolved too
+        if (frange_applicable(fmin_, fmax_)) solved = logbin_median<MAXT>(model, npix, fmin_, S, chi_fast, &med_model);
         chi_done = solved;
         // Only wave 0 is busy from here (it ranks the candidates; the others left logbin_median after its barrier):
         // waves 1 and 2 compute what only the walker's last line reads -- the contrast / photometry terms (A5/A6, which
@@ -754,7 +744,20 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             __syncthreads();
         }
     }
-    if (!solved) med_model = block_median<MAXT>(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
+    if (!solved) {
+        unsigned long long kmin, kmax;
+        exact_range<MAXT>(model, npix, S, &kmin, &kmax);
+        // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
+        if (kmax > key_of(INFINITY) || kmin < key_of(-INFINITY)) {
+            if (tid == 0) {
+                const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
+                if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
+                walker_done(P, D, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
+            }
+            return;
+        }
+        med_model = block_median<MAXT>(model, npix, kmin, kmax, S, side, chi_elem, &chi_done);
+    }
     if (fused && !chi_done) {  // degenerate vectors (all equal): the median took no pass, do it here
         chi_elem.prime();
         pass_trips<MAXT>(model, npix, chi_elem, [](const int (&)[4], const double (&)[4]) {});

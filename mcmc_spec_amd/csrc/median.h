@@ -332,6 +332,39 @@ __device__ __forceinline__ unsigned int logbin(double x) {
     return ((unsigned int)__double2hiint(x) >> 12) & (unsigned int)(kLogBins - 1);
 }
 
+// The exact value range of model[0 .. npix) as order-preserving keys (a NaN anywhere: kmax = ~0, above +inf), for the
+// paths that need it (block_median; the NaN -> -inf rule).  All threads call it; uses S.kmin / S.kmax and one barrier.
+template <int BT>
+__device__ __forceinline__ void exact_range(const double *model, int npix, BlockScratch &S, unsigned long long *kmin_out,
+                                            unsigned long long *kmax_out) {
+    constexpr int nw = BT >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double vmin = INFINITY, vmax = -INFINITY;
+    bool seen_nan = false;
+    for (int p = tid; p < npix; p += BT) {
+        const double m = model[p];
+        vmin = min_nc(vmin, m);
+        vmax = max_nc(vmax, m);
+        seen_nan = seen_nan || (m != m);
+    }
+    const double lo = wave_min_f64(vmin), hi = wave_max_f64(vmax);
+    const bool wave_nan = __ballot(seen_nan) != 0ull;
+    __syncthreads();  // (whoever still reads the slots' previous contents is done)
+    if (lane == 0) {
+        // (a wave with no pixel reports the empty range; fmin / fmax do not order -0 and +0: a zero bound stands for both)
+        S.kmin[wave] = lo == INFINITY && hi == -INFINITY ? ~0ull : key_of(lo == 0.0 ? -0.0 : lo);
+        S.kmax[wave] = wave_nan ? ~0ull : (lo == INFINITY && hi == -INFINITY ? 0ull : key_of(hi == 0.0 ? 0.0 : hi));
+    }
+    __syncthreads();
+    unsigned long long kmin = S.kmin[0], kmax = S.kmax[0];
+    for (int x = 1; x < nw; ++x) {
+        kmin = S.kmin[x] < kmin ? S.kmin[x] : kmin;
+        kmax = S.kmax[x] > kmax ? S.kmax[x] : kmax;
+    }
+    *kmin_out = kmin;
+    *kmax_out = kmax;
+}
+
 // The early histogram's counters, turned IN PLACE into running totals: thread t owns counters [t PT, (t + 1) PT) and
 // leaves in each the number of values in its wave's block of bins up to and including that bin; S.wave_tot[w] gets
 // the block's total.  Every thread of the workgroup calls it once the counters are complete (a barrier has passed);
@@ -367,16 +400,8 @@ struct LogbinSel {
     unsigned int sel_p, nxt_p;  // PHYSICAL bins whose values are the candidates (nxt_p == sel_p: one bin)
     unsigned int kk, cnt;       // ranks kk (and kk + 1 for even npix) among the cnt candidates are the middle values
 };
-// Can the early histogram locate the median, and where?  Every wave computes the answer for itself from the running
-// totals of hist_prefix_inplace (uniform result; no barrier).  false: not a positive vector spanning < 8 binades, or
-// more than kSelectFinish candidates -- the caller takes block_median.
-template <int BT>
-__device__ __forceinline__ bool logbin_applicable(unsigned long long kmin, unsigned long long kmax) {
-    if (!(kmin > key_of(0.0)) || kmin == kmax) return false;
-    const unsigned int hmin = (unsigned int)__double2hiint(val_of(kmin)) >> 12;
-    const unsigned int hmax = (unsigned int)__double2hiint(val_of(kmax)) >> 12;
-    return hmax - hmin < (unsigned int)kLogBins;  // the cycle of bins starts at min's bin; it must not lap itself
-}
+// Where is the median?  Every wave computes the answer for itself from the running totals of hist_prefix_inplace
+// (uniform result; no barrier).  false: more than kSelectFinish candidates -- the caller takes block_median.
 // (hmin = the unmasked bin number of the vector's minimum, hi32(min) >> 12)
 template <int BT>
 __device__ __forceinline__ bool logbin_locate_h(int npix, unsigned int hmin, const BlockScratch &S, LogbinSel *out) {
@@ -455,10 +480,6 @@ __device__ __forceinline__ bool logbin_locate_h(int npix, unsigned int hmin, con
     out->sel_p = sel_p; out->nxt_p = nxt_p; out->kk = kk; out->cnt = cnt;
     return cnt <= (unsigned int)kSelectFinish;  // (more: heavy duplication, the general path sorts it out)
 }
-template <int BT>
-__device__ __forceinline__ bool logbin_locate(int npix, unsigned long long kmin, const BlockScratch &S, LogbinSel *out) {
-    return logbin_locate_h<BT>(npix, (unsigned int)__double2hiint(val_of(kmin)) >> 12, S, out);
-}
 // Rank the gathered candidates (S.cand[0 .. cnt), complete: a barrier has passed).  Up to 64 candidates (the usual
 // case): wave `rank_wave` alone, in registers, and only that wave learns the median -- no further barrier.  More: the
 // first waves through LDS, one barrier, every thread learns it.  All threads of the workgroup call it.
@@ -513,16 +534,24 @@ __device__ __forceinline__ double logbin_rank(BlockScratch &S, const LogbinSel &
     return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
 }
 
+// The value range as the early-histogram median wants it: the range [f0, f1] of the UNMASKED bin number
+// F(x) = hi32(x) >> 12 over the vector.  All values positive normal numbers <=> f0 >= 1 and f1 < 0x7ff00 (zeros and
+// subnormals have F = 0; infinities, NaNs and every negative number F >= 0x7ff00); spanning less than the histogram's
+// cycle <=> f1 - f0 < 2048.  Integer min / max per pixel and one-instruction DPP steps per reduction, where the float64
+// range (min, max, a NaN flag) costs five times that -- and the exact range is only needed by block_median.
+__device__ __forceinline__ bool frange_applicable(unsigned int f0, unsigned int f1) {
+    return f0 >= 1u && f1 < 0x7ff00u && f1 - f0 < (unsigned int)kLogBins;
+}
+// hmin = F of the vector's minimum; the caller has checked frange_applicable
 template <int BT, class Elem>
-__device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned long long kmin, unsigned long long kmax,
-                                              BlockScratch &S, Elem &elem, double *med_out) {
+__device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned int hmin, BlockScratch &S, Elem &elem,
+                                              double *med_out) {
     const bool need_two = (npix & 1) == 0;
-    if (!logbin_applicable<BT>(kmin, kmax)) return false;
     MED_STAMP(0);
     MED_STAMP(1);
     elem.prime();  // the pass's first loads travel while the rank is located
     LogbinSel Q;
-    if (!logbin_locate<BT>(npix, kmin, S, &Q)) return false;
+    if (!logbin_locate_h<BT>(npix, hmin, S, &Q)) return false;
     const unsigned int sel_p = Q.sel_p, nxt_p = Q.nxt_p;
     MED_STAMP(2);
     // ---- one pass: chi^2 terms + the candidates (the values of the one or two bins above) ----------------------

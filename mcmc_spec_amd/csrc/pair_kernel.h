@@ -284,7 +284,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             LogbinSel Qs = {0u, 0u, 0u, 0u};
             // positive normal numbers only (zeros and subnormals: F = 0; infinities, NaNs, negatives: F >= 0x7ff00),
             // spanning less than the histogram's cycle; then the rank from the running totals
-            bool ap = f0 >= 1u && f1 < 0x7ff00u && f1 - f0 < (unsigned int)kLogBins;
+            bool ap = frange_applicable(f0, f1);
             if (ap) ap = logbin_locate_h<MAXT>(npix, f0, S[s], &Qs);
             if (lane == 0) {
                 Loc[s].pc[0] = c0; Loc[s].pc[1] = c1; Loc[s].pc[2] = c2;
