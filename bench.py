@@ -694,7 +694,7 @@ def main():
             for m in (128, 256, 512, 1024, 2048, 4096, 16384):
                 th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
                 lp_, st_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
-                us = device_time_us(eng, th, lp_, st_, stream, m, max(5, min(50, 200000 // m)))
+                us = device_time_us(eng, th, lp_, st_, stream, m, max(30, min(60, 400000 // m)))
                 req_m = eng.ctx.bytes_per_eval(m)
                 row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6, 'requested_bytes_per_eval': req_m,
                        'requested_GBps': m * req_m / us / 1e3, 'frac_of_l2_peak': m * req_m / us / 1e3 / L2_PEAK_GBPS}
