@@ -85,6 +85,7 @@ struct DevProblem {
                                // launch fails all its walkers with MSX_W_HANDOVER until msx_stage_problem clears it
     const struct PairItem *pair_items;   // pair form: [rows / 2] the planner's pairs, recipes included
     const struct PairRec *pair_singles;  // ... and [rows] its singles
+    int32_t *pair_lease;                 // pair form: [kPairSpillRows] leases of the spill path's scratch rows
     int32_t linked_fault;      // test hook (msx_test_hook / MSX_LINKED_FAULT=1): producers skip the increment, joiners must time out
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines

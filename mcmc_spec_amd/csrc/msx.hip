@@ -119,7 +119,7 @@ struct msx_ctx {
     int64_t scratch_rows = 0;       // 0 = neither form applies: launches are never cut into sub-batches
     int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _PAIR / _LINKED (msx_set_path)
     // pair form (pair_kernel.h): binaries of <= 4096 pixels with the register-resident recipe
-    int64_t pair_rows = 0;          // scratch rows for its rare spill path = walkers per sub-batch (0: no pair form here)
+    int64_t pair_rows = 0;          // walkers per sub-batch = capacity of the planner's item lists (0: no pair form here)
     // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN; 0 = never).  Measured at 4096 px
     // (profiles/r3_pair_sweep.txt): 2,048 walkers 74.0 us against 69.8 fused (the planner's launch costs more than the
     // shared loads save), 4,096: 111.8 against 121.2, 8,192: 188.7 against 225.1, 16,384: 344.8 against 438.3.
@@ -842,15 +842,18 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     }
     c->linked_poisoned = false;
     // the pair form: binaries of <= 4096 pixels (model values in registers), register-resident recipe.  Its spill path
-    // (vectors the early histogram cannot handle) wants one scratch row per walker of a sub-batch.
+    // (vectors the early histogram cannot handle) leases one of kPairSpillRows scratch rows (32 MB at 4096 pixels); the
+    // planner's items take 256 bytes per walker of a sub-batch.
     if (p->nspec == 2 && p->npix <= kPairMaxPix && c->recipe_fast && !p->no_spectrum) {
         int64_t rows = 16384;
         if (const char *e = getenv("MSX_PAIR_ROWS")) rows = std::max<int64_t>(2, atoll(e));
-        HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * rows * p->npix));
+        HIP_TRY(c, hipMalloc((void **)&c->d_model_scratch, sizeof(double) * kPairSpillRows * p->npix));
         P.model_scratch = c->d_model_scratch;
-        const size_t plan_bytes = sizeof(int32_t) * (size_t)kPairHdrInts;
+        // the planner's header and, behind it, the leases of the spill rows
+        const size_t plan_bytes = sizeof(int32_t) * (size_t)(kPairHdrInts + kPairSpillRows);
         HIP_TRY(c, hipMalloc((void **)&c->d_pair_plan, plan_bytes));
         HIP_TRY(c, hipMemset(c->d_pair_plan, 0, plan_bytes));
+        P.pair_lease = c->d_pair_plan + kPairHdrInts;
         HIP_TRY(c, hipMalloc((void **)&c->d_pair_items, sizeof(PairItem) * (size_t)((rows + 1) / 2)));
         HIP_TRY(c, hipMalloc((void **)&c->d_pair_singles, sizeof(PairRec) * (size_t)rows));
         P.pair_items = c->d_pair_items;

@@ -36,6 +36,7 @@
 namespace {
 
 constexpr int kPairMaxPix = 4096;   // model values in registers: kPairMaxPix / MAXT doubles per lane and walker
+constexpr int kPairSpillRows = 1024; // scratch rows of the spill path (block_median on a vector in memory), leased
 // The plan (pair_plan_kernel): int32 plan[kPairHdrInts]
 //   [0] pairs, [1] singles: the pair kernel's items (final counts); [2], [3] the same while the planner runs, [4] its
 //   finished workgroups (all three back at zero when it ends).  The items themselves -- the walkers' recipes, so that a
@@ -394,7 +395,15 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             // np.median of a vector holding a NaN is NaN -> total NaN -> -inf (mft6.py:1202-1203)
             bad[s] = kmax > key_of(INFINITY) || kmin < key_of(-INFINITY);
             if (bad[s]) return;  // (uniform)
-            double *row = P.model_scratch + (s == 0 ? wk0 : wk1) * (int64_t)npix;
+            // A scratch row on LEASE: kPairSpillRows rows serve every launch (a row per walker of a 16,384-walker batch
+            // would be 512 MB for a path that real spectra never take).  The workgroup takes row (block mod rows) and
+            // waits while an earlier workgroup still holds it -- that one's progress does not depend on this one.
+            const int lease = (int)(blockIdx.x % (unsigned int)kPairSpillRows);
+            if (tid == 0) {
+                while (atomicCAS(P.pair_lease + lease, 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+            double *row = P.model_scratch + (int64_t)lease * npix;
             auto spill = [&](auto j_c) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_c)::value;
                 const int e = j * B + tid;
@@ -409,6 +418,8 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             NoElem no_elem;
             bool unused = false;
             med[s] = block_median<MAXT>(row, npix, kmin, kmax, S[s], NoSide(), no_elem, &unused);
+            __syncthreads();  // (every thread has its last value of the row)
+            if (tid == 0) atomicExch(P.pair_lease + lease, 0);
         });
         // (no barrier: wave s has its walker's median in registers and the chi^2 partials were published before the pass's
         // barrier; the other waves are done)

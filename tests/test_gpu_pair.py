@@ -203,6 +203,13 @@ def test_pair_median_exits(shape):
         want = np.array([orc.loglikelihood(list(t), fr, 2, data, err, r, specs, ctm, ptm, 6000.0, 8800.0, matrix)
                          for t in th[:3]])
         assert rel_err(outs[1][:3], want).max() < TIGHT, (shape, npix)
+        if shape == 'steps' and npix == 2048:
+            # every walker of a large batch on the spill path: more workgroups than scratch rows, which are leased --
+            # workgroup b and b + 1024 take turns on one row
+            many = np.repeat(th, 560, axis=0)
+            many[:, 3] *= 1.0 + 1e-4 * np.arange(len(many))
+            outs = forms(eng, eng.loglikelihood, many)
+            assert same_bits(outs) and np.all(np.isfinite(outs[0]))
 
 
 def test_auto_choice_never_changes_values():
