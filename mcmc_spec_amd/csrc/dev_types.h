@@ -77,16 +77,17 @@ struct DevProblem {
     double *opt_flux;          // [nchains][npix]
     double *opt_med;           // [nchains]
     const int32_t *opt_chain;  // [n] (OPT_STEP launches)
-    double *model_scratch;     // [rows][npix]: the model vectors of the GM variants (spectra beyond the LDS) and the
-                               // producers' segments of the linked form
-    struct SegPart *segparts;  // [rows][segments] linked form: the producers' partials
-    int32_t *seg_flag;         // [rows] linked form: producers that have published their segment (the joiner resets it)
+    double *model_scratch;     // [rows][npix]: the model vectors of the GM variants (spectra beyond the LDS) and of the
+                               // linked form's rare walkers whose median needs the whole vector in one place
+    struct SegPart *segparts;  // [rows][segments] linked form: the segments' partials
+    unsigned long long *seg_flag;  // [rows] linked form: arrivals at the walker's two meeting points, counted up for ever
+                                   // (2 x segments per launch; 64 bits: never wraps)
     int32_t *linked_poison;    // linked form: != 0 once a hand-over has timed out on this context -- every later linked
                                // launch fails all its walkers with MSX_W_HANDOVER until msx_stage_problem clears it
     const struct PairItem *pair_items;   // pair form: [rows / 2] the planner's pairs, recipes included
     const struct PairRec *pair_singles;  // ... and [rows] its singles
     int32_t *pair_lease;                 // pair form: [kPairSpillRows] leases of the spill path's scratch rows
-    int32_t linked_fault;      // test hook (msx_test_hook / MSX_LINKED_FAULT=1): producers skip the increment, joiners must time out
+    int32_t linked_fault;      // test hook (msx_test_hook / MSX_LINKED_FAULT=1): nobody signals its arrival, every wait must time out
     // device-resident stretch move (f2): when smp_on, walker wk of the launch is the wk-th walker of the
     // active half; the kernel builds its own proposal and applies the accept rule in its last lines
     int32_t smp_on;
@@ -155,14 +156,18 @@ struct alignas(16) PairRec {
 static_assert(sizeof(PairRec) == 128, "PairRec layout");
 struct alignas(16) PairItem { PairRec r[2]; };    // two walkers of one grid cell
 
-// linked form: what a producer leaves per (walker, segment) for the walker's joiner
+// linked form: what the workgroup of one (walker, segment) leaves for the walker's other workgroups
 struct alignas(16) SegPart {
+    // first exchange (before the median can be located)
     double q[3];                    // the segment's three fit sums
-    unsigned long long kmin, kmax;  // its value range (order-preserving keys; ~0 / 0 = empty, kmax = ~0: a NaN)
-    unsigned int pad[6];
-    unsigned int hist[kSegBins];    // its share of the median's logarithmic histogram
+    unsigned long long kmin, kmax;  // its range of F(m) = hi32(m) >> 12 (median.h; ~0 / 0 = empty)
+    // second exchange (for whichever workgroup finishes the walker)
+    double chi;                     // the segment's chi^2 sum (canonical, before scale^2)
+    unsigned int ncand, pad[3];     // candidates of the median's bin(s) among the segment's values
+    unsigned int hist[kSegBins];    // first exchange: its share of the median's logarithmic histogram
+    unsigned long long cand[kSelectFinish];
 };
-static_assert(sizeof(SegPart) == 64 + 4 * kSegBins, "SegPart layout");
+static_assert(sizeof(SegPart) == 64 + 4 * kSegBins + 8 * kSelectFinish, "SegPart layout");
 
 }  // namespace
 

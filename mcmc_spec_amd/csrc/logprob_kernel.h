@@ -13,6 +13,11 @@ __device__ __forceinline__ int status_of_nan(double v) {  // 0 for anything that
     return ((b & 0x7ff8000000000000ll) == 0x7ff8000000000000ll && (b >> 63) == 0) ? (int)(b & 0xff) : 0;
 }
 
+// linked form: a store that is handed to another workgroup -- agent scope, i.e. written through the XCD's L2
+__device__ __forceinline__ void publish_u64(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- the walker's scalar arithmetic after the pixel loops, in ONE place: the fused kernel and the pair kernel
 // (pair_kernel.h) must give a walker the same bits, so both call these and nothing else ---------------------------
 // one pixel's contribution to the three fit sums of data / model against [1, u, u^2]      mft6.py:194-195
@@ -106,10 +111,11 @@ struct ChiElem {
             if (!PF) { nu[SET][j] = ld_off(u2, o16); nf[SET][j] = ld_off(f2, o16); }
         }
     }
-    __device__ __forceinline__ void prime() {  // before the pass (and before whatever the caller does first)
+    __device__ __forceinline__ void prime_from(int base) {  // before a pass that starts at pixel `base`
         if (!ALWAYS && !on) return;
-        if (AHEAD) load_trip<0>(0);
+        if (AHEAD) load_trip<0>(base);
     }
+    __device__ __forceinline__ void prime() { prime_from(0); }  // before the pass (and before whatever the caller does first)
     template <int PAR>
     __device__ __forceinline__ void begin_trip(int base) {
         if (!ALWAYS && !on) return;
@@ -179,19 +185,24 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // PF = phase A leaves the walker-independent pixel vectors it loads anyway (u, data flux) in LDS, in the tables'
 //      own layout, and the chi^2 pass reads them there instead of pulling them through the CU's L2 port a second
 //      time (one workgroup per CU only: 3 npix doubles of LDS).
-// LK = the LINKED form of the same kernel, for few walkers x long spectra (one workgroup per walker leaves CUs idle):
-//              one workgroup per (walker, SEGMENT of 8192 pixels), block = segment * pad8(n) + walker.  The workgroups of segments
-//              0 .. S-2 are PRODUCERS: recipe, blend of their segment -> model scratch, the segment's fit sums / value
-//              range / histogram -> P.segparts, then a release-increment of P.seg_flag[wk] (agent scope) and exit -- they
-//              never wait.  The workgroup of the LAST segment is the walker's JOINER: it blends its own
-//              segment into LDS, waits for the S-1 increments (bounded: kHandoverTicks, then the walker fails with
-//              MSX_W_HANDOVER and the context's linked form is POISONED: see below), copies the producers' model values
-//              into LDS, combines the segments' partials (the fit sums serially over the segments, exactly as the fused
-//              kernel adds them) and goes on as the fused kernel.  Joiners have the highest block indices: every producer a joiner waits for was
-//              dispatched before it, so the wait needs no co-residency guarantee beyond in-order dispatch -- and
-//              because a walker's blocks are a multiple of 8 apart they sit in the SAME XCD's dispatch queue
-//              (blocks go round-robin over the 8 XCDs), so the order holds even when the XCDs' dispatchers progress at
-//              different rates.  (Producers never wait: whatever else holds CUs, they finish.)
+// LK = the LINKED form of the same kernel, for few walkers x long spectra (one workgroup per walker leaves CUs idle
+//      and is a chain of 16,384 pixels' latencies): one workgroup per (walker, SEGMENT of 8192 pixels), all of them
+//      equals.  Each builds the recipe, blends ITS segment into LDS (fit sums, value range, histogram on the way) and
+//      leaves those partials in P.segparts; the walker's workgroups MEET (an arrival counter per walker, agent-scope
+//      release / acquire; the wait is bounded by kHandoverTicks, then the walker fails with MSX_W_HANDOVER and the
+//      context's linked form is POISONED: see below); every one of them then adds up the partials in segment order --
+//      exactly the fused kernel's association -- locates the median's bin from the summed histogram and makes the
+//      chi^2 / candidates pass over its own segment; chi^2 sum and candidates go to P.segparts again, and whichever
+//      workgroup ARRIVES LAST at the second meeting point (nobody waits there) ranks the candidates of all segments,
+//      adds the chi^2 sums in segment order and finishes the walker.  The model vector never leaves the CUs; a
+//      hand-over is 8 KB of counters and a few numbers.  (Vectors the early histogram cannot handle: every segment
+//      goes to the scratch row and the last arrival runs block_median over it, as the GM variants do.)
+//      Block = (walker / 8) * 8 S + segment * 8 + walker % 8: a walker's workgroups are 8 blocks apart -- blocks go
+//      round-robin over the 8 XCDs, so they share an XCD (one L2: the hand-over's data never leaves it) and follow
+//      each other in that XCD's dispatch queue: the workgroups of every walker dispatched earlier are resident or
+//      done, so the wait needs no co-residency guarantee beyond in-order dispatch.
+//      The counter is never reset: a launch adds 2 S to it, and a workgroup reads the launch's base off the value its
+//      own first increment returns (old - old % 2S).  (64 bits: it does not wrap.)
 //
 // TABLE LAYOUT.  A CU pulls data from L2 at ~32 B per clock when every lane loads 16 bytes, and no faster per
 // instruction when lanes load less -- so every per-pixel table the blend reads is stored in ELEMENTS of two pixels,
@@ -230,21 +241,20 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
     const bool smp_on = (ng_mode_fast >> 17) & 1;  // device-resident sampler: theta is a proposal built here (= P.smp_on)
     const int nsegs = LK ? (ng_mode_fast >> 24) & 0xff : 1;  // linked: workgroups per walker
-    const int64_t npad = (n + 7) & ~7ll;                     // linked: a walker's workgroups are a multiple of 8 blocks apart
-    const int64_t wk = LK ? blockIdx.x % npad : blockIdx.x;
-    const int myseg = LK ? (int)(blockIdx.x / npad) : 0;
-    const bool producer = LK && myseg != nsegs - 1;  // (uniform)
+    const unsigned int lk_grp = LK ? blockIdx.x / (8u * (unsigned int)nsegs) : 0u, lk_r = LK ? blockIdx.x % (8u * (unsigned int)nsegs) : 0u;
+    const int64_t wk = LK ? (int64_t)lk_grp * 8 + (lk_r & 7u) : blockIdx.x;
+    const int myseg = LK ? (int)(lk_r >> 3) : 0;
 #ifdef MSX_STAMPS
-    if (threadIdx.x == 0) msx_stamp_off = (MSX_STAMPS == 2) ? (LK && !producer) : producer;  // (-DMSX_STAMPS=2: the producers' stamps)
+    if (threadIdx.x == 0) msx_stamp_off = LK && myseg != ((MSX_STAMPS == 2) ? 0 : nsegs - 1);  // (one workgroup's stamps per walker)
 #endif
     RecipeRegs RR;
     if (fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
     if (LK) {
-        // a poisoned context (an earlier launch's hand-over timed out, see the joiner below): no flag is trusted,
+        // a poisoned context (an earlier launch's meeting timed out, see below): no counter is trusted,
         // every walker of every linked launch fails loudly until the problem is staged again
         if (__hip_atomic_load(P.linked_poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            if (!producer && threadIdx.x == 0) {
+            if (myseg == 0 && threadIdx.x == 0) {
                 logp[wk] = nan_with_status(MSX_W_HANDOVER);
                 status[wk] = MSX_W_HANDOVER;
                 if (P.smp_on) atomicMax(P.smp_worst, MSX_W_HANDOVER);
@@ -259,8 +269,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     double theta_lane = 0.0;
     if (fast && !smp_on && (threadIdx.x >> 6) < NS && (threadIdx.x & 63) < ndim)
         theta_lane = theta[wk * ndim + (threadIdx.x & 63)];
-    double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds);  // [npix]
-    double *const model_out = producer ? P.model_scratch + wk * P.npix : nullptr;
+    // [npix]; linked: LDS holds this workgroup's segment only, indexed by the pixel's own number all the same
+    double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds) - (LK ? myseg * (2 * kSegElems) : 0);
     const int tid = threadIdx.x;
     constexpr int B = MAXT;  // every variant is launched with exactly MAXT threads (msx_logprob_batch_dev)
     const int lane = tid & 63, wave = tid >> 6;
@@ -435,9 +445,6 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         for (int u = 0; u < U; ++u) {
             if (ok[u]) {
                 const double m = mm[u];
-                // (the linked form's producers write LDS too and copy the segment out after the loop: a global store
-                // among the loop's loads makes every wait for a row a wait for everything in flight -- 28-30k cycles
-                // per segment instead of 21k)
                 model[pp[u]] = m;
                 constexpr int slot = sub * U;  // (+ u: both unrolled)
 #pragma unroll
@@ -571,91 +578,15 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
       if (wave < 3) qrun += reduce_published<MAXT>(&red[wave][0][0], lane);
       if (seg + 1 < seg_hi) __syncthreads();  // the next segment rewrites red
     }
-    if (producer) {
-        // this segment's model values: LDS -> the scratch row (read back by the walker's joiner)
-        const int p_lo = myseg * kSegElems * 2, p_hi = (p_lo + kSegElems * 2 < npix) ? p_lo + kSegElems * 2 : npix;
-        if (((npix | p_hi) & 1) == 0) {
-            const double2 *src = reinterpret_cast<const double2 *>(model);
-            double2 *dst = reinterpret_cast<double2 *>(model_out);
-            for (int i = (p_lo >> 1) + tid; i < (p_hi >> 1); i += B) dst[i] = src[i];
-        } else {
-            for (int i = p_lo + tid; i < p_hi; i += B) model_out[i] = model[i];
-        }
-    }
     MSX_STAMP(P, wk, 2);
-    // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else.  Phase A is
-    // bound by the CU's memory pipeline and wave 0's loads are served first, so wave 0 leaves the pixel loop
-    // thousands of cycles before the last wave.  (Other modes: inside block_median.)
-    // (fused kernel: both run in waves 1 and 2 while wave 0 ranks the median's candidates, see phase B)
-    const bool late_side = early;
-    if (LK && !producer) {
-        // ---- the joiner meets its producers ----
-        if (tid == 0) {
-            const unsigned long long t0 = wall_clock64();
-            int seen;
-            for (;;) {
-                seen = __hip_atomic_load(P.seg_flag + wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen >= nsegs - 1 || wall_clock64() - t0 > kHandoverTicks) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (seen >= nsegs - 1) {
-                __hip_atomic_store(P.seg_flag + wk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-            } else {
-                // The producers did not come in time.  They may still increment the flag later in this launch, and
-                // nobody can tell when the last one has: the flags of this context are not to be trusted again.  POISON
-                // the linked form (sticky, device side): every linked launch checks the word first and reports
-                // MSX_W_HANDOVER for all of its walkers until msx_stage_problem clears flags and word together.
-                __hip_atomic_store(P.linked_poison, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            S.has_second = seen >= nsegs - 1 ? 0u : ~0u;  // (the median's own flag, 0 on its entry: ~0 = the producers never came)
-        }
-        MSX_STAMP(P, wk, 5);
-        __syncthreads();
-        if (S.has_second != 0u) {
-            if (tid == 0) walker_done(P, D, wk, ndim, NAN, MSX_W_HANDOVER, logp, status);
-            return;
-        }
-        // their model values (whole segments: pixels [0, 8192 (S-1)) ) into LDS, their histogram counts onto this
-        // segment's, their fit sums before this segment's -- the order the fused kernel adds them in
-        const double *msrc = P.model_scratch + wk * P.npix;
-        const int nprod = (nsegs - 1) * kSegElems * 2;
-        const SegPart *sp = P.segparts + wk * nseg_all;
-        static_assert(kLogBins == 4 * MAXT || !LK, "four counters per thread");
-        uint4 hc = reinterpret_cast<const uint4 *>(sp[0].hist)[tid];  // (requested first; added below)
-        if ((npix & 1) == 0) {
-            // every load of a round in flight before its first store (a segment is 8 rounds of 512 x 16 bytes)
-            const double2 *src = reinterpret_cast<const double2 *>(msrc);
-            double2 *dst = reinterpret_cast<double2 *>(model);
-            for (int i0 = 0; i0 < (nprod >> 1); i0 += 8 * B) {
-                const double2 *a = src + i0 + tid;
-                double2 *d = dst + i0 + tid;
-                const double2 v0 = a[0], v1 = a[B], v2 = a[2 * B], v3 = a[3 * B], v4 = a[4 * B], v5 = a[5 * B], v6 = a[6 * B],
-                              v7 = a[7 * B];
-                d[0] = v0; d[B] = v1; d[2 * B] = v2; d[3 * B] = v3; d[4 * B] = v4; d[5 * B] = v5; d[6 * B] = v6; d[7 * B] = v7;
-            }
-        } else {
-            for (int i = tid; i < nprod; i += B) model[i] = msrc[i];
-        }
-        {
-            uint4 mine = reinterpret_cast<uint4 *>(S.hist)[tid];
-            for (int g = 0;; ) {
-                mine.x += hc.x; mine.y += hc.y; mine.z += hc.z; mine.w += hc.w;
-                if (++g >= nsegs - 1) break;
-                hc = reinterpret_cast<const uint4 *>(sp[g].hist)[tid];
-            }
-            reinterpret_cast<uint4 *>(S.hist)[tid] = mine;
-        }
-        if (wave < 3) {
-            double acc = 0.0;
-            for (int g = 0; g < nsegs - 1; ++g) acc += sp[g].q[wave];
-            qrun = acc + qrun;
-        }
-        __syncthreads();  // the counters are complete: running totals next
-        MSX_STAMP(P, wk, 6);
-    }
+    // The contrast / photometry terms (A5/A6) need the recipe's nodes and weights and nothing else, the Gaussian prior
+    // terms (f1) theta alone, and only the walker's last line reads either: waves 1 and 2 compute them while wave 0 ranks
+    // the median's candidates (phase B) -- in the linked form while thread 0 waits at the meeting point.  (Other modes:
+    // inside block_median.)
+    const bool late_side = early && !LK;
     // the early histogram is complete (the segment loop's barrier): its running totals, published by the barrier below
-    if (early && !producer) hist_prefix_inplace<MAXT>(S);
+    // (linked: the counters of ONE segment -- they are exchanged first)
+    if (early && !LK) hist_prefix_inplace<MAXT>(S);
     {
         const unsigned int lo = wave_min_u32(fmin_), hi = wave_max_u32(fmax_);
         if (lane == 0) {
@@ -664,42 +595,183 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             S.kmax[wave] = hi;
             if (wave < 3) S.q[0][wave] = qrun;
         }
-        const int nother = (LK && !producer) ? nsegs - 1 : 0;  // segments blended elsewhere
-        if (tid < nother) {  // (the segments' ranges ride in the slots of waves that have none of their own)
-            S.kmin[nw + tid] = P.segparts[wk * nseg_all + tid].kmin;
-            S.kmax[nw + tid] = P.segparts[wk * nseg_all + tid].kmax;
-        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) q[i] = S.q[0][i];
         fmin_ = (unsigned int)S.kmin[0]; fmax_ = (unsigned int)S.kmax[0];
-        const int nr = nw + nother;
-        for (int x = 1; x < nr; ++x) {
+        for (int x = 1; x < nw; ++x) {
             fmin_ = (unsigned int)S.kmin[x] < fmin_ ? (unsigned int)S.kmin[x] : fmin_;
             fmax_ = (unsigned int)S.kmax[x] > fmax_ ? (unsigned int)S.kmax[x] : fmax_;
         }
     }
-    if (producer) {
-        // the segment's partials, for the joiner
-        SegPart *sp = P.segparts + wk * nseg_all + myseg;
-        for (int b = tid; b < kLogBins; b += B) sp->hist[b] = S.hist[b];
-        if (tid == 0) { sp->q[0] = q[0]; sp->q[1] = q[1]; sp->q[2] = q[2]; sp->kmin = fmin_; sp->kmax = fmax_; }
-        // EVERY wave first waits until its own stores (model values, histogram counters) have been acknowledged by the
-        // XCD's L2 -- s_waitcnt vmcnt(0), no cache operation; written out because the compiler's workgroup-scope
-        // release fence omits the wait (waves of one workgroup share their L1) -- and only then joins the barrier: a wave's wait covers its own stores only, and a CU's requests to different L2 channels are not
-        // ordered among themselves, so without it thread 0 could publish the flag while other waves' stores were still
-        // in flight.  After the barrier everything the workgroup wrote sits in the L2, and thread 0's agent-scope
-        // release (ONE write-back of that L2, then the increment) publishes it to the joiner's XCD.  (An agent-scope
-        // release in every wave is equally correct and costs eight write-backs per workgroup: 64 walkers x 16,384 px
-        // 40.3 us against 31.7.)
-        MSX_STAMP(P, wk, 3);
+    if (LK) {
+        // ==== the linked form: this workgroup holds ONE segment's model values, sums, range and counters ====
+        SegPart *const sp = P.segparts + wk * nsegs;
+        const unsigned long long period = 2ull * (unsigned long long)nsegs;
+        static_assert(kLogBins == 4 * MAXT || !LK, "four counters per thread");
+        // ---- first meeting: every segment's partials to every workgroup of the walker ----
+        // What is handed over is written with AGENT-SCOPE stores (publish_u64: they write through this XCD's L2), every
+        // wave waits for its own stores' acknowledgements (s_waitcnt vmcnt(0): a wave's wait covers its own stores only,
+        // and a CU's requests to different L2 channels are not ordered among themselves), and after the barrier thread 0
+        // signals with a RELAXED agent-scope increment.  That is a release without the release fence's buffer_wbl2: the
+        // write-back of the whole L2 is there for plain stores that may sit dirty in it, and these are none of those --
+        // with 32 workgroups per XCD arriving together the write-backs queue up (128 walkers x 2 segments: 14.5 k cycles
+        // per meeting with the fence).  The acquire side is the compiler's own fence.
+        {
+            const uint4 c = reinterpret_cast<const uint4 *>(S.hist)[tid];
+            unsigned long long *h = reinterpret_cast<unsigned long long *>(sp[myseg].hist) + 2 * tid;
+            publish_u64(h, (unsigned long long)c.x | ((unsigned long long)c.y << 32));
+            publish_u64(h + 1, (unsigned long long)c.z | ((unsigned long long)c.w << 32));
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) publish_u64(reinterpret_cast<unsigned long long *>(&sp[myseg].q[i]), (unsigned long long)__double_as_longlong(q[i]));
+            publish_u64(&sp[myseg].kmin, fmin_);
+            publish_u64(&sp[myseg].kmax, fmax_);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        MSX_STAMP(P, wk, 3);
+        // the pass over this segment (below) starts with loads that depend on nothing the meeting brings: they travel now
+        // (the element's "npix" is this segment's end: pixels beyond it are not this workgroup's, and the canonical sum
+        // of ONE segment has no fold)
+        const int p_lo = myseg * (2 * kSegElems), p_hi = (p_lo + 2 * kSegElems < npix) ? p_lo + 2 * kSegElems : npix;
+        ChiElem<MAXT, false, true, true> ce{P.u2, P.f2, P.iv2, ne, p_hi, 0.0, 0.0, 0.0, {}, true, &red[0][0][0], {}, {}, {}, 0.0};
+        ce.prime_from(p_lo);
+        if (tid == 0) {
+            // (test hook: nobody signals, so every wait below runs into its bound)
+            const unsigned long long old = P.linked_fault
+                                               ? __hip_atomic_load(P.seg_flag + wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : __hip_atomic_fetch_add(P.seg_flag + wk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long base = old - old % period, want = base + (unsigned long long)nsegs;
+            const unsigned long long t0 = wall_clock64();
+            bool met;
+            for (;;) {
+                met = __hip_atomic_load(P.seg_flag + wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+                if (met || wall_clock64() - t0 > kHandoverTicks) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!met) {
+                // The others did not come in time.  They may still arrive later in this launch, and nobody can tell when
+                // the last one has: the counters of this context are not to be trusted again.  POISON the linked form
+                // (sticky, device side): every linked launch checks the word first and reports MSX_W_HANDOVER for all of
+                // its walkers until msx_stage_problem clears counters and word together.
+                __hip_atomic_store(P.linked_poison, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            S.meet_state = met ? 1u : 0u;
+            S.meet_base = base;
+        } else if (wave == 1) {
+            recipe_band_terms<NS>(P, mode, th_row, D, lane);
+        } else if (wave == 2) {
+            recipe_prior_terms<NS>(P, mode, th_row, D, lane);
+        }
         __syncthreads();
         MSX_STAMP(P, wk, 4);
-        if (tid == 0 && !P.linked_fault) __hip_atomic_fetch_add(P.seg_flag + wk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (S.meet_state == 0u) {  // (every workgroup that gave up says so: whichever of them is the only one)
+            if (tid == 0) walker_done(P, D, wk, ndim, NAN, MSX_W_HANDOVER, logp, status);
+            return;
+        }
+        {   // the segments' counters added up, their fit sums in segment order -- the order the fused kernel adds them in
+            uint4 tot = make_uint4(0u, 0u, 0u, 0u);
+            double acc[3] = {0.0, 0.0, 0.0};
+            unsigned int f0 = ~0u, f1 = 0u;
+            for (int g = 0; g < nsegs; ++g) {
+                const bool own = g == myseg;
+                const uint4 c = own ? reinterpret_cast<const uint4 *>(S.hist)[tid] : reinterpret_cast<const uint4 *>(sp[g].hist)[tid];
+                tot.x += c.x; tot.y += c.y; tot.z += c.z; tot.w += c.w;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] += own ? q[i] : sp[g].q[i];
+                const unsigned int g0 = own ? fmin_ : (unsigned int)sp[g].kmin, g1 = own ? fmax_ : (unsigned int)sp[g].kmax;
+                f0 = g0 < f0 ? g0 : f0;
+                f1 = g1 > f1 ? g1 : f1;
+            }
+            reinterpret_cast<uint4 *>(S.hist)[tid] = tot;  // (each thread its own four counters)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q[i] = acc[i];
+            fmin_ = f0; fmax_ = f1;
+        }
+        hist_prefix_inplace<MAXT>(S);  // (own counters again: no barrier in between)
+        __syncthreads();
+        MSX_STAMP(P, wk, 5);
+        // ---- the pass over this segment: chi^2 terms and the candidates of the median's bin(s) ----
+        fit_coefs(P, q, ce.c0, ce.c1, ce.c2);
+        const bool need_two = (npix & 1) == 0;
+        LogbinSel Q;
+        // (uniform over the walker's workgroups: all of them hold the same totals)
+        const bool direct = frange_applicable(fmin_, fmax_) && logbin_locate_h<MAXT>(npix, fmin_, S, &Q);
+        if (direct) {
+            const unsigned int sel_p = Q.sel_p, nxt_p = Q.nxt_p;
+            pass_trips_range<MAXT>(model, p_lo, p_hi, ce, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned int pb = logbin(xv[u]);
+                    if (p[u] < p_hi && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
+                }
+            });
+            ce.flush(S);
+            __syncthreads();
+            const unsigned int nc = S.cand_n;  // (<= Q.cnt <= kSelectFinish)
+            if (wave == 0) {
+                const double c = reduce_published<MAXT>(&red[0][0][0], lane);
+                if (lane == 0) {
+                    publish_u64(reinterpret_cast<unsigned long long *>(&sp[myseg].chi), (unsigned long long)__double_as_longlong(c));
+                    publish_u64(reinterpret_cast<unsigned long long *>(&sp[myseg].ncand), (unsigned long long)nc);  // (and pad[0])
+                }
+            }
+            if (tid < (int)nc) publish_u64(&sp[myseg].cand[tid], S.cand[tid]);
+        } else {
+            // not a positive vector spanning < 8 binades, or > 256 equal-bin candidates: block_median wants the whole
+            // vector in one place -- the scratch row (plain stores: this arrival is a release with its fence)
+            double *row = P.model_scratch + wk * P.npix;
+            for (int i = p_lo + tid; i < p_hi; i += B) row[i] = model[i];
+        }
+        MSX_STAMP(P, wk, 6);
+        // ---- second meeting: nobody waits; whoever arrives last finishes the walker ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (!direct) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned long long old = __hip_atomic_fetch_add(P.seg_flag + wk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == S.meet_base + period - 1ull;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            S.meet_state = last ? 2u : 1u;
+        }
+        __syncthreads();
+        if (S.meet_state != 2u) return;
+#ifdef MSX_STAMPS
+        if (tid == 0) msx_stamp_off = 0;  // (whoever finishes the walker stamps its last lines)
+#endif
         MSX_STAMP(P, wk, 7);
-        return;
+        if (direct) {
+            // the other segments' candidates behind this one's; the chi^2 sums in segment order
+            unsigned int have = S.cand_n;
+            double chi = 0.0;
+            for (int g = 0; g < nsegs; ++g) {
+                // (the candidate slot is requested with the count, not after it: one round trip, not two)
+                const unsigned long long cg = (g != myseg && tid < kSelectFinish) ? sp[g].cand[tid] : 0ull;
+                chi += sp[g].chi;
+                if (g == myseg) continue;
+                const unsigned int ngc = sp[g].ncand;
+                if (tid < (int)ngc && have + (unsigned int)tid < (unsigned int)kSelectFinish) S.cand[have + tid] = cg;
+                have += ngc;
+            }
+            __syncthreads();
+            // (the histogram said how many there are: anything else means the segments did not see the same totals)
+            const bool sane = have == Q.cnt;
+            const double med = sane ? logbin_rank<MAXT>(S, Q, need_two, 0) : 0.0;
+            if (tid == 0) {
+                const double total = fused_total(P, chi, P.median_flux, med, npix, D.chi_extra);
+                walker_done(P, D, wk, ndim, sane ? value_of_total(mode, total, D.lp) : NAN, sane ? MSX_W_OK : MSX_W_HANDOVER, logp, status);
+                MSX_STAMP(P, wk, 15);
+            }
+            return;
+        }
+        // the whole vector is in the scratch row: on as the variants with the model vector in global memory
+        model = P.model_scratch + wk * P.npix;
+        for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
+        if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
+        __syncthreads();
     }
     MSX_STAMP(P, wk, 3);
 
@@ -723,7 +795,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     bool chi_done = false;
     double med_model = 0.0;
     bool solved = false;
-    if (early) {
+    if (early && !LK) {  // (linked: only vectors the early histogram could not handle come this far)
         ChiElem<MAXT, PF, true, kAhead> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
                                          &red[0][0][0], {}, {}, {}, 0.0};
         // positive normal values spanning < 8 binades (anything else -- zeros, negatives, infinities, NaNs, huge ranges --

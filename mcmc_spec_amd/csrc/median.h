@@ -22,6 +22,9 @@ struct alignas(16) BlockScratch {
     unsigned long long sel_result[2];
     unsigned int sel_bin, sel_k, sel_cnt, cand_n, has_second;
     unsigned int cnt_le;
+    // linked form (logprob_kernel.h): what thread 0 learnt at the walker's meeting points
+    unsigned int meet_state;
+    unsigned long long meet_base;
 };
 
 // Exact k-th smallest (0-based) of the keys of model[0..npix) by MSB radix passes; the general,
@@ -130,11 +133,12 @@ struct NoElem {
     template <int PAR> __device__ __forceinline__ void process4(int, const int (&)[4], const double (&)[4]) {}
     __device__ __forceinline__ void flush(BlockScratch &) {}
 };
-// One pass over the model vector in trips of 4 BT pixels (pass_pixel order): elem.process4, then per(p, xv).
+// One pass over the pixels [p_lo, p_hi) of the model vector in trips of 4 BT pixels (pass_pixel order; p_lo a multiple
+// of 8 BT): elem.process4, then per(p, xv).  A pixel p of a trip is valid iff p < p_hi.
 // (Validity travels as the pixel index, not as a flag: flags handed through arrays get packed into bytes and
-// unpacked again, a dozen instructions per trip; a compare against npix is one.)
+// unpacked again, a dozen instructions per trip; a compare against the end is one.)
 template <int BT, class Elem, class Per>
-__device__ __forceinline__ void pass_trips(const double *model, int npix, Elem &elem, Per per) {
+__device__ __forceinline__ void pass_trips_range(const double *model, int p_lo, int p_hi, Elem &elem, Per per) {
     const int tid = threadIdx.x;
     auto one = [&](int base, auto par) __attribute__((always_inline)) {
         elem.template begin_trip<decltype(par)::value>(base);
@@ -143,15 +147,20 @@ __device__ __forceinline__ void pass_trips(const double *model, int npix, Elem &
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // loads first, then use
             p[u] = pass_pixel<BT>(base, u, tid);
-            xv[u] = model[p[u] < npix ? p[u] : npix - 1];
+            xv[u] = model[p[u] < p_hi ? p[u] : p_hi - 1];
         }
         elem.template process4<decltype(par)::value>(base, p, xv);
         per(p, xv);
     };
-    for (int base = 0; base < npix; base += 8 * BT) {
+    for (int base = p_lo; base < p_hi; base += 8 * BT) {
         one(base, std::integral_constant<int, 0>{});
-        if (base + 4 * BT < npix) one(base + 4 * BT, std::integral_constant<int, 1>{});  // (uniform)
+        if (base + 4 * BT < p_hi) one(base + 4 * BT, std::integral_constant<int, 1>{});  // (uniform)
     }
+}
+// ... over the whole vector
+template <int BT, class Elem, class Per>
+__device__ __forceinline__ void pass_trips(const double *model, int npix, Elem &elem, Per per) {
+    pass_trips_range<BT>(model, 0, npix, elem, per);
 }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {  // l wave-uniform

@@ -114,7 +114,7 @@ struct msx_ctx {
     // (2..8 segments of 8192 pixels), the producers' partials and hand-over flags.  No launch allocates.
     double *d_model_scratch = nullptr;
     SegPart *d_segparts = nullptr;  // linked form: [scratch_rows][segments]
-    int32_t *d_seg_flag = nullptr;  // linked form: [scratch_rows] producers arrived (zero between launches), + the poison word
+    unsigned long long *d_seg_flag = nullptr;  // linked form: [scratch_rows] arrival counters (a multiple of 2 x segments between launches), + the poison word
     int nseg = 1;                   // segments of the staged spectrum (8192 pixels each)
     int64_t scratch_rows = 0;       // 0 = neither form applies: launches are never cut into sub-batches
     int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _PAIR / _LINKED (msx_set_path)
@@ -131,7 +131,7 @@ struct msx_ctx {
     // for it (so possibly a launch or two old): MSX_PATH_AUTO's only evidence of whether pairing pays (pair_worth_it)
     int32_t *h_pair_stats = nullptr;
     int64_t pair_auto_launches = 0;
-    int32_t linked = -1;            // MSX_LINKED: -1 = automatic (walkers x segments <= #CUs / 2), 0 never, 1 whenever possible
+    int32_t linked = -1;            // MSX_LINKED: -1 = automatic (walkers x segments <= #CUs), 0 never, 1 whenever possible
     bool linked_poisoned = false;   // a hand-over of the linked form timed out on this context (seen by a synchronous
                                     // entry point): MSX_PATH_AUTO takes the fused form until the problem is staged again
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
@@ -334,17 +334,18 @@ bool takes_pf(const msx_ctx *c, int64_t n) {
 // workgroup per walker and segment; else the fused kernel in the variant the table in pick_block() names).
 template <bool LK>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
-    // (linked: block = segment * pad8(n) + walker, see the kernel)
+    // (linked: block = (walker / 8) * 8 segments + segment * 8 + walker % 8, see the kernel)
     const dim3 g((unsigned)(LK ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
-    const size_t lds = sizeof(double) * (size_t)P.npix + (size_t)c->pad_lds;
+    // dynamic LDS: the model vector (linked: one segment of it)
+    const size_t lds = sizeof(double) * (size_t)(LK ? std::min<int64_t>(P.npix, 2 * kSegElems) : P.npix) + (size_t)c->pad_lds;
 #define MSX_LEAD_ARGS (P.smp_on ? (const double *)P.smp_coords : A.theta), (const unsigned char *)c->d_recipe_block, A.niso_nt, \
                       A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, P.smp_rec
 #define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                   \
     hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, LK>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
                        A.logp, A.status)
-    // dynamic LDS: the model vector; PF adds u and the data flux in the tables' pair layout
+    // PF adds u and the data flux in the tables' pair layout
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
-    if constexpr (LK) {  // (the joiner holds the whole model vector; one workgroup per CU)
+    if constexpr (LK) {
         if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
     } else if (c->model_in_global) {
         // spectra longer than the LDS: the model vector lives in the global scratch (the kernel writes it there itself)
@@ -818,7 +819,7 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     // spectrum can take: the GM variants (model vectors beyond the LDS) and the linked form (2..8 segments).  A batch
     // beyond `scratch_rows` walkers is then cut into sub-batches.  Everything else (config 2, 3, 5) allocates nothing.
     c->nseg = (int)((npair + kSegElems - 1) / kSegElems);
-    const bool can_link = c->nseg >= 2 && c->nseg <= 8 && !model_in_global;
+    const bool can_link = c->nseg >= 2 && c->nseg <= 8;  // (a workgroup of the linked form holds one segment: up to 65,536 pixels)
     P.linked_fault = 0;
     if (const char *e = getenv("MSX_LINKED_FAULT")) P.linked_fault = e[0] == '1';  // (tests: the bounded wait)
     if (model_in_global || can_link) {
@@ -834,10 +835,10 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
             HIP_TRY(c, hipMalloc((void **)&c->d_segparts, sizeof(SegPart) * sb * c->nseg));
             P.segparts = c->d_segparts;
             // hand-over flags, and behind them the poison word (cleared together, here and nowhere else)
-            HIP_TRY(c, hipMalloc((void **)&c->d_seg_flag, sizeof(int32_t) * (sb + 1)));
-            HIP_TRY(c, hipMemset(c->d_seg_flag, 0, sizeof(int32_t) * (sb + 1)));
+            HIP_TRY(c, hipMalloc((void **)&c->d_seg_flag, sizeof(unsigned long long) * (sb + 1)));
+            HIP_TRY(c, hipMemset(c->d_seg_flag, 0, sizeof(unsigned long long) * (sb + 1)));
             P.seg_flag = c->d_seg_flag;
-            P.linked_poison = c->d_seg_flag + sb;
+            P.linked_poison = reinterpret_cast<int32_t *>(c->d_seg_flag + sb);
         }
     }
     c->linked_poisoned = false;
@@ -925,20 +926,19 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
                      ((Pc.dist_fit ? 1 : 0) << 18) | ((Pc.use_av ? 1 : 0) << 19);
 
     // ---- which form of the path -------------------------------------------------------------------------
-    // linked (logprob_kernel<..., LK>): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel segment), the
-    // segments' workgroups hand over to the walker's last one inside the kernel, so that a launch of <= #CUs / 2 walkers
-    // still uses every CU.  Only the likelihood / posterior / chi^2 modes of a problem with a spectrum term and the
-    // register-resident recipe.  MSX_PATH_AUTO takes it while the launch fills at most HALF the CUs (16 walkers x
-    // 16,384 px 29.1 against 34.0 us fused, 64 walkers 32.1 against 33.9; at 128 walkers every CU is busy, the blend runs
-    // at the L2's aggregate rate instead of the CU's own and the hand-over's fences cost more than the blend gains: 36.9
-    // against 34.8).  MSX_LINKED=0 / 1 in the environment: never / whenever possible.
-    // A context whose hand-over has once timed out is POISONED until the problem is staged again: AUTO takes the
+    // linked (logprob_kernel<..., LK>): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel segment); the
+    // walker's workgroups exchange their segments' partial sums and counters inside the kernel and each makes the chi^2 /
+    // median pass over its own segment, so a launch of <= #CUs / segments walkers uses segments x as many CUs and every
+    // workgroup's chain of latencies is 8192 pixels long.  Only the likelihood / posterior / chi^2 modes of a problem
+    // with a spectrum term and the register-resident recipe.  MSX_PATH_AUTO takes it while walkers x segments <= #CUs
+    // (one workgroup per CU: they wait for each other).  MSX_LINKED=0 / 1 in the environment: never / whenever possible.
+    // A context on which a meeting has once timed out is POISONED until the problem is staged again: AUTO takes the
     // fused form, an explicit MSX_PATH_LINKED is refused (and the kernel itself fails every walker, for callers of
     // this entry point who never looked at the statuses).
     const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-    const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum && !Pc.smp_on &&
+    const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum &&
                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool linked = can_link && !c->linked_poisoned && c->linked != 0 && (c->linked > 0 || 2 * n * c->nseg <= cus);
+    bool linked = can_link && !c->linked_poisoned && c->linked != 0 && (c->linked > 0 || n * c->nseg <= cus);
     if (c->path == MSX_PATH_FUSED) linked = false;
     if (c->path == MSX_PATH_LINKED) {
         if (!can_link) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");

@@ -185,3 +185,94 @@ def test_segment_forms_with_an_odd_pixel_count(npix):
     one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
                                    c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
     assert rel_err(l[0], one) < TIGHT
+
+
+@pytest.mark.parametrize('shape', ['two_clusters', 'wide_range', 'plateau_at_median', 'flat', 'steps', 'split_plateau'])
+def test_linked_median_exits(shape):
+    """Every exit of the median with the model vector spread over several workgroups: the upper middle value in a later
+    bin (and in ANOTHER segment), candidates gathered from all segments, 65..256 equal candidates, and the vectors the
+    early histogram cannot handle -- more than 8 binades, a constant vector, thousands of duplicates -- for which
+    every segment goes to the scratch row and the last arrival runs the general select.  Two segments, a short third
+    one, odd and even pixel counts; against the fused kernel bit for bit, and the oracle."""
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import synth
+    from oracle import mft6_oracle as orc
+    teffs = np.arange(3000, 3500, 100)
+    loggs = np.array([4.5, 5.0, 5.5])
+    wl = np.arange(5400, 9100, 0.2)
+    x = (wl - 5600.0) / (8800.0 - 5600.0)
+    if shape == 'two_clusters':
+        base = np.where(x < 0.5, 1.0e5 * (1 + 1e-3 * x), 2.0e5 * (1 + 1e-3 * x))
+    elif shape == 'wide_range':
+        base = 1.0e5 * 10.0 ** (4.0 * np.clip(x, 0, 1))
+    elif shape == 'plateau_at_median':
+        base = 1.0e5 * (1 + 0.5 * np.where(np.abs(x - 0.5) < 0.004, 0.5, x))
+    elif shape == 'split_plateau':   # the median's bin holds values of the first AND the last segment
+        base = 1.0e5 * (1 + 0.5 * np.where((np.abs(x - 0.1) < 0.002) | (np.abs(x - 0.9) < 0.002), 0.5, x))
+    elif shape == 'steps':
+        base = np.where(wl < 7000.0, 1.0e5, 3.0e5) + np.where((wl > 7500) & (wl < 7600), 1.0e5 * np.sin(wl), 0.0)
+    else:
+        base = np.full_like(wl, 1.0e5)
+    flux = np.empty((len(teffs), len(loggs), len(wl)))
+    for i in range(len(teffs)):
+        for j in range(len(loggs)):
+            flux[i, j] = base * (1 + 0.01 * i + 0.02 * j)
+    specs = synth.grid_to_specs(teffs, loggs, wl, flux)
+    matrix = synth.make_isochrone_matrix()
+    ctm = [[list(np.linspace(6000, 8800, 40))], [list(np.ones(40))], [0], [7400.0]]
+    ptm = [[], [], [], []]
+    fr = [[1.0], [0.1], ['x'], [], [], []]
+    th = np.array([[3250.0, 3120.0, 0.0, 0.5, 0.4, 2e-3], [3260.0, 3149.0, 0.0, 0.7, 0.9, 3e-3],
+                   [3250.0, 3120.0, 0.3, 0.5, 0.4, 2e-3], [3300.0, 3049.0, 0.2, 0.7, 0.9, 3e-3],
+                   [3210.0, 3110.0, 0.1, 0.6, 0.5, 2e-3]])
+    for npix in (16384, 9001, 20000):
+        wl_um = np.linspace(0.56, 0.88, npix)
+        rng = np.random.default_rng(4)
+        data = [wl_um, 1 + 0.05 * rng.normal(size=npix)]
+        err = np.full(npix, 0.05)
+        r = [wl_um.min(), wl_um.max()]
+        eng = Engine(0)
+        eng.stage_specs(specs)
+        eng.stage_problem(data, err, fr, r, ctm, ptm, 6000.0, 8800.0, matrix, nspec=2)
+        f, l = both(eng, eng.loglikelihood, th)
+        assert np.array_equal(f, l, equal_nan=True), (shape, npix)
+        assert np.all(np.isfinite(l)), (shape, npix)
+        want = np.array([orc.loglikelihood(list(t), fr, 2, data, err, r, specs, ctm, ptm, 6000.0, 8800.0, matrix)
+                         for t in th[:2]])
+        assert rel_err(l[:2], want).max() < TIGHT, (shape, npix)
+        if shape == 'steps' and npix == 16384:
+            # more walkers than CUs, all of them through the scratch rows, and again (the counters went on counting)
+            many = np.repeat(th, 80, axis=0)
+            many[:, 3] *= 1.0 + 1e-4 * np.arange(len(many))
+            for _ in range(2):
+                f, l = both(eng, eng.loglikelihood, many)
+                assert np.array_equal(f, l) and np.all(np.isfinite(l))
+
+
+def test_device_resident_sampler_through_the_linked_form():
+    """The stretch move resident on the GPU over config 4's spectrum: a half-step of 24 walkers x 2 segments takes the
+    linked form by itself (MSX_PATH_AUTO) -- proposal, both meetings, accept step by whichever workgroup finishes the
+    walker -- and must walk the chain the fused kernel walks, bit for bit; the same through a sharded loopback group
+    (two ranks: 12 proposals each, log p(q) only, the accept step after the gather)."""
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    from test_gpu_shard_loopback import run_group
+    eng, W = _config4_engine()
+    nw = 48
+    p0 = synth.draw_walkers(nw, seed=21, tmin=W['tmin'], tmax=W['tmax'])
+    chains = []
+    for path in (_lib.PATH_FUSED, _lib.PATH_AUTO, _lib.PATH_LINKED):
+        eng.ctx.set_path(path)
+        s = DeviceEnsembleSampler(nw, 6, eng, seed=3, chunk=8)
+        st = s.run_mcmc(p0, 20)
+        chains.append((s.get_chain(), s.get_log_prob(), st.coords, st.log_prob))
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    for c in chains[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(chains[0], c))
+    acc = np.mean(np.any(np.diff(chains[0][0], axis=0) != 0, axis=2))
+    assert 0.05 < acc < 0.95
+    eng2, _ = _config4_engine()
+    _lib.Context.comm_init_loopback([eng.ctx, eng2.ctx])
+    got = run_group([eng, eng2], p0, 20, seed=3)
+    for chain, lp, nacc, worst, coords, logp in got:
+        assert worst == 0 and np.array_equal(chain, chains[0][0]) and np.array_equal(lp, chains[0][1])

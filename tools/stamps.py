@@ -3,9 +3,8 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=8 -DMSX_STAMPS -o build/libmsx_stamps.so mcmc_spec_amd/csrc/msx.hip
     MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 256 --block 1024
-    MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 128 --npix 16384 --path linked     # the joiners' stamps
-(-DMSX_STAMPS=2 -o build/libmsx_stamps2.so: the linked form's PRODUCERS write the stamps instead;
-    MSX_STAMPS_PRODUCERS=1 MSX_LIB=build/libmsx_stamps2.so python tools/stamps.py --walkers 128 --npix 16384 --path linked)
+    MSX_LIB=build/libmsx_stamps.so python tools/stamps.py --walkers 128 --npix 16384 --path linked     # each walker's last segment
+(-DMSX_STAMPS=2 -o build/libmsx_stamps2.so: the workgroup of the walker's FIRST segment writes the stamps instead)
 """
 import argparse
 import ctypes as C
@@ -24,7 +23,7 @@ def main():
     ap.add_argument('--npix', type=int, default=4096)
     ap.add_argument('--mode', default='logpost')
     ap.add_argument('--av0', action='store_true', help='all walkers at A_V = 0: no reddening, the blend loads R only')
-    ap.add_argument('--path', default='fused', help='fused | linked (linked: the joiners; with MSX_STAMPS_PRODUCERS and a -DMSX_STAMPS=2 build, the producers)')
+    ap.add_argument('--path', default='fused', help='fused | linked')
     args = ap.parse_args()
     import torch
     from bench import build_workload
@@ -50,24 +49,20 @@ def main():
     fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     fn.restype = C.c_int
     assert fn(eng.ctx.h, n, out.ctypes.data) == 0
-    if args.path == 'linked' and os.environ.get('MSX_STAMPS_PRODUCERS'):  # library built with -DMSX_STAMPS=2
+    if args.path == 'linked':  # the stamps of each walker's LAST segment's workgroup (-DMSX_STAMPS=2: of its first)
         o = out.astype(np.int64)
-        order = [0, 1, 2, 3, 4, 7]
-        names = ['phase0 recipe', 'phaseA blend + copy to the scratch', 'fit sums + range + partials stored', 'barrier', 'release + increment']
-        print('linked path, producers (segment 0), walkers {}: median total {} cycles'.format(n, int(np.median(o[:, 7] - o[:, 0]))))
+        order = [0, 1, 2, 3, 4, 5, 6]
+        names = ['phase0 recipe', 'phaseA blend (one segment)', 'fit sums + range + partials stored', 'first meeting (release, wait, acquire)',
+                 'totals + running totals', 'locate + chi2 / candidates pass + stored']
+        print('linked form, walkers {}: median entry -> pass stored {} cycles'.format(n, int(np.median(o[:, 6] - o[:, 0]))))
         for i, nm in enumerate(names):
             v = o[:, order[i + 1]] - o[:, order[i]]
-            print('  {:36s} median {:8d} cycles'.format(nm, int(np.median(v))))
-        return
-    if args.path == 'linked':  # the joiner's stamps (the producers write none)
-        o = out.astype(np.int64)
-        order = [0, 1, 2, 5, 6, 3, 4, 7, 15]
-        names = ['phase0 recipe', 'phaseA blend (last segment)', 'wait for the producers', 'their model values + partials', 'fit sums + range',
-                 'median + chi2 pass', 'tail', 'closing barrier + store']
-        print('linked path, joiners, walkers {}: median total {} cycles'.format(n, int(np.median(o[:, 15] - o[:, 0]))))
-        for i, nm in enumerate(names):
-            v = o[:, order[i + 1]] - o[:, order[i]]
-            print('  {:32s} median {:8d} cycles'.format(nm, int(np.median(v))))
+            print('  {:40s} median {:8d}   max {:8d} cycles'.format(nm, int(np.median(v)), int(v.max())))
+        fin = o[:, 15] - o[:, 7]
+        print('  {:40s} median {:8d} cycles'.format('finisher: gather + rank + last lines', int(np.median(fin))))
+        mine = o[:, 7] > o[:, 6]   # (this workgroup was the finisher of the last launch -- or of an earlier one)
+        if mine.any():
+            print('  {:40s} median {:8d} cycles  ({} of {} walkers)'.format('second meeting (when the finisher)', int(np.median((o[:, 7] - o[:, 6])[mine])), int(mine.sum()), n))
         print('  first start -> last end: {} cycles'.format(int(o[:, 15].max() - o[:, 0].min())))
         return
     d = np.diff(out[:, :8].astype(np.int64), axis=1)
