@@ -713,8 +713,11 @@ def main():
                 th = torch.from_numpy(synth.draw_walkers(128, seed=3, tmin=W4['tmin'], tmax=W4['tmax'])).to(dev)
                 lp_, st_ = torch.empty(128, dtype=torch.float64, device=dev), torch.empty(128, dtype=torch.int32, device=dev)
                 us = device_time_us(e4, th, lp_, st_, stream, 128, 50)
+                # (MSX_PATH_AUTO's rule, msx.hip auto_takes_linked: walkers x segments <= #CUs)
+                linked = os.environ.get('MSX_LINKED', '') != '0' and 128 * 2 <= e4.ctx.device_info()['cus']
                 extra['config4_per_gpu_share'] = {'walkers': 128, 'npix': 16384, 'photometry_bands': 6, 'device_us': us,
                                                   'evals_per_s': 128 / us * 1e6,
+                                                  'form': 'linked (one workgroup per walker and 8192-pixel segment)' if linked else 'fused',
                                                   'requested_bytes_per_eval': e4.ctx.bytes_per_eval(128)}
         if extra:
             out['extra'] = extra

@@ -146,15 +146,17 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
 /* Two forms of the same path, same bits.
  * FUSED: one launch, one workgroup per walker.
  * LINKED: for few walkers x long spectra (2..8 segments of 8192 pixels), one workgroup per (walker, segment) in ONE
- * launch, so that e.g. 32 walkers x 16,384 pixels use 64 CUs instead of 32.  The workgroups of a walker's first S-1
- * segments publish their model values and partials and leave; the workgroup of the last segment waits for them inside
- * the kernel (bounded: 20 ms), and runs the median / chi^2 phases.  MSX_PATH_AUTO takes it while walkers x segments
- * <= #CUs / 2 (MSX_LINKED=0 in the environment: never; =1: whenever the spectrum has 2..8 segments): 16 walkers x
- * 16,384 px 29.1 us against 34.0 fused; with every CU busy it loses.
- * A hand-over that times out fails its walker with MSX_W_HANDOVER and POISONS the context's linked form: a device-side
+ * launch, so that e.g. 128 walkers x 16,384 pixels use 256 CUs instead of 128 and each workgroup's chain of latencies
+ * is 8192 pixels long.  A walker's workgroups are equals: each blends its segment, they exchange the segments' fit
+ * sums / value ranges / histogram counters inside the kernel (a bounded wait: 20 ms), each makes the chi^2 / median-
+ * candidates pass over its own segment, and whichever finishes last ranks the candidates and completes the walker.
+ * MSX_PATH_AUTO takes it while walkers x segments <= #CUs (MSX_LINKED=0 in the environment: never; =1: whenever the
+ * spectrum has 2..8 segments): 128 walkers x 16,384 px 28.6 us against 33.3 fused, 8..64 walkers 24.4..25.8 us
+ * (DESIGN.md); also under the device-resident sampler.
+ * A meeting that times out fails its walker with MSX_W_HANDOVER and POISONS the context's linked form: a device-side
  * word makes every later linked launch fail ALL its walkers with MSX_W_HANDOVER (never a value computed from stale
- * flags), MSX_PATH_AUTO takes the fused form once a synchronous entry point has seen the status, an explicit
- * MSX_PATH_LINKED is refused with MSX_ERR_STATE -- until msx_stage_problem clears flags and word together.
+ * counters), MSX_PATH_AUTO takes the fused form once a synchronous entry point has seen the status, an explicit
+ * MSX_PATH_LINKED is refused with MSX_ERR_STATE -- until msx_stage_problem clears counters and word together.
  * (Values 2 and 3 were the split and wide forms of rounds 1-2: measured slower than FUSED at every size and removed;
  * the measurements are kept in DESIGN.md.)                                                                        */
 #define MSX_PATH_AUTO 0
@@ -260,8 +262,8 @@ int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
 int msx_pair_stats(msx_ctx *ctx, int64_t *out2);
 
 /* ---- test hooks (used by tests/ only) ------------------------------------------------------------ */
-/* MSX_HOOK_LINKED_FAULT: value != 0 makes the producers of the linked form skip their signal, so that every joiner
- * runs into its bounded wait; takes effect at the next launch, without restaging                                  */
+/* MSX_HOOK_LINKED_FAULT: value != 0 makes the workgroups of the linked form skip their signal, so that every one of
+ * them runs into its bounded wait; takes effect at the next launch, without restaging                             */
 #define MSX_HOOK_LINKED_FAULT 1
 int msx_test_hook(msx_ctx *ctx, int32_t what, int32_t value);
 

@@ -645,11 +645,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                                                : __hip_atomic_fetch_add(P.seg_flag + wk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long base = old - old % period, want = base + (unsigned long long)nsegs;
             const unsigned long long t0 = wall_clock64();
-            bool met;
-            for (;;) {
-                met = __hip_atomic_load(P.seg_flag + wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
-                if (met || wall_clock64() - t0 > kHandoverTicks) break;
+            bool met = !P.linked_fault && old + 1ull >= want;  // (whoever arrives last knows from its own increment)
+            while (!met) {
+                if (wall_clock64() - t0 > kHandoverTicks) break;
                 __builtin_amdgcn_s_sleep(1);
+                met = __hip_atomic_load(P.seg_flag + wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (!met) {

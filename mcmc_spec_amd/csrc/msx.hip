@@ -380,6 +380,14 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     return MSX_OK;
 }
 
+// Does MSX_PATH_AUTO take the linked form for n walkers (of a problem and mode that have one)?  While every workgroup
+// gets a CU of its own: the walker's workgroups wait for each other.
+bool auto_takes_linked(const msx_ctx *c, int64_t n) {
+    const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    return c->d_seg_flag != nullptr && c->recipe_fast && !c->P.no_spectrum && !c->linked_poisoned && c->linked != 0 &&
+           c->path != MSX_PATH_FUSED && c->path != MSX_PATH_PAIR && (c->linked > 0 || c->path == MSX_PATH_LINKED || n * c->nseg <= cus);
+}
+
 // Does MSX_PATH_AUTO take the pair form for the next large batch?  A walker the planner cannot pair costs the pair kernel
 // a whole workgroup (two per CU: 0.042 us per item at 16,384 walkers) where the fused kernel runs three per CU (0.027 us
 // per walker), so pairing pays while singles < 0.75 pairs -- an ensemble in a handful of grid cells, the normal state of
@@ -935,11 +943,9 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // A context on which a meeting has once timed out is POISONED until the problem is staged again: AUTO takes the
     // fused form, an explicit MSX_PATH_LINKED is refused (and the kernel itself fails every walker, for callers of
     // this entry point who never looked at the statuses).
-    const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum &&
                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool linked = can_link && !c->linked_poisoned && c->linked != 0 && (c->linked > 0 || n * c->nseg <= cus);
-    if (c->path == MSX_PATH_FUSED) linked = false;
+    bool linked = can_link && auto_takes_linked(c, n);
     if (c->path == MSX_PATH_LINKED) {
         if (!can_link) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
         if (c->linked_poisoned)
@@ -1622,8 +1628,15 @@ int msx_bytes_per_eval(msx_ctx *c, int64_t n, int64_t *requested_bytes) {
     // what the variant an automatic launch of n walkers takes requests from the memory system, per walker:
     //   blend: 12-B {R f64, H f32} per corner + {k_lo f64, dk f32} + data flux, u (f64)        per pixel
     //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
-    const bool pf = pick_block(c, n, npix) == 512 && takes_pf(c, n);
+    const bool linked = auto_takes_linked(c, n);
+    const bool pf = !linked && pick_block(c, n, npix) == 512 && takes_pf(c, n);
     *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
+    // the linked form: every segment's workgroup reads theta and writes its partials (counters, sums, range; chi^2 sum
+    // and candidates: <= 64 of them as a rule), reads the other segments' partials, and one of them their candidates
+    if (linked) {
+        const int64_t S = c->nseg, part = 4 * kSegBins + 64, fin = 16 + 8 * 64;
+        *requested_bytes += (S - 1) * (8 * (2 * c->P.nspec + 2)) + S * (part + fin) + S * (S - 1) * part + (S - 1) * fin;
+    }
     // the pair form (MSX_PATH_AUTO from pair_min_walkers on, for an ensemble that pairs): two walkers per set of loads --
     // rows, extinction terms, the fit sweep's data flux / u, the pass's three vectors -- + the planner's record
     if (c->pair_rows > 0 && c->P.nspec == 2 && n >= c->pair_min_walkers && c->path != MSX_PATH_FUSED && c->path != MSX_PATH_LINKED)

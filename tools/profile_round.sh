@@ -5,7 +5,7 @@
 # 1. kernel trace + stats of the default bench (config 2: 256 walkers x 4096 px), then two separate PMC passes
 #    (FETCH_SIZE, WRITE_SIZE -- never combined with trace domains) -> <tag>_logprob_kernel_stats.csv, _traffic.json
 # 2. SQ counter passes (counters only) at 256 / 3072 walkers (fused), 16,384 walkers (fused and pair) and config 4's
-#    share -> <tag>_valu.json, <tag>_sq_*.json
+#    share (fused and linked) -> <tag>_valu.json, <tag>_sq_*.json
 # 3. per-kernel times of the forms: fused against pair (planner + pair kernel) at 4,096 / 16,384 walkers, fused against
 #    linked at 16,384 px
 # 4. sweeps (device time per batch), the dependent chain
@@ -26,7 +26,7 @@ python3 tools/pmc_summary.py --kt $out/kt --fetch $out/pmc_fetch --write $out/pm
 grep '^{' $out/bench_kt.json > $dst/${tag}_bench_under_rocprof.json
 echo "[profile_round] 1 done" >&2
 # ---- SQ counters
-for cs in 4096:256:fused 4096:3072:fused 4096:16384:fused 4096:16384:pair 16384:128:fused; do
+for cs in 4096:256:fused 4096:3072:fused 4096:16384:fused 4096:16384:pair 16384:128:fused 16384:128:linked; do
   IFS=: read npix n path <<< "$cs"
   tools/pmc_kernels.sh $tag $npix $n $path > $out/sq_${npix}_${n}_$path.txt 2>&1
   cp $root/gpurun_out/pmck_${tag}_${npix}_${n}_$path/summary.json $dst/${tag}_sq_${npix}px_${n}walkers_$path.json
@@ -38,7 +38,7 @@ out = {'source': 'rocprofv3 --pmc (SQ counters only, two passes per point; tools
        'note': 'SQ_INSTS_VALU = vector ALU wave-instructions per launch; SQ_ACTIVE_INST_VALU counts quad-cycles; VALU busy = '
                '4 x SQ_ACTIVE_INST_VALU / (kernel time x clock x 1024 SIMDs) is derived in DESIGN.md from the kernel times of the same points',
        'points': []}
-for npix, n, path in ((4096, 256, 'fused'), (4096, 3072, 'fused'), (4096, 16384, 'fused'), (4096, 16384, 'pair'), (16384, 128, 'fused')):
+for npix, n, path in ((4096, 256, 'fused'), (4096, 3072, 'fused'), (4096, 16384, 'fused'), (4096, 16384, 'pair'), (16384, 128, 'fused'), (16384, 128, 'linked')):
     j = json.load(open('%s/%s_sq_%dpx_%dwalkers_%s.json' % (dst, tag, npix, n, path)))
     for k, m in j.items():
         if 'pair_plan' in k:
