@@ -215,6 +215,15 @@ int msx_sampler_enqueue(msx_ctx *ctx, int32_t slot /* 0|1 */, int64_t nsteps, co
 int msx_sampler_collect(msx_ctx *ctx, int32_t slot, double *chain_out, double *logp_out, int64_t *naccept,
                         int32_t *worst_status);
 int msx_sampler_end(msx_ctx *ctx, double *coords, double *logp);
+/* OVERLAPPED half-steps (one GPU, unsharded, a half-step of at most #CUs / 2 walkers through the fused kernel with one
+ * workgroup per CU -- config 2's 256 walkers): consecutive half-steps go to two streams and run concurrently; a walker's
+ * workgroup waits inside the kernel (bounded: 20 ms, then the chunk's worst_status is MSX_W_HANDOVER) until the two
+ * walkers its move reads have reached the versions the move is defined on, the coordinates are double-buffered by
+ * version parity and each finished walker publishes its new version -- so a half-step's launch, start-up and slowest
+ * walker no longer sit between two dependent evaluations (256 walkers x 4096 px: 33.9 us per iteration against 37.1).
+ * Same chain, bit for bit.  Chosen by the first msx_sampler_enqueue of a run; MSX_SMP_OVERLAP=0 in the environment:
+ * never.  *out = 1 if the run begun on ctx takes it, 0 if not, -1 before its first chunk.                           */
+int msx_sampler_overlapped(msx_ctx *ctx, int32_t *out);
 
 /* ---- A4-A6: make_composite (mft6.py:651-831, plot=False) -------------------------------------- */
 /* teff/logg/rad are [nspec]; use_distance = 0 mirrors `distance=False` (mft6.py:701-703).         */
@@ -262,8 +271,9 @@ int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
 int msx_pair_stats(msx_ctx *ctx, int64_t *out2);
 
 /* ---- test hooks (used by tests/ only) ------------------------------------------------------------ */
-/* MSX_HOOK_LINKED_FAULT: value != 0 makes the workgroups of the linked form skip their signal, so that every one of
- * them runs into its bounded wait; takes effect at the next launch, without restaging                             */
+/* MSX_HOOK_LINKED_FAULT: value != 0 makes the workgroups of the linked form skip their signal -- and the walkers of an
+ * overlapped sampler run the publication of their new version -- so that every in-kernel wait runs into its bound;
+ * takes effect at the next launch, without restaging                                                              */
 #define MSX_HOOK_LINKED_FAULT 1
 int msx_test_hook(msx_ctx *ctx, int32_t what, int32_t value);
 

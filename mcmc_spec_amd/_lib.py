@@ -117,6 +117,7 @@ def load():
         'msx_bytes_per_eval': (C.c_int, [vp, C.c_int64, _ip]),
         'msx_test_hook': (C.c_int, [vp, C.c_int32, C.c_int32]),
         'msx_pair_stats': (C.c_int, [vp, _ip]),
+        'msx_sampler_overlapped': (C.c_int, [vp, C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library skew, fail loudly
@@ -132,7 +133,7 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_logprob_batch_dev', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
-            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook', 'msx_pair_stats']
+            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped']
 
 
 def as_f64(a):
@@ -301,6 +302,12 @@ class Context:
         self.check(self.lib.msx_sampler_begin(self.h, int(mode), nw, ndim, int(max_chunk_steps), dptr(coords), dptr(logp),
                                               None if nacc is None else iptr(nacc)))
         self._smp_shape = (nw, ndim)
+
+    def sampler_overlapped(self):
+        """1 if the run in flight overlaps its half-steps (msx_sampler_overlapped), 0 if not, -1 before its first chunk."""
+        out = C.c_int32()
+        self.check(self.lib.msx_sampler_overlapped(self.h, C.byref(out)))
+        return out.value
 
     def sampler_shard(self, rank, world):
         """Shard the run begun by sampler_begin over `world` ranks (msx_sampler_shard); world > 1 needs comm_init."""

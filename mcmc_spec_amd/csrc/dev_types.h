@@ -26,6 +26,9 @@ constexpr double kLog2Of10 = 3.3219280948873623478703194294893901758648313930245
 struct SmpRec {  // the stretch move of one walker of a half-step
     int32_t si, ci;  // ensemble index of the walker and of its partner in the complementary half
     double zz;       // the stretch factor
+    // overlapped half-steps (smp_overlap): the VERSIONS (= updates so far) of the two walkers this move reads -- the
+    // workgroup waits until the ensemble holds them, and finds version v of a walker in coordinate buffer v & 1
+    uint32_t ver_own, ver_partner;
 };
 struct DevProblem {
     // grid (A0)
@@ -103,6 +106,12 @@ struct DevProblem {
     int64_t *smp_naccept;                   // [nw]
     double *smp_chain_row, *smp_lp_row;     // chain[step] [nw][ndim], logp chain[step] [nw]
     int32_t *smp_worst;
+    // overlapped half-steps (msx.hip, chunk_half_eval): consecutive half-steps are launched on two streams and run
+    // concurrently; a walker's workgroup waits for the versions of the two walkers it reads (SmpRec), the state is
+    // double-buffered by version parity (smp_coords = [2][nw][ndim], smp_stride = nw * ndim) and published per walker
+    int32_t smp_overlap;
+    int64_t smp_stride;
+    uint32_t *smp_ver;                      // [nw] updates of each walker so far
 #ifdef MSX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
 #endif
@@ -135,6 +144,7 @@ struct WalkerDesc {
     double smp_old, smp_zfac, smp_logu;   // its current log-probability, (ndim-1) ln z, ln u
     int64_t smp_s;                        // its index in the ensemble
     int64_t smp_nacc;                     // its acceptance count so far
+    uint32_t smp_ver;                     // overlapped half-steps: its version before this move
 };
 
 // The recipe's small tables, gathered into ONE block so that a single preloaded pointer reaches them all (fixed

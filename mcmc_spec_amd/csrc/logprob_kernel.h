@@ -67,6 +67,27 @@ __device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDes
     const int64_t s = D.smp_s;
     const double lnpdiff = (D.smp_zfac + out) - D.smp_old;
     const bool acc = D.smp_logu < lnpdiff;
+    if (P.smp_overlap) {
+        // Overlapped half-steps: the next half-step's workgroups are already resident and wait for THIS walker's next
+        // version.  The state goes out with agent-scope stores (through the L2, like the linked form's partials), into
+        // the coordinate buffer of the new version's parity -- accepted or not: the other buffer still holds what
+        // workgroups of the half-steps in flight may be reading -- and then the version itself.
+        double *row = P.smp_coords + (int64_t)((D.smp_ver + 1u) & 1u) * P.smp_stride + s * ndim;
+        for (int d = 0; d < ndim; ++d) {
+            const double v = acc ? D.theta[d] : D.smp_sv[d];
+            publish_u64(reinterpret_cast<unsigned long long *>(row + d), (unsigned long long)__double_as_longlong(v));
+            P.smp_chain_row[s * ndim + d] = v;
+        }
+        if (acc) {
+            publish_u64(reinterpret_cast<unsigned long long *>(P.smp_logp + s), (unsigned long long)__double_as_longlong(out));
+            publish_u64(reinterpret_cast<unsigned long long *>(P.smp_naccept + s), (unsigned long long)(D.smp_nacc + 1));
+        }
+        P.smp_lp_row[s] = acc ? out : D.smp_old;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (test hook: nobody publishes, so every wait of the following half-steps runs into its bound)
+        if (!P.linked_fault) __hip_atomic_store(P.smp_ver + s, D.smp_ver + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (acc) {
         P.smp_logp[s] = out;
         P.smp_naccept[s] = D.smp_nacc + 1;
@@ -225,7 +246,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     //   rblk            the recipe's tables in one block (dev_types.h: isochrone Teff / logg, the grid's node lists and
     //                   per-Teff-node presence bits at fixed offsets; from P.iso_t, P.iso_g, P.teff_nodes, ...)
     //   niso_nt         niso | nt << 16
-    //   ng_mode_fast    ng | mode << 8 | fast << 16 | sampler << 17 | dist_fit << 18 | use_av << 19 | segments << 24
+    //   ng_mode_fast    ng | mode << 8 | fast << 16 | sampler << 17 | dist_fit << 18 | use_av << 19 | overlap << 20 | segments << 24
     //   n               the batch size (ndim is 2 NS + 2, checked by the host)
     //   gate_tmin/tmax  the Teff box of the prior's hard gates (= P.tmin, P.tmax)
     //   theta, smp_rec  device-resident sampler: `theta` is the resident ensemble (= P.smp_coords) and smp_rec the
@@ -240,6 +261,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const bool fast = (ng_mode_fast >> 16) & 1;  // register-resident tables fit one wave (the usual case)
     const bool smp_on = (ng_mode_fast >> 17) & 1;  // device-resident sampler: theta is a proposal built here (= P.smp_on)
+    const bool overlap = (ng_mode_fast >> 20) & 1;  // ... with overlapped half-steps (= P.smp_overlap)
     const int nsegs = LK ? (ng_mode_fast >> 24) & 0xff : 1;  // linked: workgroups per walker
     const unsigned int lk_grp = LK ? blockIdx.x / (8u * (unsigned int)nsegs) : 0u, lk_r = LK ? blockIdx.x % (8u * (unsigned int)nsegs) : 0u;
     const int64_t wk = LK ? (int64_t)lk_grp * 8 + (lk_r & 7u) : blockIdx.x;
@@ -301,12 +323,35 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // trip, no barrier.  Wave 0 also leaves it in LDS for the phases after phase 0; a non-recipe wave meanwhile
         // fetches what the accept step will need at the very end.
         const SmpRec rc = smp_rec[wk];
+        // Overlapped half-steps: this workgroup may have been dispatched while the half-step(s) before it are still
+        // running.  Every wave that reads the ensemble -- the recipe waves (both rows) and the wave that fetches the
+        // accept step's inputs (the walker's own entries) -- first waits until the walkers it reads have reached the
+        // versions the move is defined on (bounded: then the chunk reports MSX_W_HANDOVER), acquires, and takes version
+        // v of a walker from coordinate buffer v & 1.
+        int64_t own_off = 0, par_off = 0;
+        if (overlap && wave <= NS) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                const unsigned int vo = __hip_atomic_load(P.smp_ver + rc.si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int vp = wave < NS ? __hip_atomic_load(P.smp_ver + rc.ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rc.ver_partner;
+                // (versions only grow; a walker is never more than one version ahead of what this move wants)
+                if ((int)(vo - rc.ver_own) >= 0 && (int)(vp - rc.ver_partner) >= 0) break;
+                if (wall_clock64() - t0 > kHandoverTicks) {
+                    if (lane == 0) atomicMax(P.smp_worst, MSX_W_HANDOVER);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            own_off = (int64_t)(rc.ver_own & 1u) * P.smp_stride;
+            par_off = (int64_t)(rc.ver_partner & 1u) * P.smp_stride;
+        }
         if (wave < NS && lane < ndim) {
 #pragma clang fp contract(off)
             // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
             // the device-resident and the host-driven sampler stay in lock-step
-            const double sv = theta[(int64_t)rc.si * ndim + lane];
-            const double cv = theta[(int64_t)rc.ci * ndim + lane];
+            const double sv = theta[own_off + (int64_t)rc.si * ndim + lane];
+            const double cv = theta[par_off + (int64_t)rc.ci * ndim + lane];
             const double diff = cv - sv;
             const double prod = diff * rc.zz;
             const double qv = cv - prod;
@@ -319,6 +364,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         } else if (tid == NS * kWave) {
             const int64_t si = rc.si;
             D.smp_s = si;
+            D.smp_ver = rc.ver_own;
             D.smp_old = P.smp_logp[si];
             D.smp_nacc = P.smp_naccept[si];
             D.smp_zfac = P.smp_zfac[wk];

@@ -137,6 +137,7 @@ struct msx_ctx {
     bool recipe_fast = false;       // the register-resident recipe applies (small tables)
     unsigned char *d_recipe_block = nullptr;  // ... and its tables in one block (dev_types.h), freed with the problem
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
+    bool smp_overlap_launch = false;   // the launch being queued is a half-step of an overlapped run: fused form, bit 20
 };
 static void sampler_free(msx_ctx *c);
 
@@ -945,7 +946,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // this entry point who never looked at the statuses).
     const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum &&
                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool linked = can_link && auto_takes_linked(c, n);
+    bool linked = can_link && auto_takes_linked(c, n) && !c->smp_overlap_launch;
     if (c->path == MSX_PATH_LINKED) {
         if (!can_link) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
         if (c->linked_poisoned)
@@ -956,6 +957,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     const bool can_pair = c->pair_rows > 0 && fast && !Pc.smp_on && Pc.nspec == 2 &&
                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
     bool pair = can_pair && n >= c->pair_min_walkers && pair_worth_it(c);
+    if (c->smp_overlap_launch) A.ng_mode_fast |= 1 << 20;
     if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_LINKED) pair = false;
     if (c->path == MSX_PATH_PAIR) {
         if (!can_pair) return fail(c, MSX_ERR_STATE, "msx_set_path(PAIR): needs a binary of <= 4096 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
@@ -1097,12 +1099,22 @@ struct SamplerRun {
     int32_t *d_wst = nullptr;
     hipStream_t copy = nullptr, up = nullptr;  // downloads / uploads: separate queues, or chunk i+1's upload
                                                // would wait behind chunk i's download (which waits for its kernels)
+    // Overlapped half-steps (one GPU, a half-step that fills at most half the CUs): half-step j goes to stream j & 1
+    // and starts while j - 1 is still running; its workgroups wait per walker for the versions they read (SmpRec,
+    // logprob_kernel.h), the coordinates are double-buffered by version parity, and an event keeps j behind j - 3 --
+    // the last launch that may still read what j overwrites (j - 2 shares j's stream).
+    int overlap = -1;               // -1: decided at the first chunk; 0 / 1
+    hipStream_t s2 = nullptr;
+    hipEvent_t hs_done[4] = {nullptr, nullptr, nullptr, nullptr}, chunk_open = nullptr, s2_done = nullptr;
+    int64_t steps_done = 0;         // iterations queued so far = every walker's version when they are done
+    uint32_t *d_ver = nullptr;
     struct Slot {
         char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
         hipEvent_t in_ready = nullptr, kernels_done = nullptr, out_ready = nullptr;
         int64_t nsteps = 0;
         bool busy = false;
     } slot[2];
+    double *coords_now() const { return d_coords + (overlap == 1 ? (steps_done & 1) * nw * ndim : 0); }
     size_t in_bytes(int64_t st) const {  // [zz | zfac | logu | sidx | cidx | partner | records]
         return (size_t)(st * 2 * ns) * (3 * sizeof(double) + 3 * sizeof(int32_t) + sizeof(SmpRec));
     }
@@ -1127,6 +1139,12 @@ static void sampler_free(msx_ctx *c) {
         if (sl.kernels_done) (void)hipEventDestroy(sl.kernels_done);
         if (sl.out_ready) (void)hipEventDestroy(sl.out_ready);
     }
+    if (r->s2) (void)hipStreamSynchronize(r->s2);
+    for (auto &ev : r->hs_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (r->chunk_open) (void)hipEventDestroy(r->chunk_open);
+    if (r->s2_done) (void)hipEventDestroy(r->s2_done);
+    if (r->s2) (void)hipStreamDestroy(r->s2);
     if (r->d_state) (void)hipFree(r->d_state);
     if (r->d_newlp_all) (void)hipFree(r->d_newlp_all);
     if (r->copy) (void)hipStreamDestroy(r->copy);
@@ -1135,6 +1153,8 @@ static void sampler_free(msx_ctx *c) {
     c->smp = nullptr;
     c->P.smp_on = 0;
     c->P.smp_defer = 0;
+    c->P.smp_overlap = 0;
+    c->smp_overlap_launch = false;
 }
 
 int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_t max_chunk_steps, const double *coords,
@@ -1151,11 +1171,18 @@ int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_
     c->smp = r;
     r->mode = mode; r->ndim = ndim; r->nw = nw; r->ns = nw / 2; r->cap_steps = max_chunk_steps;
     const int64_t ns = r->ns;
-    const size_t state_bytes = sizeof(double) * (size_t)(nw * ndim + nw + ns * ndim + ns) + sizeof(int64_t) * (size_t)nw +
-                               sizeof(int32_t) * (size_t)ns + 64;
+    // (two coordinate buffers, two half-steps' worth of per-launch outputs: overlapped half-steps)
+    const size_t state_bytes = sizeof(double) * (size_t)(2 * nw * ndim + nw + 2 * ns * ndim + 2 * ns) + sizeof(int64_t) * (size_t)nw +
+                               sizeof(int32_t) * (size_t)(2 * ns) + sizeof(uint32_t) * (size_t)nw + 64;
     hipError_t e = hipMalloc((void **)&r->d_state, state_bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_state, 0, state_bytes, c->stream);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->s2, hipStreamNonBlocking);
+    for (auto &ev : r->hs_done)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->chunk_open, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->s2_done, hipEventDisableTiming);
     for (auto &sl : r->slot) {
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_in, r->in_bytes(max_chunk_steps));
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_out, r->out_bytes(max_chunk_steps));
@@ -1166,8 +1193,9 @@ int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.out_ready, hipEventDisableTiming);
     }
     if (e == hipSuccess) {
-        r->d_coords = (double *)r->d_state; r->d_logp = r->d_coords + nw * ndim; r->d_q = r->d_logp + nw;
-        r->d_newlp = r->d_q + ns * ndim; r->d_nacc = (int64_t *)(r->d_newlp + ns); r->d_wst = (int32_t *)(r->d_nacc + nw);
+        r->d_coords = (double *)r->d_state; r->d_logp = r->d_coords + 2 * nw * ndim; r->d_q = r->d_logp + nw;
+        r->d_newlp = r->d_q + 2 * ns * ndim; r->d_nacc = (int64_t *)(r->d_newlp + 2 * ns); r->d_wst = (int32_t *)(r->d_nacc + nw);
+        r->d_ver = (uint32_t *)(r->d_wst + 2 * ns);
         e = hipMemcpyAsync(r->d_coords, coords, sizeof(double) * nw * ndim, hipMemcpyHostToDevice, c->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_logp, logp, sizeof(double) * nw, hipMemcpyHostToDevice, c->stream);
@@ -1243,8 +1271,26 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     // two dependent loads (index, coordinates) instead of three
     for (int64_t i = 0; i < nh; ++i) hi[2 * nh + i] = hi[nh + (i / ns) * ns + hi[2 * nh + i]];
     // ... and the proposal's inputs once more as one record per walker (the kernel's first load)
+    // Overlapped half-steps?  Decided once per run, here (sharding is set up after msx_sampler_begin): an unsharded run
+    // whose half-step takes the fused kernel (one workgroup per walker) and fills at most HALF the CUs -- two half-steps
+    // are resident together, and a workgroup that waits for a walker of the half-step before it must never keep that
+    // walker's workgroup off the chip.  MSX_SMP_OVERLAP=0 in the environment: never.
+    if (r->overlap < 0) {
+        const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+        const char *e = getenv("MSX_SMP_OVERLAP");
+        r->overlap = !(e && e[0] == '0') && !r->sharded && 2 * ns <= cus && !c->model_in_global && c->recipe_fast &&
+                     c->path != MSX_PATH_LINKED && c->path != MSX_PATH_PAIR && !auto_takes_linked(c, ns);
+    }
+    // ... and the proposal's inputs once more as one record per walker (the kernel's first load), with the versions of
+    // the two walkers the move reads: before iteration k every walker has version k; the second half-step's partners
+    // were updated by the first
     SmpRec *hr = (SmpRec *)(hi + 3 * nh);
-    for (int64_t i = 0; i < nh; ++i) { hr[i].si = hi[i]; hr[i].ci = hi[2 * nh + i]; hr[i].zz = hz[i]; }
+    for (int64_t i = 0; i < nh; ++i) {
+        hr[i].si = hi[i]; hr[i].ci = hi[2 * nh + i]; hr[i].zz = hz[i];
+        const int64_t k = r->steps_done + i / (2 * ns), half = (i / ns) & 1;
+        hr[i].ver_own = r->overlap == 1 ? (uint32_t)k : 0u;
+        hr[i].ver_partner = r->overlap == 1 ? (uint32_t)(k + half) : 0u;
+    }
     HIP_TRY(c, hipMemcpyAsync(sl.d_in, sl.h_in, r->in_bytes(nsteps), hipMemcpyHostToDevice, r->up));
     HIP_TRY(c, hipEventRecord(sl.in_ready, r->up));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.in_ready, 0));
@@ -1259,6 +1305,11 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     DevProblem &P = c->P;
     P.smp_on = 1;
     P.smp_coords = r->d_coords; P.smp_logp = r->d_logp; P.smp_q = r->d_q; P.smp_naccept = r->d_nacc; P.smp_worst = cp->d_worst;
+    P.smp_overlap = r->overlap == 1; P.smp_stride = nw * ndim; P.smp_ver = r->d_ver;
+    if (r->overlap == 1) {  // the second stream's launches of this chunk come after the chunk's inputs and the cleared status
+        HIP_TRY(c, hipEventRecord(r->chunk_open, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(r->s2, r->chunk_open, 0));
+    }
     return MSX_OK;
 }
 
@@ -1273,6 +1324,20 @@ static int chunk_half_eval(msx_ctx *c, const ChunkPtrs &cp, int64_t st, int half
     P.smp_sidx = cp.d_sidx + off; P.smp_cidx = cp.d_cidx + off; P.smp_partner = cp.d_partner + off;
     P.smp_zz = cp.d_zz + off; P.smp_zfac = cp.d_zfac + off; P.smp_logu = cp.d_logu + off; P.smp_rec = cp.d_rec + off;
     P.smp_chain_row = cp.d_chain + st * nw * ndim; P.smp_lp_row = cp.d_lpchain + st * nw;
+    if (r->overlap == 1) {
+        // half-step j on stream j & 1, behind j - 3 (see SamplerRun); per-launch outputs nobody reads go to the
+        // stream's own half of their arrays
+        const int64_t j = (r->steps_done + st) * 2 + half;
+        hipStream_t s = (j & 1) ? r->s2 : c->stream;
+        if (j >= 3) HIP_TRY(c, hipStreamWaitEvent(s, r->hs_done[(j - 3) & 3], 0));
+        P.smp_q = r->d_q + (j & 1) * ns * ndim;
+        c->smp_overlap_launch = true;
+        const int rc = msx_logprob_batch_dev(c, r->mode, P.smp_q, ns, ndim, r->d_newlp + (j & 1) * ns, r->d_wst + (j & 1) * ns, s, 0);
+        c->smp_overlap_launch = false;
+        if (rc != MSX_OK) return rc;
+        HIP_TRY(c, hipEventRecord(r->hs_done[j & 3], s));
+        return MSX_OK;
+    }
     if (!r->sharded) return msx_logprob_batch_dev(c, r->mode, r->d_q, ns, ndim, r->d_newlp, r->d_wst, c->stream, 0);
     // sharded: (1) this rank's block of proposals -> log p(q) only; (2) ONE all-gather of shard_m float64 per rank, in
     // place in the gathered vector; (3) every rank finishes the half-step for all ns walkers
@@ -1321,6 +1386,11 @@ static int chunk_finish(msx_ctx *c, int32_t slot, int64_t nsteps, const ChunkPtr
         r->failed = true;
         return rc;
     }
+    if (r->overlap == 1) {  // the chunk's last half-step ran on the second stream
+        HIP_TRY(c, hipEventRecord(r->s2_done, r->s2));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, r->s2_done, 0));
+    }
+    r->steps_done += nsteps;
     // acceptance counters keep running while this chunk's results travel: snapshot them in stream order
     HIP_TRY(c, hipMemcpyAsync(cp.d_nacc_snap, r->d_nacc, sizeof(int64_t) * r->nw, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(sl.kernels_done, c->stream));
@@ -1439,10 +1509,18 @@ int msx_sampler_end(msx_ctx *c, double *coords, double *logp) {
     if (!r) return MSX_OK;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess && coords) e = hipMemcpy(coords, r->d_coords, sizeof(double) * r->nw * r->ndim, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && r->s2) e = hipStreamSynchronize(r->s2);
+    if (e == hipSuccess && coords) e = hipMemcpy(coords, r->coords_now(), sizeof(double) * r->nw * r->ndim, hipMemcpyDeviceToHost);
     if (e == hipSuccess && logp) e = hipMemcpy(logp, r->d_logp, sizeof(double) * r->nw, hipMemcpyDeviceToHost);
     sampler_free(c);
     if (e != hipSuccess) return fail(c, MSX_ERR_HIP, std::string("msx_sampler_end: ") + hipGetErrorString(e));
+    return MSX_OK;
+}
+
+int msx_sampler_overlapped(msx_ctx *c, int32_t *out) {
+    if (!c || !out) return MSX_ERR_INVALID;
+    if (!c->smp) return fail(c, MSX_ERR_STATE, "msx_sampler_overlapped: call msx_sampler_begin first");
+    *out = c->smp->overlap;
     return MSX_OK;
 }
 

@@ -26,7 +26,8 @@ def _raise_for_status(status, theta):
     if code == _lib.W_VALUEERROR:
         raise ValueError('A value in x_new is outside the interpolation range (isochrone Teff) for ' + where)
     if code == _lib.W_HANDOVER:
-        raise RuntimeError('device fault: the workgroups of a linked launch did not meet within 20 ms for ' + where +
+        raise RuntimeError('device fault: workgroups that wait for each other inside a launch (the linked form; the '
+                           'overlapped half-steps of the device-resident sampler) did not meet within 20 ms for ' + where +
                            ' (stage the problem again before the next launch)')
     raise RuntimeError('unknown walker status {} for {}'.format(code, where))
 

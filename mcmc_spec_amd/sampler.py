@@ -216,6 +216,7 @@ class DeviceEnsembleSampler(EnsembleSampler):
         communicator (``mcmc_spec_amd.dist.init_engine_comm``)."""
         from . import _lib
         self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        self.overlapped = None   # set by the first chunk of a run: did its half-steps overlap (include/msx.h)?
         self.engine = engine
         self._mode = {'logposterior': _lib.MODE_LOGPOST, 'loglikelihood': _lib.MODE_LOGLIKE}[mode]
         fn = engine.logposterior if mode == 'logposterior' else engine.loglikelihood
@@ -270,6 +271,7 @@ class DeviceEnsembleSampler(EnsembleSampler):
                         m_next = next_size(m, left) if left > 0 else 0
                         fut = submit(pool, m_next)
                         ctx.sampler_enqueue(slot, *arrays)
+                        self.overlapped = ctx.sampler_overlapped() == 1   # (half-steps on two streams: include/msx.h)
                         queued.append((slot, m))
                         slot ^= 1
                         m = m_next

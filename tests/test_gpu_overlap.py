@@ -1,0 +1,115 @@
+"""Overlapped half-steps of the device-resident sampler (include/msx.h: msx_sampler_overlapped; logprob_kernel.h,
+walker_done; msx.hip, chunk_half_eval).
+
+Consecutive half-steps run concurrently on two streams; what orders them is inside the kernel: a walker's workgroup
+waits until the two walkers its move reads hold the versions the move is defined on, coordinates are double-buffered by
+version parity, every finished walker publishes its version.  None of that may change a single bit of the chain -- the
+host-driven loop over the same randomness is the reference -- and a walker that never publishes must end in a loud
+MSX_W_HANDOVER, not in a hang or a value.
+"""
+import numpy as np
+import pytest
+
+import common
+from common import golden_case
+from test_gpu_parity import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _config2():
+    import bench
+    from mcmc_spec_amd.engine import Engine
+    if 'config2' not in common._cache:
+        eng = Engine(0)
+        common._cache['config2'] = (eng, bench.build_workload(eng, 4096, False))
+    return common._cache['config2']
+
+
+def _chains(eng, p0, nsteps, seed, chunk, mode='logposterior'):
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    fn = eng.logposterior if mode == 'logposterior' else eng.loglikelihood
+    host = EnsembleSampler(p0.shape[0], p0.shape[1], fn, vectorize=True, seed=seed)
+    hs = host.run_mcmc(p0, nsteps)
+    dev = DeviceEnsembleSampler(p0.shape[0], p0.shape[1], eng, mode=mode, seed=seed, chunk=chunk)
+    ds = dev.run_mcmc(p0, nsteps)
+    return host, hs, dev, ds
+
+
+@pytest.mark.parametrize('nw,nsteps,chunk', [(256, 40, 16), (64, 27, 8), (12, 9, 4)])
+def test_overlapped_half_steps_walk_the_host_chain(nw, nsteps, chunk, monkeypatch):
+    """BASELINE config 2's ensemble (256 walkers: two half-steps of 128 fill the chip), a small one over several chunk
+    boundaries with an odd number of iterations (the final state sits in the second coordinate buffer), and six
+    walkers per half-step -- against the host loop, and against the same run with the overlap switched off."""
+    from mcmc_spec_amd import synth
+    eng, W = _config2()
+    p0 = synth.draw_walkers(nw, seed=5 + nw, tmin=W['tmin'], tmax=W['tmax'])
+    host, hs, dev, ds = _chains(eng, p0, nsteps, 17, chunk)
+    assert dev.overlapped is True
+    assert np.array_equal(dev.get_chain(), host.get_chain())
+    assert np.array_equal(dev.get_log_prob(), host.get_log_prob())
+    assert np.array_equal(ds.coords, hs.coords) and np.array_equal(ds.log_prob, hs.log_prob)
+    assert np.array_equal(dev.acceptance_fraction, host.acceptance_fraction)
+    assert 0.1 < dev.acceptance_fraction.mean() < 0.9
+    # a second run on the same context starts from version 0 again
+    dev2 = _chains(eng, ds.coords, 5, 3, chunk)
+    assert np.array_equal(dev2[2].get_chain(), dev2[0].get_chain())
+    monkeypatch.setenv('MSX_SMP_OVERLAP', '0')
+    host3, hs3, dev3, ds3 = _chains(eng, p0, nsteps, 17, chunk)
+    assert dev3.overlapped is False
+    assert np.array_equal(dev3.get_chain(), dev.get_chain()) and np.array_equal(ds3.log_prob, ds.log_prob)
+
+
+def test_overlap_is_not_taken_where_it_could_deadlock_or_does_not_apply():
+    """More walkers per half-step than half the CUs: the next half-step's waiting workgroups could keep the previous
+    one's off the chip -- plain launches.  A sharded run has a collective between its half-steps -- plain launches."""
+    from mcmc_spec_amd import synth
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    eng, W = _config2()
+    cus = eng.ctx.device_info()['cus']
+    nw = 2 * (cus // 2 + 2)
+    p0 = synth.draw_walkers(nw, seed=2, tmin=W['tmin'], tmax=W['tmax'])
+    s = DeviceEnsembleSampler(nw, 6, eng, seed=1, chunk=4)
+    s.run_mcmc(p0, 4)
+    assert s.overlapped is False
+    s = DeviceEnsembleSampler(64, 6, eng, seed=1, chunk=4, shard=(0, 1))
+    s.run_mcmc(p0[:64], 4)
+    assert s.overlapped is False
+
+
+def test_a_walker_error_in_an_overlapped_run_is_reported():
+    """Likelihood mode has no prior box: a proposal below the isochrone table is an error status, not a value.  The
+    failing walker still publishes its version (nobody waits for it for ever) and the chunk reports the status."""
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    c = golden_case('B')
+    eng = make_engine(c, rad_prior=False)
+    nw = 48
+    rng = np.random.default_rng(9)
+    p0 = c.theta[0] + rng.normal(size=(nw, 6)) * np.array([30, 30, 0.02, 0.02, 0.02, 2e-5])
+    p0[:, 1] = 2905.0 + np.abs(np.random.default_rng(2).normal(size=nw)) * 3   # stretch moves step below 2900 K
+    s = DeviceEnsembleSampler(nw, 6, eng, mode='loglikelihood', seed=2, chunk=16)
+    with pytest.raises(ValueError):
+        s.run_mcmc(p0, 60)
+    assert s.overlapped is True
+
+
+def test_a_version_that_is_never_published_ends_in_a_loud_failure():
+    """The fault hook keeps every walker from publishing its new version: the next half-step's workgroups wait 20 ms of
+    wall clock, give up, and the chunk's worst status is MSX_W_HANDOVER -- Python raises; no hang, no chain.  The next
+    run on the context (hook off) is healthy: the versions belong to the run, not to the context."""
+    import time
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    eng, W = _config2()
+    p0 = synth.draw_walkers(32, seed=4, tmin=W['tmin'], tmax=W['tmax'])
+    eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 1)
+    try:
+        s = DeviceEnsembleSampler(32, 6, eng, seed=1, chunk=2)
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match='did not meet'):
+            s.run_mcmc(p0, 2)
+        assert time.time() - t0 < 10.0
+    finally:
+        eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 0)
+    host, hs, dev, ds = _chains(eng, p0, 6, 8, 4)
+    assert dev.overlapped is True and np.array_equal(dev.get_chain(), host.get_chain())
