@@ -55,7 +55,23 @@ __device__ __forceinline__ double value_of_total(int mode, double total, double 
 // stretch move's accept rule  log(u) < (ndim-1) ln z + ln p(q) - ln p(s)  (NaN differences compare false,
 // like -inf - -inf on the host) and record the walker's row of the chain: a walker only changes in its
 // own half-step, so its row after the step is written here.
-__device__ __forceinline__ void walker_done(const DevProblem &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
+// What the walker's last lines read of the problem, copied out of the by-value kernel argument ONCE per kernel (smp_view):
+// walker_done is inlined at every exit of the kernel, and a by-value DevProblem with too many uses is no longer
+// recognised as read-only by the compiler, which then keeps a private copy of all 1.2 KB of it in scratch
+// (tests/test_abi.py watches the variants' scratch size).
+struct SmpView {
+    int32_t smp_on, smp_defer, smp_overlap, linked_fault;
+    int64_t smp_stride;
+    double *smp_coords, *smp_logp, *smp_chain_row, *smp_lp_row;
+    int64_t *smp_naccept;
+    int32_t *smp_worst;
+    uint32_t *smp_ver;
+};
+__device__ __forceinline__ SmpView smp_view(const DevProblem &P) {
+    return {P.smp_on, P.smp_defer, P.smp_overlap, P.linked_fault, P.smp_stride, P.smp_coords, P.smp_logp, P.smp_chain_row,
+            P.smp_lp_row, P.smp_naccept, P.smp_worst, P.smp_ver};
+}
+__device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
                             double *__restrict__ logp, int32_t *__restrict__ status) {
     // an error status travels inside the NaN it produces (payload = MSX_W_*): the sharded sampler's all-gather
     // carries log-probabilities only, and every rank must learn of every rank's failures
@@ -253,6 +269,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     //                   half-step's records (= P.smp_rec): the proposal is two dependent loads away from wave start
     const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
     constexpr int ndim = 2 * NS + 2;
+    const SmpView V = smp_view(P);  // (for walker_done)
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
@@ -405,7 +422,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         for (int k = 1; k < NS; ++k) wst = (wst != MSX_W_REJECT && D.stat[k] == MSX_W_VALUEERROR) ? MSX_W_VALUEERROR : wst;
     }
     if (wst != MSX_W_OK) {
-        if (tid == 0 && myseg == 0) walker_done(P, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
+        if (tid == 0 && myseg == 0) walker_done(V, D, wk, ndim, (wst == MSX_W_REJECT) ? -INFINITY : NAN, wst, logp, status);
         return;
     }
     if (mode == MSX_MODE_LOGPRIOR) {  // logprior alone (mft6.py:1207-1272): no spectrum pass
@@ -425,7 +442,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         if (tid == 0) {
             const double total = D.chi_extra;
             const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
-            walker_done(P, D, wk, ndim, chi_valued ? total : (isnan(total) ? -INFINITY : D.lp + (-0.5 * total)), MSX_W_OK, logp,
+            walker_done(V, D, wk, ndim, chi_valued ? total : (isnan(total) ? -INFINITY : D.lp + (-0.5 * total)), MSX_W_OK, logp,
                         status);
         }
         return;
@@ -715,7 +732,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         __syncthreads();
         MSX_STAMP(P, wk, 4);
         if (S.meet_state == 0u) {  // (every workgroup that gave up says so: whichever of them is the only one)
-            if (tid == 0) walker_done(P, D, wk, ndim, NAN, MSX_W_HANDOVER, logp, status);
+            if (tid == 0) walker_done(V, D, wk, ndim, NAN, MSX_W_HANDOVER, logp, status);
             return;
         }
         {   // the segments' counters added up, their fit sums in segment order -- the order the fused kernel adds them in
@@ -808,7 +825,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             const double med = sane ? logbin_rank<MAXT>(S, Q, need_two, 0) : 0.0;
             if (tid == 0) {
                 const double total = fused_total(P, chi, P.median_flux, med, npix, D.chi_extra);
-                walker_done(P, D, wk, ndim, sane ? value_of_total(mode, total, D.lp) : NAN, sane ? MSX_W_OK : MSX_W_HANDOVER, logp, status);
+                walker_done(V, D, wk, ndim, sane ? value_of_total(mode, total, D.lp) : NAN, sane ? MSX_W_OK : MSX_W_HANDOVER, logp, status);
                 MSX_STAMP(P, wk, 15);
             }
             return;
@@ -870,7 +887,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             if (tid == 0) {
                 const bool chi_valued = mode == MSX_MODE_CHISQ || mode == MSX_MODE_OPT_STEP || mode == MSX_MODE_OPT_INIT;
                 if (mode == MSX_MODE_OPT_INIT) P.opt_med[wk] = NAN;
-                walker_done(P, D, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
+                walker_done(V, D, wk, ndim, chi_valued ? NAN : -INFINITY, MSX_W_OK, logp, status);
             }
             return;
         }
@@ -965,7 +982,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             const double iic = fast_div(tot, (double)npix) * 3;  // mft6.py:1179; :893,1015
             out = iic * (double)(P.nc + P.np) + D.chi_extra;      // mft6.py:904 / :1028
         }
-        walker_done(P, D, wk, ndim, out, MSX_W_OK, logp, status);
+        walker_done(V, D, wk, ndim, out, MSX_W_OK, logp, status);
         MSX_STAMP(P, wk, 15);
     }
 }
