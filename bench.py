@@ -680,6 +680,21 @@ def main():
             out['multi_gpu_diag'] = diag
         out['cpu_baseline'] = None
         extra = {}
+        if world == 1 and not replicas and not args.no_extras and args.npix == 4096 and not args.phot:
+            # what an emcee run gets: ONE dependent chain of this ensemble, walker state resident on the GPU
+            # (DeviceEnsembleSampler; consecutive half-steps overlap on two streams).  Before the CPU
+            # baseline: the chain's launches are issued by this host thread, and the baseline's pools leave the host busy
+            from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+            p0 = synth.draw_walkers(args.walkers, seed=9, tmin=W['tmin'], tmax=W['tmax'])
+            smp = DeviceEnsembleSampler(args.walkers, p0.shape[1], eng, seed=1, chunk=100)
+            smp.run_mcmc(p0, 20)
+            t0 = time.perf_counter()
+            smp.run_mcmc(p0, 1000, store=False)
+            dt = time.perf_counter() - t0
+            extra['dependent_chain'] = {'walkers': args.walkers, 'iterations': 1000, 'us_per_iteration': dt / 1000 * 1e6,
+                                        'evals_per_s': args.walkers * 1000 / dt, 'overlapped_half_steps': bool(smp.overlapped),
+                                        'acceptance': float(smp.acceptance_fraction.mean()),
+                                        'note': 'wall time of run_mcmc, host randomness and chain download included'}
         if want_cpu:
             th_cpu = synth.draw_walkers(8192, seed=77, tmin=W['tmin'], tmax=W['tmax'])
             g, st = eng.ctx.logprob_batch(th_cpu, _lib.MODE_LOGPOST)

@@ -76,15 +76,15 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
     __shared__ WalkerLoc Loc[2];
     const int mode = (ng_mode_fast >> 8) & 0xff;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
-    // ---- this workgroup's item: the planner's singles first, then its pairs -------------------------------------
+    // ---- this workgroup's item: the planner's pairs first (the longer workgroups), then its singles ----------------
     const PairRec *rec[2];
     bool is_pair;
     {
         const int2 cnt = *reinterpret_cast<const int2 *>(plan);  // {pairs, singles}
-        const int nsingle = cnt.y, b = (int)blockIdx.x - nsingle;
-        if (b >= cnt.x) return;
-        is_pair = b >= 0;
-        rec[0] = is_pair ? &P.pair_items[b].r[0] : P.pair_singles + blockIdx.x;
+        const int b = (int)blockIdx.x, sb = b - cnt.x;
+        if (sb >= cnt.y) return;
+        is_pair = sb < 0;
+        rec[0] = is_pair ? &P.pair_items[b].r[0] : P.pair_singles + sb;
         rec[1] = is_pair ? &P.pair_items[b].r[1] : rec[0];
     }
     const int npix = (int)P.npix;
@@ -468,7 +468,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
 //      is a chain of dependent steps per thread, 341.1 / 346.0 us per batch against 340.2).
 // Per workgroup: one global atomic add for its pairs, one for its singles.  Walkers the prior box rejects or whose
 // recipe will fail are singles from the start.  Pairs and singles are ONE list of items for
-// logprob_pair_kernel (singles first: a lone walker's workgroup is the longest, it starts at once).  Who meets whom
+// logprob_pair_kernel (pairs first: the longer workgroups start first, the lone walkers fill the tail).  Who meets whom
 // depends on the batch order only; values depend on neither: a walker's bits are its own (see the header of this
 // file).  And a cell mis-computed here costs time, not correctness: the pair kernel compares the real recipes and
 // evaluates walkers that differ one after the other.
