@@ -687,12 +687,13 @@ def main():
             from mcmc_spec_amd.sampler import DeviceEnsembleSampler
             p0 = synth.draw_walkers(args.walkers, seed=9, tmin=W['tmin'], tmax=W['tmax'])
             smp = DeviceEnsembleSampler(args.walkers, p0.shape[1], eng, seed=1, chunk=100)
-            smp.run_mcmc(p0, 20)
+            smp.run_mcmc(p0, 400, store=False)   # (clocks, the chunk sizes' ramp, the host's random-number threads)
+            nit = 3000
             t0 = time.perf_counter()
-            smp.run_mcmc(p0, 1000, store=False)
+            smp.run_mcmc(p0, nit, store=False)
             dt = time.perf_counter() - t0
-            extra['dependent_chain'] = {'walkers': args.walkers, 'iterations': 1000, 'us_per_iteration': dt / 1000 * 1e6,
-                                        'evals_per_s': args.walkers * 1000 / dt, 'overlapped_half_steps': bool(smp.overlapped),
+            extra['dependent_chain'] = {'walkers': args.walkers, 'iterations': nit, 'us_per_iteration': dt / nit * 1e6,
+                                        'evals_per_s': args.walkers * nit / dt, 'overlapped_half_steps': bool(smp.overlapped),
                                         'acceptance': float(smp.acceptance_fraction.mean()),
                                         'note': 'wall time of run_mcmc, host randomness and chain download included'}
         if want_cpu:
