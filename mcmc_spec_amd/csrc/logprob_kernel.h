@@ -219,9 +219,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //        always 2, the two pixels of one table element (below).
 // GM = the walker's model vector lives in global memory (spectra longer than ~17k pixels) instead of LDS.
 // SH = 512-thread variant that shares its CU with a second workgroup (MSX_BLOCK_512_SHARED).
-// PF = phase A leaves the walker-independent pixel vectors it loads anyway (u, data flux) in LDS, in the tables'
-//      own layout, and the chi^2 pass reads them there instead of pulling them through the CU's L2 port a second
-//      time (one workgroup per CU only: 3 npix doubles of LDS).
+// PF = the walker-independent pixel vectors u and data flux are staged in LDS, in the tables' own layout, by the waves
+//      that idle during the recipe; the blend loop and the chi^2 pass read them there instead of pulling them through
+//      the CU's L2 port, twice (one workgroup per CU only: 3 npix doubles of LDS).
 // LK = the LINKED form of the same kernel, for few walkers x long spectra (one workgroup per walker leaves CUs idle
 //      and is a chain of 16,384 pixels' latencies): one workgroup per (walker, SEGMENT of 8192 pixels), all of them
 //      equals.  Each builds the recipe, blends ITS segment into LDS (fit sums, value range, histogram on the way) and
@@ -395,6 +395,21 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     for (int i = tid; i < kLogBins; i += B) S.hist[i] = 0;
     if (tid == 0) { S.cand_n = 0; S.has_second = 0; }
     fill_exp2_table(e2tab, tid - (B - kWave));  // the last wave (no recipe work); published by phase 0's barrier
+    if (PF && wave > NS) {
+        // The waves with no recipe work bring the walker-independent pixel vectors the blend loop and the chi^2 pass
+        // read -- u and the data flux -- into LDS while the recipe waves work (64 KB through the CU's L2 port in the
+        // recipe's 1.9 us; published by phase 0's barrier): the blend loop, which runs at that port's limit, then
+        // requests 116 instead of 132 bytes per pixel and has four loads fewer per trip to wait for.
+        // (256 walkers x 4096 px: 15.3 -> 13.7 us on the same box.  Round 1 staged them like this, round 2 let the
+        // blend loop leave them in LDS "since it loads them anyway" -- it does not have to.  The extinction curve k too,
+        // 16 more bytes per element: no further gain, 13.7 us.)
+        const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
+#pragma unroll 4
+        for (int e = id; e < ne; e += nthr) {
+            lds_u2[e] = P.u2[e];
+            lds_f2[e] = P.f2[e];
+        }
+    }
     constexpr int NC = NS * 4;
     const int nseg_all = (ne + kSegElems - 1) / kSegElems;
     const int seg_lo = LK ? myseg : 0, seg_hi = LK ? myseg + 1 : nseg_all;
@@ -502,7 +517,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
         const bool ok[U] = {live && pa < npix, live && pb < npix};
         const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
-        if (PF && live) { lds_u2[ec] = u2; lds_f2[ec] = f2; }  // for the chi^2 pass
+        static_assert(!PF || kQuad, "PF: u and the data flux come from LDS (staged in phase 0; the quad trips read them there)");
         const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -537,7 +552,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // after the blend at 256 (two workgroups per CU: 512 walkers 16.2 us early against 15.95 late)
         constexpr bool kEarlyFUq = MAXT == 512;
         double2 fA = make_double2(0.0, 0.0), uA = fA, fB = fA, uB = fA;
-        if (kEarlyFUq) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
+        if (kEarlyFUq && !PF) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
         double sr[4] = {0.0, 0.0, 0.0, 0.0};
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         double2 klA = make_double2(0.0, 0.0), klB = klA;
@@ -571,6 +586,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         mB.x = blend_finish(sr[2], sh[2], klB.x, (double)dk.z, redc, RED, e2tab);
         mB.y = blend_finish(sr[3], sh[3], klB.y, (double)dk.w, redc, RED, e2tab);
         if (!kEarlyFUq) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
+        if (PF) { fA = lds_f2[ecA]; uA = lds_u2[ecA]; fB = lds_f2[ecB]; uB = lds_u2[ecB]; }  // (staged in phase 0)
         finish_elem(mA, fA, uA, ecA, liveA, std::integral_constant<int, 0>{});
         finish_elem(mB, fB, uB, ecB, liveB, std::integral_constant<int, SUB - 1>{});  // (256 threads: the trip's second element)
       }

@@ -798,7 +798,14 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->max_dyn_lds = (int)need_lds;
     c->model_in_global = model_in_global;
-    c->pf_ok = !model_in_global && need_lds + 16 + 32 * npair <= 147 * 1024;  // model + u2 + f2, + ~12 KB static <= 160 KB
+    {   // the PF variants' dynamic LDS -- model + u2 + f2 -- must fit beside their static LDS (asked of the functions
+        // themselves: the static part has grown over the rounds, a constant here once let 5,800..6,270 pixels through)
+        hipFuncAttributes a2, a3;
+        HIP_TRY(c, hipFuncGetAttributes(&a2, (const void *)logprob_kernel<2, 2, 512, false, false, true>));
+        HIP_TRY(c, hipFuncGetAttributes(&a3, (const void *)logprob_kernel<3, 2, 512, false, false, true>));
+        const int64_t room = (160 * 1024 - (int64_t)std::max(a2.sharedSizeBytes, a3.sharedSizeBytes)) & ~15ll;
+        c->pf_ok = !model_in_global && (int64_t)sizeof(double) * ((p->npix + 1) & ~1ll) + 32 * npair + (int64_t)c->pad_lds <= room;
+    }
     if ((rc = raise_dynamic_lds_limits(c))) return rc;
     c->recipe_fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= 32 && P.nav + 1 <= 2 * kWave;
     c->d_recipe_block = nullptr;

@@ -1101,3 +1101,28 @@ def test_statuses_and_values_beyond_the_box(which):
     wrapped = ok & ~inside
     if wrapped.any():
         assert rel_err(got[wrapped], want[wrapped]).max() < 1e-4
+
+
+@pytest.mark.parametrize('npix', [5700, 5800, 6000, 6271, 6400])
+def test_lds_staged_variant_is_only_taken_where_it_fits(npix):
+    """Around the spectrum length where model vector + u + data flux stop fitting the LDS beside the kernel's static
+    part (the PF variants; the bound is asked of the compiled functions at msx_stage_problem): a launch of few walkers
+    -- one workgroup per CU, the variant in question -- must work on either side of it and give the bits of a large
+    launch (256-thread variant, nothing staged)."""
+    from mcmc_spec_amd import bands
+    from mcmc_spec_amd.engine import Engine
+    c = golden_case('B')
+    rng = np.random.default_rng(npix)
+    wl = np.sort(rng.uniform(0.56, 0.89, npix))
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega))
+    few = eng.loglikelihood(c.theta[:9])
+    many = eng.loglikelihood(np.tile(c.theta[:9], (80, 1)))
+    assert np.all(np.isfinite(few)) and np.array_equal(np.tile(few, 80), many)
+    one = common.orc.loglikelihood(list(c.theta[0]), c.fr, 2, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(few[0], one) < TIGHT
