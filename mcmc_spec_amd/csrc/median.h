@@ -22,6 +22,7 @@ struct alignas(16) BlockScratch {
     unsigned long long sel_result[2];
     unsigned int sel_bin, sel_k, sel_cnt, cand_n, has_second;
     unsigned int cnt_le;
+    unsigned int rk[2][kWave];  // split ranking (logbin_rank_part): per candidate, how many are below / not above it; zero on entry
     // linked form (logprob_kernel.h): what thread 0 learnt at the walker's meeting points
     unsigned int meet_state;
     unsigned long long meet_base;
@@ -543,6 +544,46 @@ __device__ __forceinline__ double logbin_rank(BlockScratch &S, const LogbinSel &
     return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
 }
 
+// The same ranking for <= 64 candidates, SPLIT over several waves (the fused kernel's last lines: the pass is over, most
+// waves have nothing left to do, and one wave comparing every candidate with every other is the longest chain left):
+// wave `part` of `nparts` takes every nparts-th trip of eight candidates and adds its counts to S.rk (zero on entry);
+// after a barrier, logbin_rank_pick (one wave) reads the sums.  The pad slots S.cand[cnt .. cnt + 8) must hold ~0.
+template <int BT>
+__device__ __forceinline__ void logbin_rank_part(BlockScratch &S, const LogbinSel &Q, int part, int nparts) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int cnt = Q.cnt;
+    const unsigned long long mine = S.cand[lane < (int)cnt ? lane : (int)cnt];
+    unsigned int lt = 0, le = 0;
+    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(S.cand);
+    for (int j = 8 * part; j < (int)cnt; j += 8 * nparts) {
+        ulonglong2 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = c2[(j >> 1) + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lt += (x[u].x < mine) + (x[u].y < mine);
+            le += (x[u].x <= mine) + (x[u].y <= mine);
+        }
+    }
+    if (lane < (int)cnt && 8 * part < (int)cnt) {
+        atomicAdd(&S.rk[0][lane], lt);
+        atomicAdd(&S.rk[1][lane], le);
+    }
+}
+template <int BT>
+__device__ __forceinline__ double logbin_rank_pick(BlockScratch &S, const LogbinSel &Q, bool need_two) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int cnt = Q.cnt, kk = Q.kk;
+    const unsigned long long mine = S.cand[lane < (int)cnt ? lane : (int)cnt];
+    const unsigned int lt = S.rk[0][lane], le = S.rk[1][lane];
+    const unsigned long long b1 = __ballot(lane < (int)cnt && lt <= kk && kk < le);
+    const unsigned long long b2 = __ballot(lane < (int)cnt && lt <= kk + 1 && kk + 1 < le);
+    const unsigned long long v1 = readlane_u64(mine, uni(__ffsll((long long)b1) - 1));
+    unsigned long long v2 = 0;
+    if (b2 != 0ull) v2 = readlane_u64(mine, uni(__ffsll((long long)b2) - 1));
+    return need_two ? (val_of(v1) + val_of(v2)) / 2.0 : val_of(v1);
+}
+
 // The value range as the early-histogram median wants it: the range [f0, f1] of the UNMASKED bin number
 // F(x) = hi32(x) >> 12 over the vector.  All values positive normal numbers <=> f0 >= 1 and f1 < 0x7ff00 (zeros and
 // subnormals have F = 0; infinities, NaNs and every negative number F >= 0x7ff00); spanning less than the histogram's
@@ -552,9 +593,11 @@ __device__ __forceinline__ bool frange_applicable(unsigned int f0, unsigned int 
     return f0 >= 1u && f1 < 0x7ff00u && f1 - f0 < (unsigned int)kLogBins;
 }
 // hmin = F of the vector's minimum; the caller has checked frange_applicable
+// split != nullptr: with <= 64 candidates the ranking is left to the caller (logbin_rank_part / _pick; *split = true, the
+// bins in *Qout, the pad slots written) -- it has idle waves to spread it over
 template <int BT, class Elem>
 __device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned int hmin, BlockScratch &S, Elem &elem,
-                                              double *med_out) {
+                                              double *med_out, bool *split = nullptr, LogbinSel *Qout = nullptr) {
     const bool need_two = (npix & 1) == 0;
     MED_STAMP(0);
     MED_STAMP(1);
@@ -571,9 +614,15 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
             if (p[u] < npix && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
         }
     });
+    if (split) {
+        *split = Q.cnt <= (unsigned int)kWave;
+        *Qout = Q;
+        if (*split && threadIdx.x < 8) S.cand[Q.cnt + threadIdx.x] = ~0ull;  // (the slots behind the candidates: Q.cnt is exact)
+    }
     elem.flush(S);
     __syncthreads();
     MED_STAMP(3);
+    if (split && *split) return true;
     *med_out = logbin_rank<BT>(S, Q, need_two, 0);
     MED_STAMP(4);
 #ifdef MSX_STAMPS

@@ -826,6 +826,22 @@ __device__ __forceinline__ void recipe_band_terms(const DevProblem &P, int mode,
     if (lane == 0) D.chi_extra = chi;
 }
 
+// ... in two parts: the jobs' magnitudes (the round trip to the band table and the logarithms; needs the recipe's nodes
+// and weights) and, from them, the chi^2 terms
+template <int NS>
+__device__ __forceinline__ double recipe_band_values(const DevProblem &P, const WalkerDesc &D, int lane) {
+    const int njobs = P.nc * NS + P.np;
+    return lane < njobs ? band_job_value<NS>(P, D.node, D.w, lane) : 0.0;
+}
+template <int NS>
+__device__ __forceinline__ void recipe_band_finish(const DevProblem &P, int mode, const double *__restrict__ th, WalkerDesc &D,
+                                                   int lane, double val) {
+    const double a_v = th[NS];
+    const bool redden = redden_rule(mode, P.use_av, a_v);
+    const double chi = band_chi<NS>(P, redden, a_v, [&](int k) __attribute__((always_inline)) { return readlane_f64(val, k); });
+    if (lane == 0) D.chi_extra = chi;
+}
+
 // ---- the one-thread forms (pair_kernel.h's planner) ---------------------------------------------------------------------
 struct ScalarPriorTabs {
     const double *isot, *isol;               // isochrone Teff, luminosity (LDS)
