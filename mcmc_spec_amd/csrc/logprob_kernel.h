@@ -125,7 +125,8 @@ __device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &
 // ALWAYS = the terms are wanted whatever `on` says (the early-histogram median only runs in the fused modes): no
 //         run-time flag inside the pass, whose merge points would bring register copies back.
 // Holds plain pointers, never a reference to the by-value kernel argument (see DevProblem).
-template <int MAXT, bool PF, bool ALWAYS, bool AHEAD>
+// FLDS = the data flux (alone) comes from LDS: the linked form, whose workgroup has room for one more vector of its segment.
+template <int MAXT, bool PF, bool ALWAYS, bool AHEAD, bool FLDS = false>
 struct ChiElem {
     static constexpr int VK = kMaxWaves / (MAXT / kWave);
     static constexpr int NSET = AHEAD ? 2 : 1;
@@ -145,7 +146,7 @@ struct ChiElem {
             e = e < ne ? e : ne - 1;
             const unsigned int o16 = (unsigned int)e << 4;
             nv[SET][j] = ld_off(iv2, o16);
-            if (!PF) { nu[SET][j] = ld_off(u2, o16); nf[SET][j] = ld_off(f2, o16); }
+            if (!PF) { nu[SET][j] = ld_off(u2, o16); if (!FLDS) nf[SET][j] = ld_off(f2, o16); }
         }
     }
     __device__ __forceinline__ void prime_from(int base) {  // before a pass that starts at pixel `base`
@@ -172,6 +173,11 @@ struct ChiElem {
                 cu[j] = u2[e]; cf[j] = f2[e];  // LDS
             } else {
                 cu[j] = nu[SET][j]; cf[j] = nf[SET][j];
+                if (FLDS) {
+                    int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
+                    e = e < ne ? e : ne - 1;
+                    cf[j] = f2[e];  // LDS (f2 is the workgroup's staged copy, indexed by the element's own number)
+                }
             }
         }
         if (AHEAD) load_trip<AHEAD ? 1 - PAR : 0>(base + 4 * MAXT);
@@ -320,6 +326,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // PF: u and data flux in LDS behind the model vector, in the tables' own pair layout (16-byte aligned)
     double2 *const lds_u2 = PF ? reinterpret_cast<double2 *>(reinterpret_cast<double *>(dyn_lds) + ((npix + 1) & ~1)) : nullptr;
     double2 *const lds_f2 = PF ? lds_u2 + ne : nullptr;
+    // linked: the data flux of this workgroup's segment behind its model values, indexed by the element's own number
+    double2 *const lds_lf2 = LK ? reinterpret_cast<double2 *>(reinterpret_cast<double *>(dyn_lds) + 2 * kSegElems) - myseg * kSegElems : nullptr;
 
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
@@ -410,6 +418,12 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             lds_u2[e] = P.u2[e];
             lds_f2[e] = P.f2[e];
         }
+    }
+    if (LK && wave > NS) {  // linked: the same for the data flux of this workgroup's segment (the LDS has room for one vector)
+        const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
+        const int e_hi = (myseg + 1) * kSegElems < ne ? (myseg + 1) * kSegElems : ne;
+#pragma unroll 4
+        for (int e = myseg * kSegElems + id; e < e_hi; e += nthr) lds_lf2[e] = P.f2[e];
     }
     constexpr int NC = NS * 4;
     const int nseg_all = (ne + kSegElems - 1) / kSegElems;
@@ -563,7 +577,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // after the blend at 256 (two workgroups per CU: 512 walkers 16.2 us early against 15.95 late)
         constexpr bool kEarlyFUq = MAXT == 512;
         double2 fA = make_double2(0.0, 0.0), uA = fA, fB = fA, uB = fA;
-        if (kEarlyFUq && !PF) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
+        if (kEarlyFUq && !PF) {
+            uA = ld_off(P.u2, oA); uB = ld_off(P.u2, oB);
+            if (!LK) { fA = ld_off(P.f2, oA); fB = ld_off(P.f2, oB); }
+        }
         double sr[4] = {0.0, 0.0, 0.0, 0.0};
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         double2 klA = make_double2(0.0, 0.0), klB = klA;
@@ -598,6 +615,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         mB.y = blend_finish(sr[3], sh[3], klB.y, (double)dk.w, redc, RED, e2tab);
         if (!kEarlyFUq) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
         if (PF) { fA = lds_f2[ecA]; uA = lds_u2[ecA]; fB = lds_f2[ecB]; uB = lds_u2[ecB]; }  // (staged in phase 0)
+        if (LK) { fA = lds_lf2[ecA]; fB = lds_lf2[ecB]; }
         finish_elem(mA, fA, uA, ecA, liveA, std::integral_constant<int, 0>{});
         finish_elem(mB, fB, uB, ecB, liveB, std::integral_constant<int, SUB - 1>{});  // (256 threads: the trip's second element)
       }
@@ -726,7 +744,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // (the element's "npix" is this segment's end: pixels beyond it are not this workgroup's, and the canonical sum
         // of ONE segment has no fold)
         const int p_lo = myseg * (2 * kSegElems), p_hi = (p_lo + 2 * kSegElems < npix) ? p_lo + 2 * kSegElems : npix;
-        ChiElem<MAXT, false, true, true> ce{P.u2, P.f2, P.iv2, ne, p_hi, 0.0, 0.0, 0.0, {}, true, &red[0][0][0], {}, {}, {}, 0.0};
+        ChiElem<MAXT, false, true, true, true> ce{P.u2, lds_lf2, P.iv2, ne, p_hi, 0.0, 0.0, 0.0, {}, true, &red[0][0][0], {}, {}, {}, 0.0};
         ce.prime_from(p_lo);
         if (tid == 0) {
             // (test hook: nobody signals, so every wait below runs into its bound)

@@ -337,8 +337,9 @@ template <bool LK>
 int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
     // (linked: block = (walker / 8) * 8 segments + segment * 8 + walker % 8, see the kernel)
     const dim3 g((unsigned)(LK ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
-    // dynamic LDS: the model vector (linked: one segment of it)
-    const size_t lds = sizeof(double) * (size_t)(LK ? std::min<int64_t>(P.npix, 2 * kSegElems) : P.npix) + (size_t)c->pad_lds;
+    // dynamic LDS: the model vector (linked: one segment of it, and the segment's data flux behind it)
+    const size_t lds = LK ? sizeof(double) * (size_t)(2 * kSegElems) + sizeof(double2) * (size_t)kSegElems
+                          : sizeof(double) * (size_t)P.npix + (size_t)c->pad_lds;
 #define MSX_LEAD_ARGS (P.smp_on ? (const double *)P.smp_coords : A.theta), (const unsigned char *)c->d_recipe_block, A.niso_nt, \
                       A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, P.smp_rec
 #define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                   \
