@@ -151,7 +151,7 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
  * sums / value ranges / histogram counters inside the kernel (a bounded wait: 20 ms), each makes the chi^2 / median-
  * candidates pass over its own segment, and whichever finishes last ranks the candidates and completes the walker.
  * MSX_PATH_AUTO takes it while walkers x segments <= #CUs (MSX_LINKED=0 in the environment: never; =1: whenever the
- * spectrum has 2..8 segments): 128 walkers x 16,384 px 28.6 us against 33.3 fused, 8..64 walkers 24.4..25.8 us
+ * spectrum has 2..8 segments): 128 walkers x 16,384 px 27.2 us against 31.9 fused, 8..64 walkers 23.5..24.5 us
  * (DESIGN.md); also under the device-resident sampler.
  * A meeting that times out fails its walker with MSX_W_HANDOVER and POISONS the context's linked form: a device-side
  * word makes every later linked launch fail ALL its walkers with MSX_W_HANDOVER (never a value computed from stale
@@ -220,7 +220,8 @@ int msx_sampler_end(msx_ctx *ctx, double *coords, double *logp);
  * workgroup waits inside the kernel (bounded: 20 ms, then the chunk's worst_status is MSX_W_HANDOVER) until the two
  * walkers its move reads have reached the versions the move is defined on, the coordinates are double-buffered by
  * version parity and each finished walker publishes its new version -- so a half-step's launch, start-up and slowest
- * walker no longer sit between two dependent evaluations (256 walkers x 4096 px: 33.9 us per iteration against 37.1).
+ * walker no longer sit between two dependent evaluations (256 walkers x 4096 px: 32.4 us per iteration; 34.3 against
+ * 38.0 with plain launches when it was measured side by side).
  * Same chain, bit for bit.  Chosen by the first msx_sampler_enqueue of a run; MSX_SMP_OVERLAP=0 in the environment:
  * never.  *out = 1 if the run begun on ctx takes it, 0 if not, -1 before its first chunk.                           */
 int msx_sampler_overlapped(msx_ctx *ctx, int32_t *out);
