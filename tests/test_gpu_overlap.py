@@ -7,6 +7,8 @@ version parity, every finished walker publishes its version.  None of that may c
 host-driven loop over the same randomness is the reference -- and a walker that never publishes must end in a loud
 MSX_W_HANDOVER, not in a hang or a value.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,7 +16,8 @@ import common
 from common import golden_case
 from test_gpu_parity import make_engine
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('MSX_SMP_OVERLAP', '') == '0', reason='overlap switched off in the environment')]
 
 
 def _config2():

@@ -2,6 +2,8 @@
 vectors and against the CPU oracle on identical inputs.  Tolerance on log-probabilities is the
 north-star's 1e-6 relative; what is actually observed is ~1e-12, and the tighter bound 1e-9 is
 asserted so regressions in summation order or table staging are caught early."""
+import os
+
 import numpy as np
 import pytest
 
@@ -892,10 +894,11 @@ def test_resampled_tables_stay_at_rounding_level_under_heavy_extinction():
     print('resampled tables, A_V in {0, 0.3, 1, 3}: max relative deviation from the oracle', e.max())
     assert e.max() < 1e-11
     # 12 bytes per node-pixel are in use; a workgroup with a CU to itself keeps u and the data flux in LDS for the chi^2 pass
-    assert eng.ctx.bytes_per_eval(1000) == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12
-    assert eng.ctx.bytes_per_eval(64) == 700 * (12 * 8 + 12 + 16 + 8) + 8 * 6 + 12
-    # ... and from 4,096 walkers on two walkers of one grid cell share every load (+ the planner's 128-byte record)
-    assert eng.ctx.bytes_per_eval(100000) == 700 * (12 * 8 + 12 + 16 + 24) // 2 + 128 + 8 * 6 + 12
+    if not any(k in os.environ for k in ('MSX_NO_PF', 'MSX_PAIR_MIN', 'MSX_LINKED')):   # (the variants AUTO takes by default)
+        assert eng.ctx.bytes_per_eval(1000) == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12
+        assert eng.ctx.bytes_per_eval(64) == 700 * (12 * 8 + 12 + 16 + 8) + 8 * 6 + 12
+        # ... and from 4,096 walkers on two walkers of one grid cell share every load (+ the planner's 128-byte record)
+        assert eng.ctx.bytes_per_eval(100000) == 700 * (12 * 8 + 12 + 16 + 24) // 2 + 128 + 8 * 6 + 12
 
 
 def test_fuzzed_problems_against_the_oracle():
