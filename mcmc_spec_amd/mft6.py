@@ -6,6 +6,7 @@ signatures: ``logposterior``, ``loglikelihood``, ``logprior``, 
     mft6.set_band_library(bands)               # replaces the module global `lib` (mft6.py:21)
     mft6.set_av_prior(edges_pc, mu, sigma)     # replaces the module global `bayestar` (mft6.py:23)
     sampler = EnsembleSampler(nwalkers, ndim, mft6.logposterior, args=[...], kwargs={...}, vectorize=True)
+    sampler = mft6.device_sampler(nwalkers, ndim, args=[...], kwargs={...})   # the same chain, resident on the GPU
 
 Differences from the reference, all at the boundary:
   * ``p0`` may also be a 2-D ``(n, ndim)`` array (emcee ``vectorize=True``): a length-n array comes back.
@@ -153,6 +154,37 @@ def logposterior(p0, fr, nspec, ndust, data, err, broadening, r, specs, ctm, ptm
     eng = _staged(specs, fr, nspec, data, err, r, ctm, ptm, tmi, tma, matrix, tmin, tmax, prior, a, dist_fit,
                   rad_prior, need_prior=True)
     return eng.logposterior(p)
+
+
+def device_sampler(nwalkers, ndim, args, kwargs=None, a=2.0, seed=None, chunk=64):
+    """The sampler line of ``run_emcee`` -- ``emcee.EnsembleSampler(nwalkers, ndim, logposterior, args=[...],
+    kwargs={...})``, mft6.py:1490-1492 -- with the walker state RESIDENT on the GPU: ``args`` / ``kwargs`` are exactly
+    what that line passes for ``logposterior`` (everything after ``p0``); the problem they describe is staged once and
+    the stretch move runs on the device (``DeviceEnsembleSampler``: same interface -- ``sample``, ``run_mcmc``,
+    ``get_chain``, ``get_log_prob``, ``acceptance_fraction``, ``reset`` -- and, for the same seed, the same chain bit
+    for bit as ``EnsembleSampler(nwalkers, ndim, logposterior, args=args, kwargs=kwargs, vectorize=True)``)."""
+    from .sampler import DeviceEnsembleSampler
+    names = ('fr', 'nspec', 'ndust', 'data', 'err', 'broadening', 'r', 'specs', 'ctm', 'ptm', 'tmi', 'tma', 'vs', 'tmin',
+             'tmax', 'matrix', 'ra', 'dec', 'wu', 'dust', 'norm', 'prior', 'a', 'models', 'dist_fit', 'rad_prior')
+    given = dict(zip(names, args))
+    if len(args) > len(names):
+        raise TypeError('device_sampler: too many positional arguments for logposterior')
+    for k, v in (kwargs or {}).items():
+        if k not in names:
+            raise TypeError("logposterior() got an unexpected keyword argument '{}'".format(k))
+        if k in given:
+            raise TypeError("logposterior() got multiple values for argument '{}'".format(k))
+        given[k] = v
+    missing = [k for k in names[:18] if k not in given]
+    if missing:
+        raise TypeError('device_sampler: logposterior arguments missing: ' + ', '.join(missing))
+    g = given.get
+    if 2 * int(g('nspec')) + 2 != int(ndim):
+        raise ValueError("P0 doesn't match what I was expecting")
+    eng = _staged(g('specs'), g('fr'), g('nspec'), g('data'), g('err'), g('r'), g('ctm'), g('ptm'), g('tmi'), g('tma'),
+                  g('matrix'), g('tmin'), g('tmax'), g('prior', 0), g('a', True), g('dist_fit', True),
+                  g('rad_prior', False), need_prior=True)
+    return DeviceEnsembleSampler(nwalkers, ndim, eng, mode='logposterior', a=a, seed=seed, chunk=chunk)
 
 
 def loglikelihood(p0, fr, nspec, ndust, data, err, broadening, r, specs, ctm, ptm, tmi, tma, vs, matrix, w='aa',

@@ -402,6 +402,31 @@ def test_dropin_signatures_match_reference_golden():
         m.logposterior(np.zeros(7), *post_args, **kw)
 
 
+def test_dropin_device_sampler_walks_the_chain_of_the_emcee_line():
+    """run_emcee's sampler line (mft6.py:1490-1492) with the same args / kwargs: the host sampler over the drop-in
+    logposterior and mft6.device_sampler give one chain, bit for bit; argument mistakes fail like the function's."""
+    from mcmc_spec_amd.sampler import EnsembleSampler
+    c = golden_case('A')
+    m = _dropin(c)
+    args = [c.fr, 2, 0, c.data, c.err, 1700, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma, None, c.tmin, c.tmax, c.matrix,
+            10.0, 20.0]
+    kw = dict(dust=False, norm=True, prior=c.prior, a=True, models='btsettl', dist_fit=True, rad_prior=True)
+    rng = np.random.default_rng(3)
+    p0 = c.theta[0] + rng.normal(size=(32, 6)) * np.array([20, 20, 0.02, 0.02, 0.02, 2e-5])
+    host = EnsembleSampler(32, 6, m.logposterior, args=args, kwargs=kw, vectorize=True, seed=4)
+    hs = host.run_mcmc(p0, 30)
+    dev = m.device_sampler(32, 6, args=args, kwargs=kw, seed=4, chunk=8)
+    ds = dev.run_mcmc(p0, 30)
+    assert np.array_equal(dev.get_chain(), host.get_chain()) and np.array_equal(dev.get_log_prob(), host.get_log_prob())
+    assert np.array_equal(ds.coords, hs.coords) and 0.05 < dev.acceptance_fraction.mean() < 0.95
+    with pytest.raises(TypeError):
+        m.device_sampler(32, 6, args=args, kwargs=dict(kw, bogus=1))
+    with pytest.raises(TypeError):
+        m.device_sampler(32, 6, args=args[:-3], kwargs=kw)
+    with pytest.raises(ValueError):
+        m.device_sampler(32, 8, args=args, kwargs=kw)
+
+
 def test_dropin_logprior_with_two_live_datasets():
     """logprior takes its dataset from the LAST staging call (or from `specs=`), explicitly -- and since the value
     depends on p0 and the prior arguments only, it is the same whichever dataset carries it."""
