@@ -373,6 +373,40 @@ def main():
     # launches); the default 200-step run is long enough not to care, the driver's 20-step run is not.
     # (issued right before the timed region, after the graph capture: capturing leaves the GPU idle for milliseconds)
     ramp = int(os.environ.get('MSX_BENCH_RAMP', '1500'))
+    # N > 1, which variant next to the collective?  The N = 1 variant needs every CU for itself (123 KB of LDS each): if
+    # RCCL's kernel cannot share a CU with it, a displaced walker costs a second round; the <= 128-VGPR variant leaves
+    # room but is the slower kernel (it has no LDS for the staged pixel vectors: DESIGN.md section 4).  Whether RCCL's
+    # kernel fits beside a workgroup cannot be known from here, so both are timed -- 40 steps each of the very loop that
+    # follows, collective included -- and the ranks agree on the one whose SLOWEST rank is faster.  Setup, untimed.
+    block_tuned = None
+    if use_gather and not args.block and args.npix < 8192 and os.environ.get('MSX_BENCH_TUNE_BLOCK', '1') == '1':
+        cands, tms = [_lib.BLOCK_512_SHARED, 0], []
+        for cb in cands:
+            block = cb
+            calls = calls_for(sptr)
+            for i in range(8):
+                reuse_guard(i)
+                launch(i)
+                gather(i)
+            drain()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(40):
+                reuse_guard(i)
+                launch(i)
+                gather(i)
+            drain()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            tms.append(e0.elapsed_time(e1) * 1e3 / 40)
+        t_all = torch.tensor(tms, dtype=torch.float64, device=dev)
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        pick = int(torch.argmin(t_all).item())
+        block = cands[pick]
+        calls = calls_for(sptr)
+        block_tuned = {'shared_512_us_per_step': float(t_all[0].item()), 'own_cu_512_us_per_step': float(t_all[1].item()),
+                       'taken': 'shared (<= 128 VGPRs, two per CU)' if pick == 0 else 'own CU (pixel vectors staged in LDS)'}
     for i in range(args.warmup):
         reuse_guard(i)
         launch(i)
@@ -666,7 +700,7 @@ def main():
             'config': {'workload': workload, 'baseline_config': args.config if args.config != 2 or world == 1 else 3,
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': W.get('nwin'),
                        'grid': '26x4x135000 f64 synthetic',
-                       'block_threads': block or 'auto', 'collective': collective,
+                       'block_threads': block or 'auto', 'block_tuned_next_to_the_collective': block_tuned, 'collective': collective,
                        'device_warmup': '{} untimed launches (>= {}, until two runs of 500 agree to 0.7 %) after the {} warm-up steps, right before the timed region (sustained-load clocks)'.format(ramp_done, ramp, args.warmup),
                        'step_loop': ('{} eager + hipGraph of {} steps x {} replays + {} eager'.format(
                            head, chunk, (args.steps - head) // chunk, args.steps - head - (args.steps - head) // chunk * chunk)
