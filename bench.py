@@ -379,10 +379,19 @@ def main():
     # kernel fits beside a workgroup cannot be known from here, so both are timed -- 40 steps each of the very loop that
     # follows, collective included -- and the ranks agree on the one whose SLOWEST rank is faster.  Setup, untimed.
     block_tuned = None
-    if use_gather and not args.block and args.npix < 8192 and os.environ.get('MSX_BENCH_TUNE_BLOCK', '1') == '1':
-        cands, tms = [_lib.BLOCK_512_SHARED, 0], []
-        for cb in cands:
+    if use_gather and not args.block and os.environ.get('MSX_BENCH_TUNE_BLOCK', '1') == '1':
+        # (long spectra: the same question for the LINKED form, whose workgroups fill every CU and wait for each other,
+        # against the fused kernel, which leaves half the CUs free)
+        if args.npix < 8192:
+            cands = [('shared (<= 128 VGPRs, two per CU)', _lib.BLOCK_512_SHARED, _lib.PATH_AUTO),
+                     ('own CU (pixel vectors staged in LDS)', 0, _lib.PATH_AUTO)]
+        else:
+            cands = [('fused (one workgroup per walker)', 0, _lib.PATH_FUSED), ('automatic (linked while walkers x segments <= #CUs)', 0, _lib.PATH_AUTO)]
+        tms = []
+        for _, cb, cpath in cands:
             block = cb
+            for e in engines:
+                e.ctx.set_path(cpath)
             calls = calls_for(sptr)
             for i in range(8):
                 reuse_guard(i)
@@ -403,10 +412,11 @@ def main():
         t_all = torch.tensor(tms, dtype=torch.float64, device=dev)
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         pick = int(torch.argmin(t_all).item())
-        block = cands[pick]
+        block = cands[pick][1]
+        for e in engines:
+            e.ctx.set_path(cands[pick][2])
         calls = calls_for(sptr)
-        block_tuned = {'shared_512_us_per_step': float(t_all[0].item()), 'own_cu_512_us_per_step': float(t_all[1].item()),
-                       'taken': 'shared (<= 128 VGPRs, two per CU)' if pick == 0 else 'own CU (pixel vectors staged in LDS)'}
+        block_tuned = {'candidates_us_per_step': {cands[k][0]: float(t_all[k].item()) for k in range(len(cands))}, 'taken': cands[pick][0]}
     for i in range(args.warmup):
         reuse_guard(i)
         launch(i)
