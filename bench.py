@@ -664,9 +664,10 @@ def main():
             'note': 'achieved = bytes the launch requests from the memory system (L2-served) / kernel time, averaged over '
                     'the WHOLE kernel (recipe, blend, median, chi^2); peak = the L2 aggregate of MI355X_MICROARCH.md, beside '
                     'it the same guide\'s measured chip-wide rate for rows gathered from L2 (16.8-18.8 TB/s).  The blend '
-                    'phase alone moves its ~500 KB per walker in ~6.5 us: ~20 TB/s chip-wide with 256 CUs pulling, 78 GB/s '
-                    'per CU (the guide measures 66-73); the rest of the kernel is the walker\'s dependent chain (recipe, '
-                    'median, chi^2) and moves little.  Large batches reach 21.6 TB/s over the whole kernel (extra.sweep)',
+                    'phase alone moves its ~440 KB per walker in ~5.4 us: ~21 TB/s chip-wide with 256 CUs pulling, 81 GB/s '
+                    'per CU (the guide measures 66-73); u and the data flux (64 KB) come in while the recipe runs; the rest of '
+                    'the kernel is the walker\'s dependent chain (recipe, median, chi^2) and moves little.  Large batches '
+                    'reach 16 TB/s over the whole kernel with half the requests per walker (pair form, extra.sweep)',
         }
         if not replicas:
             nwin = W['nwin']
