@@ -1289,6 +1289,18 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
         r->overlap = !(e && e[0] == '0') && !r->sharded && 2 * ns <= cus && !c->model_in_global && c->recipe_fast &&
                      c->path != MSX_PATH_LINKED && c->path != MSX_PATH_PAIR && !auto_takes_linked(c, ns);
     }
+    if (r->overlap == 1) {
+        // the version protocol rests on every walker moving exactly once per iteration: the two half-steps' walkers must
+        // be a permutation of the ensemble (emcee's random split is; checked here because a violation would not fail
+        // until a workgroup's wait runs out on the device)
+        std::vector<int64_t> seen((size_t)nw, -1);
+        for (int64_t i = 0; i < nh; ++i) {
+            const int64_t it = i / (2 * ns);
+            if (seen[(size_t)hi[i]] == it)
+                return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue: a walker appears twice in one iteration's two half-steps");
+            seen[(size_t)hi[i]] = it;
+        }
+    }
     // ... and the proposal's inputs once more as one record per walker (the kernel's first load), with the versions of
     // the two walkers the move reads: before iteration k every walker has version k; the second half-step's partners
     // were updated by the first

@@ -116,3 +116,29 @@ def test_a_version_that_is_never_published_ends_in_a_loud_failure():
         eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 0)
     host, hs, dev, ds = _chains(eng, p0, 6, 8, 4)
     assert dev.overlapped is True and np.array_equal(dev.get_chain(), host.get_chain())
+
+
+def test_half_steps_that_do_not_partition_the_ensemble_are_refused():
+    """The version protocol rests on every walker moving exactly once per iteration; an enqueue whose two half-steps
+    name a walker twice is refused on the host instead of failing after a 20 ms wait on the device."""
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.sampler import EnsembleSampler
+    eng, W = _config2()
+    nw = 32
+    p0 = synth.draw_walkers(nw, seed=6, tmin=W['tmin'], tmax=W['tmax'])
+    lp0 = eng.logposterior(p0)
+    c = eng.ctx
+    draw = EnsembleSampler(nw, 6, lambda x: x, seed=1)
+    c.sampler_begin(_lib.MODE_LOGPOST, p0.copy(), lp0.copy(), 4)
+    try:
+        arrays = [np.array(a) for a in draw._draw_steps(2)]
+        c.sampler_enqueue(0, *arrays)                      # a proper split: taken (and the run overlaps)
+        assert c.sampler_overlapped() == 1
+        c.sampler_collect(0, 2)
+        bad = [np.array(a) for a in draw._draw_steps(2)]
+        bad[0] = bad[0].copy()
+        bad[0][1, 1, 0] = bad[0][1, 0, 0]                  # second iteration: one walker in both half-steps
+        with pytest.raises(_lib.MsxError, match='appears twice'):
+            c.sampler_enqueue(1, *bad)
+    finally:
+        c.sampler_end()
