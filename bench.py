@@ -626,11 +626,11 @@ def main():
         else:
             bt = 512 if n <= 2 * cus else 256
         nseg = (args.npix + 8191) // 8192
-        if block == 0 and 2 <= nseg <= 8 and args.npix * 8 <= 134 * 1024 and 2 * n * nseg <= cus and os.environ.get('MSX_LINKED', '') != '0':
-            kernel_name = ('logprob_kernel<NS=2, 512 threads, linked> (one workgroup per walker and 8192-pixel segment, handed over inside '
-                           'the launch; four pixels per lane and trip)')
+        if block == 0 and 2 <= nseg <= 8 and n * nseg <= cus and os.environ.get('MSX_LINKED', '') != '0' and eng.ctx.bytes_per_eval(n) != eng.ctx.bytes_per_eval(10 ** 9):
+            kernel_name = ('logprob_kernel<NS=2, 512 threads, linked> (one workgroup per walker and 8192-pixel segment; partial sums and '
+                           'histogram counters exchanged inside the launch; the segment\'s data flux staged in LDS; four pixels per lane and trip)')
         elif bt == 256 and n <= 2 * cus:
-            kernel_name = 'logprob_kernel<NS=2, 256 threads, two per CU> (four pixels per lane and trip)'
+            kernel_name = 'logprob_kernel<NS=2, 256 threads, two per CU> (u / flux staged in LDS where two such workgroups fit a CU; four pixels per lane and trip)'
         elif bt == 256:
             kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
         elif args.npix * 8 <= 70 * 1024 and (n > cus or block == _lib.BLOCK_512_SHARED):
@@ -638,7 +638,7 @@ def main():
         elif args.npix * 8 * 3 > 130 * 1024:
             kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU, four pixels per lane and trip)'
         else:
-            kernel_name = 'logprob_kernel<NS=2, 512 threads, PF> (one workgroup per CU, u / flux kept in LDS, four pixels per lane and trip)'
+            kernel_name = 'logprob_kernel<NS=2, 512 threads, PF> (one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip)'
         # ---- the roofline that bounds THIS design --------------------------------------------------------------
         # The kernel never streams the windowed grid from HBM: staging folds the resample into per-node tables of
         # 12 bytes per pixel (R float64 + H float32, 5.1 MB at config 2) that live in L2 / Infinity Cache, and a

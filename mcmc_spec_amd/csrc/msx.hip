@@ -91,6 +91,7 @@ struct msx_ctx {
     int64_t opt_chains = 0, cap_chain = 0;
     int max_dyn_lds = 0;
     bool pf_ok = false;   // the LDS-staged-statics variants fit (msx_stage_problem)
+    bool pf256_ok = false; // ... the 256-thread two-per-CU one (two workgroups of it in a CU's LDS)
     bool use_pf = true;   // MSX_NO_PF=1 in the environment turns them off (A/B measurements)
     int q256 = -1;           // 256-thread launches: the two-per-CU quad-trip variant always (1) / never (0) / up to two walkers per CU (-1); MSX_Q256
     bool force_sh2 = false;  // MSX_NO_SH2=0: binaries take the <= 128-VGPR variant even with a CU to themselves (A/B measurements)
@@ -365,7 +366,9 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
             // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
             // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
             const bool q256 = c->q256 > 0 || (c->q256 < 0 && A.n <= 2 * (int64_t)c->prop.multiProcessorCount);
-            if (B == 256 && q256) MSX_GO(2, 2, 256, false, true, false, lds);
+            // (... with u and the data flux staged in LDS when two such workgroups still fit a CU)
+            if (B == 256 && q256 && c->pf256_ok && c->use_pf) MSX_GO(2, 2, 256, false, true, true, lds_pf);
+            else if (B == 256 && q256) MSX_GO(2, 2, 256, false, true, false, lds);
             else if (B == 256) MSX_GO(2, 2, 256, false, false, false, lds);
             else if (pf) MSX_GO(2, 2, 512, false, false, true, lds_pf);
             else if (sh) MSX_GO(2, 2, 512, false, true, false, lds);   // two workgroups per CU
@@ -447,7 +450,7 @@ hipError_t raise_one(K kernel) {
 hipError_t raise_all() {
     hipError_t e = hipSuccess;
 #define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__>)
-    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 256, false, true, false);
+    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 256, false, true, false); MSX_R(2, 2, 256, false, true, true);
     MSX_R(2, 2, 512, false, false, false); MSX_R(2, 2, 512, false, true, false); MSX_R(2, 2, 512, false, false, true);
     MSX_R(3, 2, 256, false, false, false); MSX_R(3, 2, 512, false, false, false); MSX_R(3, 2, 512, false, false, true);
     MSX_R(2, 2, 512, false, false, false, true); MSX_R(3, 2, 512, false, false, false, true);  // linked
@@ -806,6 +809,9 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         HIP_TRY(c, hipFuncGetAttributes(&a3, (const void *)logprob_kernel<3, 2, 512, false, false, true>));
         const int64_t room = (160 * 1024 - (int64_t)std::max(a2.sharedSizeBytes, a3.sharedSizeBytes)) & ~15ll;
         c->pf_ok = !model_in_global && (int64_t)sizeof(double) * ((p->npix + 1) & ~1ll) + 32 * npair + (int64_t)c->pad_lds <= room;
+        hipFuncAttributes a256;
+        HIP_TRY(c, hipFuncGetAttributes(&a256, (const void *)logprob_kernel<2, 2, 256, false, true, true>));
+        c->pf256_ok = 2 * ((int64_t)sizeof(double) * ((p->npix + 1) & ~1ll) + 32 * npair + (int64_t)a256.sharedSizeBytes) <= 160 * 1024;
     }
     if ((rc = raise_dynamic_lds_limits(c))) return rc;
     c->recipe_fast = P.niso <= 4 * kWave && P.nt <= kWave && P.ng <= 32 && P.nav + 1 <= 2 * kWave;
@@ -1727,7 +1733,10 @@ int msx_bytes_per_eval(msx_ctx *c, int64_t n, int64_t *requested_bytes) {
     //   blend: 12-B {R f64, H f32} per corner + {k_lo f64, dk f32} + data flux, u (f64)        per pixel
     //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
     const bool linked = auto_takes_linked(c, n);
-    const bool pf = !linked && pick_block(c, n, npix) == 512 && takes_pf(c, n);
+    const int64_t cus_ = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    const bool q256pf = !linked && pick_block(c, n, npix) == 256 && c->P.nspec == 2 && c->pf256_ok && c->use_pf &&
+                        (c->q256 > 0 || (c->q256 < 0 && n <= 2 * cus_));
+    const bool pf = q256pf || (!linked && pick_block(c, n, npix) == 512 && takes_pf(c, n));
     *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
     // the linked form: every segment's workgroup reads theta and writes its partials (counters, sums, range; chi^2 sum
     // and candidates: <= 64 of them as a rule), reads the other segments' partials, and one of them their candidates
