@@ -118,7 +118,7 @@ struct DevProblem {
 };
 
 #ifdef MSX_STAMPS
-__shared__ int msx_stamp_off;  // linked path: a walker's producers leave the stamps to its joiner
+__shared__ int msx_stamp_off;  // linked form: one of a walker's workgroups writes the stamps
 #define MSX_STAMP(P, wk, i) do { if (threadIdx.x == 0 && !msx_stamp_off) (P).stamps[(wk) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MSX_STAMP(P, wk, i) do { } while (0)
@@ -153,7 +153,7 @@ struct WalkerDesc {
 constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPresent = 5120, kRecipeBlockBytes = 5376;
 constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the linked form
 constexpr int kSegBins = 2048;      // (= kLogBins, median.h)
-constexpr unsigned long long kHandoverTicks = 2000000ull;  // linked path: a joiner gives up after 20 ms of the 100 MHz wall clock
+constexpr unsigned long long kHandoverTicks = 2000000ull;  // in-kernel waits (the linked form's meetings, the overlapped sampler's versions) give up after 20 ms of the 100 MHz wall clock
 
 // pair form: a walker's recipe as the planner (one thread per walker) leaves it for the pair kernel
 struct alignas(16) PairRec {

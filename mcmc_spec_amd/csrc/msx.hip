@@ -111,8 +111,8 @@ struct msx_ctx {
     hipEvent_t loop_eval_done = nullptr; // this rank's block of log p(q) is in its gathered vector
     hipEvent_t loop_copied = nullptr;    // this rank has copied every peer's block (peers may overwrite theirs)
     // Scratch rows (walkers per sub-batch), sized once at msx_stage_problem and only for the forms that can run on
-    // the staged spectrum: model vectors of the GM variants (> 17,152 pixels) and of the linked form's producers
-    // (2..8 segments of 8192 pixels), the producers' partials and hand-over flags.  No launch allocates.
+    // the staged spectrum: model vectors of the GM variants (> 17,152 pixels) and of the linked form's scratch-row exit
+    // (2..8 segments of 8192 pixels), the segments' partials and arrival counters.  No launch allocates.
     double *d_model_scratch = nullptr;
     SegPart *d_segparts = nullptr;  // linked form: [scratch_rows][segments]
     unsigned long long *d_seg_flag = nullptr;  // linked form: [scratch_rows] arrival counters (a multiple of 2 x segments between launches), + the poison word

@@ -97,7 +97,7 @@ def _config4_engine():
 
 
 def test_linked_hand_over_that_never_comes_fails_loudly_and_poisons_the_context():
-    """The fault hook makes the producers skip their signal: every joiner gives up after 20 ms of wall clock, the
+    """The fault hook makes the workgroups skip their signal: every one of them gives up after 20 ms of wall clock, the
     walker reports MSX_W_HANDOVER and Python raises -- no hang, no value.  From then on, WITHOUT staging again and
     with the fault gone, the context must never hand out a value computed from the flags the failed launch left
     behind: the automatic choice takes the fused form (bit-equal), an explicit PATH_LINKED is refused; staging again
@@ -150,7 +150,7 @@ def test_linked_poison_reaches_callers_who_never_read_a_status():
     good = lp.cpu().numpy().copy()
     assert np.all(st.cpu().numpy() == _lib.W_OK) and np.all(np.isfinite(good))
     eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 1)
-    launch()                                               # every joiner times out; nobody reads the statuses
+    launch()                                               # every workgroup times out; nobody reads the statuses
     eng.ctx.test_hook(_lib.HOOK_LINKED_FAULT, 0)
     for _ in range(2):                                     # healthy launches, same context, not staged again
         lp.zero_()
