@@ -276,3 +276,42 @@ def test_device_resident_sampler_through_the_linked_form():
     got = run_group([eng, eng2], p0, 20, seed=3)
     for chain, lp, nacc, worst, coords, logp in got:
         assert worst == 0 and np.array_equal(chain, chains[0][0]) and np.array_equal(lp, chains[0][1])
+
+
+@pytest.mark.parametrize('npix', [16384, 12001])
+def test_linked_triple_system(npix):
+    """nspec = 3 (ndim 8) over a two-segment spectrum: the triple's linked variant (twelve corners, the third star's
+    recipe wave) against the fused kernel bit for bit and against the oracle, posterior mode (the triple prior box with
+    rad_prior), and through the device-resident sampler."""
+    from mcmc_spec_amd import _lib, bands
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    c = golden_case('C')
+    rng = np.random.default_rng(npix)
+    wl = np.sort(rng.uniform(0.56, 0.89, npix))
+    data = [wl, 1.0 + 0.05 * rng.normal(size=wl.size)]
+    err = np.full(wl.size, 0.05)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(data, err, c.fr, [wl.min(), wl.max()], c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=3,
+                      bands=bands.make_bands(c.tables, *c.vega), av_table=common.av_table_exact(), tmin=c.tmin, tmax=c.tmax,
+                      prior=c.prior, rad_prior=True)
+    f, l = both(eng, eng.logposterior, c.theta)
+    assert np.array_equal(f, l, equal_nan=True) and np.isfinite(l).sum() >= 3
+    ok = np.isfinite(l)
+    fl, ll = both(eng, eng.loglikelihood, c.theta[ok][:6])
+    assert np.array_equal(fl, ll)
+    one = common.orc.loglikelihood(list(c.theta[ok][0]), c.fr, 3, data, err, [wl.min(), wl.max()], c.specs, c.ctm, c.ptm,
+                                   c.tmi, c.tma, c.matrix, bandlib=c.bandlib)
+    assert rel_err(ll[0], one) < TIGHT
+    good = c.theta[ok]
+    nw = 16
+    p0 = good[0] + rng.normal(size=(nw, 8)) * np.array([10, 10, 10, 0.01, 0.01, 0.01, 0.01, 1e-5])
+    chains = []
+    for path in (_lib.PATH_FUSED, _lib.PATH_LINKED):
+        eng.ctx.set_path(path)
+        s = DeviceEnsembleSampler(nw, 8, eng, seed=3, chunk=4)
+        s.run_mcmc(p0, 6)
+        chains.append((s.get_chain(), s.get_log_prob()))
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1], equal_nan=True)
