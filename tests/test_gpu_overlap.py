@@ -142,3 +142,17 @@ def test_half_steps_that_do_not_partition_the_ensemble_are_refused():
             c.sampler_enqueue(1, *bad)
     finally:
         c.sampler_end()
+
+
+def test_overlapped_half_steps_of_a_triple_system():
+    """ndim 8 (three recipe waves wait for the walkers' versions, the fourth wave fetches the accept inputs): against
+    the host loop, bit for bit."""
+    c = golden_case('C')
+    eng = make_engine(c, rad_prior=True)
+    good = c.theta[np.isfinite(eng.logposterior(c.theta))]
+    rng = np.random.default_rng(12)
+    p0 = good[0] + rng.normal(size=(24, 8)) * np.array([10, 10, 10, 0.01, 0.01, 0.01, 0.01, 1e-5])
+    host, hs, dev, ds = _chains(eng, p0, 21, 5, 8)
+    assert dev.overlapped is True
+    assert np.array_equal(dev.get_chain(), host.get_chain()) and np.array_equal(dev.get_log_prob(), host.get_log_prob(), equal_nan=True)
+    assert np.array_equal(ds.coords, hs.coords)
