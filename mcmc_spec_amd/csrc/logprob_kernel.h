@@ -411,8 +411,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // requests 116 instead of 132 bytes per pixel and has four loads fewer per trip to wait for.
         // (256 walkers x 4096 px: 15.3 -> 13.7 us on the same box.  Round 1 staged them like this, round 2 let the
         // blend loop leave them in LDS "since it loads them anyway" -- it does not have to.  The extinction curve k too,
-        // 16 more bytes per element: no further gain, 13.7 us.  The staging is hidden entirely: a build that skips it
-        // is not faster.)
+        // 16 more bytes per element: no further gain, 13.7 us; 1/err^2 for the chi^2 pass likewise.  The staging is hidden
+        // entirely: a build that skips it is not faster.)
         const int nthr = B - (NS + 1) * kWave, id = tid - (NS + 1) * kWave;
 #pragma unroll 4
         for (int e = id; e < ne; e += nthr) {
