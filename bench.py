@@ -759,7 +759,7 @@ def main():
                 req_m = eng.ctx.bytes_per_eval(m)
                 row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6, 'requested_bytes_per_eval': req_m,
                        'requested_GBps': m * req_m / us / 1e3, 'frac_of_l2_peak': m * req_m / us / 1e3 / L2_PEAK_GBPS}
-                row['form'] = 'pair (planner + two walkers of one grid cell per workgroup)' if m >= 4096 and args.npix <= 4096 else 'fused'
+                row['form'] = 'pair (planner + two walkers of one grid cell per workgroup)' if m >= (2304 if args.npix > 3072 else 4096) and args.npix <= 4096 else 'fused'
                 # VALU wave-instructions per evaluation: profiles/r3_sq_*_pair_vs_fused.json (16,384 walkers: fused
                 # 256-thread variant 9,028, pair kernel 8,741)
                 vi = (8741 if row['form'] != 'fused' else 9028) if (m > 1024 and args.npix == 4096) else None

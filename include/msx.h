@@ -143,8 +143,13 @@ int msx_logprob_batch(msx_ctx *ctx, int32_t mode, const double *theta, int64_t n
 int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim,
                           double *d_logp, int32_t *d_status, void *hip_stream, int32_t block_threads);
 
-/* Two forms of the same path, same bits.
+/* Three forms of the same path, same bits.
  * FUSED: one launch, one workgroup per walker.
+ * PAIR: for large batches of a binary with <= 4096 pixels: a planner kernel (one thread per walker: the recipe, the
+ * prior and band terms, who shares a grid cell with whom) and a kernel that evaluates TWO walkers of one grid cell
+ * per workgroup from one set of loads, model values in registers (16,384 walkers 316 us against 419 fused).
+ * MSX_PATH_AUTO takes it from 9 walkers per CU on (2,304; spectra of <= 3,072 pixels: 16 per CU; MSX_PAIR_MIN in the
+ * environment) while the planner's last count says the ensemble pairs (msx_pair_stats); DESIGN.md section 5.1.
  * LINKED: for few walkers x long spectra (2..8 segments of 8192 pixels), one workgroup per (walker, segment) in ONE
  * launch, so that e.g. 128 walkers x 16,384 pixels use 256 CUs instead of 128 and each workgroup's chain of latencies
  * is 8192 pixels long.  A walker's workgroups are equals: each blends its segment, they exchange the segments' fit

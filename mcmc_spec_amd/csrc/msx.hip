@@ -886,6 +886,14 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         c->h_pair_stats[0] = 1; c->h_pair_stats[1] = 0;  // (nothing known yet: try)
         c->pair_auto_launches = 0;
         c->pair_rows = rows;
+        // From where the pair form pays (the planner costs 13 us whatever the batch): measured on 256 CUs, fused against
+        // pair -- 4096 px: 2,048 walkers 62.9 / 71.5 us, 2,304: 73.9 / 70.3, 3,072: 87.9 / 83.0; 1194 and 2048 px: 2,304
+        // walkers 45.5 / 49.3 and 48.8 / 52.1, 4,096: 72.7 / 68.0 and 76.8 / 71.6.  In walkers per CU: 9 for the long
+        // spectra, 16 for the short ones.
+        {
+            const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+            c->pair_min_walkers = (p->npix > 3072 ? 9 : 16) * cus;
+        }
         if (const char *e = getenv("MSX_PAIR_MIN")) c->pair_min_walkers = atoll(e) > 0 ? std::max<int64_t>(2, atoll(e)) : INT64_MAX;
     }
 #ifdef MSX_STAMPS
