@@ -198,6 +198,35 @@ def load_profile(name):
     return json.load(open(p)) if os.path.exists(p) else None
 
 
+def self_launch(n_gpus, argv, run=None):
+    """`python bench.py --gpus N ...` outside any launcher: run the same command under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P` (one rank
+    per GPU over RCCL -- the form the task statement gives for N > 1; the reference's own fan-out is the commented
+    `threads=nwalkers` pool of /root/reference/mft6.py:1490-1492) as a CHILD process -- this process has not imported
+    torch nor touched a GPU, and never replaces itself -- and pass rank 0's ONE JSON line through on stdout.
+    Returns the child's return code (non-zero too when it printed no result line)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    print('[bench] --gpus {} without WORLD_SIZE: launching {}'.format(n_gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    res = (run or subprocess.run)(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in (res.stdout or '').splitlines() if ln.lstrip().startswith('{')]
+    for ln in (res.stdout or '').splitlines():
+        if not ln.lstrip().startswith('{') and ln.strip():
+            print(ln, file=sys.stderr)     # anything else a rank or the launcher wrote to stdout
+    if lines:
+        sys.stdout.write(lines[-1].strip() + '\n')
+        sys.stdout.flush()
+    if res.returncode != 0:
+        return res.returncode
+    return 0 if lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -223,6 +252,11 @@ def main():
         args.walkers = args.walkers or 512
     args.npix = args.npix or 4096
     args.walkers = args.walkers or 256
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (a CHILD process,
+    # before this one imports torch or touches a GPU), hand rank 0's one JSON line through and leave with its code
+    # (MSX_BENCH_SELF_LAUNCH=1: the same for N = 1 -- the one-GPU rehearsal of this path, tests/test_gpu_bench_contract.py)
+    if (args.gpus > 1 or os.environ.get('MSX_BENCH_SELF_LAUNCH') == '1') and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the result: libraries that print banners there (RCCL does at start-up) are
     # sent to stderr for the duration of the run
@@ -387,7 +421,7 @@ def main():
                      ('own CU (pixel vectors staged in LDS)', 0, _lib.PATH_AUTO)]
         else:
             cands = [('fused (one workgroup per walker)', 0, _lib.PATH_FUSED), ('automatic (linked while walkers x segments <= #CUs)', 0, _lib.PATH_AUTO)]
-        tms = []
+        tms, errs = [], []
         for _, cb, cpath in cands:
             block = cb
             for e in engines:
@@ -409,14 +443,23 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize(dev)
             tms.append(e0.elapsed_time(e1) * 1e3 / 40)
+            # a launch that FAILS is the fastest one (a timed-out linked form returns MSX_W_HANDOVER for every walker after
+            # one load): a candidate with any walker error status on any rank is out, whatever its time
+            errs.append(float((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item()))
+            for b_ in range(2):
+                status[b_].zero_()
         t_all = torch.tensor(tms, dtype=torch.float64, device=dev)
+        e_all = torch.tensor(errs, dtype=torch.float64, device=dev)
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        pick = int(torch.argmin(t_all).item())
+        dist.all_reduce(e_all, op=dist.ReduceOp.MAX)
+        t_rank = torch.where(e_all > 0, torch.full_like(t_all, float('inf')), t_all)
+        pick = int(torch.argmin(t_rank).item())
         block = cands[pick][1]
         for e in engines:
             e.ctx.set_path(cands[pick][2])
         calls = calls_for(sptr)
-        block_tuned = {'candidates_us_per_step': {cands[k][0]: float(t_all[k].item()) for k in range(len(cands))}, 'taken': cands[pick][0]}
+        block_tuned = {'candidates_us_per_step': {cands[k][0]: float(t_all[k].item()) for k in range(len(cands))},
+                       'candidates_walker_errors': {cands[k][0]: int(e_all[k].item()) for k in range(len(cands))}, 'taken': cands[pick][0]}
     for i in range(args.warmup):
         reuse_guard(i)
         launch(i)
@@ -570,7 +613,11 @@ def main():
         torch.cuda.synchronize(dev)
         kern_ms = e0.elapsed_time(e1) / ev_run
         kern_samples = ev_run
-    bad = int((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item())
+    bad_t = ((status[0] > _lib.W_REJECT).sum() + (status[1] > _lib.W_REJECT).sum()).to(torch.int64).reshape(1)
+    if world > 1:
+        dist.all_reduce(bad_t, op=dist.ReduceOp.SUM)   # every rank's walkers count, and every rank leaves with the same code
+    bad = int(bad_t.item())
+    n_ranks_seen = dist.get_world_size() if (world > 1 or force_gather) else 1
     # ---- beside the headline: the SAME K steps without the device warm-up --------------------------------------
     # (N = 1 only.)  The GPU is left idle for a second, the W warm-up steps are repeated and the timed region runs
     # again, with no untimed launches in between: what a caller gets who evaluates one short burst now and then.
@@ -717,8 +764,14 @@ def main():
                            head, chunk, (args.steps - head) // chunk, args.steps - head - (args.steps - head) // chunk * chunk)
                            if graph is not None else 'eager')},
             'roofline': roofline,
-            'walker_error_statuses': bad, 'gather_verified': gather_ok,
+            'walker_error_statuses': bad, 'gather_verified': gather_ok, 'n_ranks_seen': n_ranks_seen,
         }
+        if bad > 0 or gather_ok is False:
+            # evaluations that failed are not evaluations: no headline from them (and a non-zero exit code below)
+            out['invalid'] = ('{} walker error statuses in the timed region\'s last two steps'.format(bad) if bad > 0
+                              else 'the gathered log-probabilities differ from the ranks\' own')
+            out['value_if_it_were_valid'] = out['value']
+            out['value'] = None
         if unramped is not None:
             out['unramped'] = unramped
         if diag is not None:
@@ -786,6 +839,8 @@ def main():
         os.write(result_fd, (json.dumps(out, default=lambda o: o.item() if hasattr(o, 'item') else str(o)) + '\n').encode())
     if world > 1 or force_gather:
         dist.destroy_process_group()
+    if bad > 0 or gather_ok is False:
+        raise SystemExit(3)
 
 
 if __name__ == '__main__':

@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
+def _run(*extra, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '8', '--warmup', '2',
-                          '--no-extras', '--cpu-budget', '2'] + list(extra), capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          '--no-extras', '--cpu-budget', '2'] + list(extra), capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines          # exactly ONE line on stdout
@@ -46,3 +47,12 @@ def test_bench_config4_takes_the_linked_form():
     j = _run('--config', '4', '--no-cpu-baseline')
     assert j['config']['baseline_config'] == 4 and j['config']['npix'] == 16384
     assert 'linked' in j['roofline']['kernel'] and j['cpu_baseline'] is None
+
+
+def test_bench_launches_its_own_ranks_and_passes_the_line_through():
+    """The N > 1 entry rehearsed on one GPU: bench.py starts `python -m torch.distributed.run` as a child, the rank
+    builds a (one-rank) RCCL communicator, all-gathers every step, and its line arrives on the parent's stdout."""
+    j = _run('--no-cpu-baseline', env={'MSX_BENCH_SELF_LAUNCH': '1', 'MSX_BENCH_FORCE_GATHER': '1'})
+    assert j['n_gpus'] == 1 and j['n_ranks_seen'] == 1 and j['gather_verified'] is True
+    assert j['walker_error_statuses'] == 0 and j['value'] > 0
+    assert j['config']['collective'] != 'none' and 'multi_gpu_diag' in j
