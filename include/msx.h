@@ -281,6 +281,10 @@ int msx_pair_stats(msx_ctx *ctx, int64_t *out2);
  * overlapped sampler run the publication of their new version -- so that every in-kernel wait runs into its bound;
  * takes effect at the next launch, without restaging                                                              */
 #define MSX_HOOK_LINKED_FAULT 1
+/* MSX_HOOK_PAIR_LEASES: value != 0 marks every scratch row of the pair form's spill path as leased (what a launch torn
+ * down mid-spill would leave behind), 0 clears them: the next pair launch's spilling walkers must end with
+ * MSX_W_HANDOVER inside the bound instead of hanging; synchronises                                                  */
+#define MSX_HOOK_PAIR_LEASES 2
 int msx_test_hook(msx_ctx *ctx, int32_t what, int32_t value);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR, W_HANDOVER = 0, 1, 2, 3,
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
 PATH_AUTO, PATH_FUSED, PATH_PAIR, PATH_LINKED = 0, 1, 2, 4  # include/msx.h MSX_PATH_*
-HOOK_LINKED_FAULT = 1  # include/msx.h MSX_HOOK_*
+HOOK_LINKED_FAULT, HOOK_PAIR_LEASES = 1, 2  # include/msx.h MSX_HOOK_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
 _dp = C.POINTER(C.c_double)
@@ -256,7 +256,9 @@ class Context:
                                                   C.c_void_p(stream_ptr), int(block_threads)))
 
     def set_path(self, path):
-        """PATH_AUTO / PATH_FUSED / PATH_LINKED: which form of the hot path launches take (same bits either way)."""
+        """PATH_AUTO / PATH_FUSED / PATH_PAIR / PATH_LINKED: which form of the hot path launches take (same bits either
+        way).  PATH_PAIR (two walkers of one grid cell per workgroup) needs a binary of <= 4096 pixels, PATH_LINKED
+        (one workgroup per walker and 8192-pixel segment) a spectrum of 2..8 segments; AUTO picks by batch size."""
         self.check(self.lib.msx_set_path(self.h, int(path)))
 
     def opt_init(self, theta0):

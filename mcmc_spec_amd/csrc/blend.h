@@ -1,7 +1,7 @@
 // blend.h -- part of the single translation unit msx.hip (included there, in this order).
 // The per-pixel arithmetic of the model vector (A2 blend, A4 scale + sum, A7 reddening, A8.1 resample) as ONE inline
-// function, shared by the fused hot kernel (logprob_kernel.h) and by the walker-tiled blend kernel of the split
-// path (split_kernels.h): both must produce the same bits for a walker, so both call this and nothing else.
+// function, shared by the fused hot kernel (logprob_kernel.h, its linked form included) and by the pair kernel
+// (pair_kernel.h): every form must produce the same bits for a walker, so all of them call this and nothing else.
 #ifndef MSX_BLEND_H
 #define MSX_BLEND_H
 
@@ -11,7 +11,7 @@ namespace {
 // "nearest node first" (mft6.py:439-477, 508-511) with a lerp-of-lerps formula; here the blend is a weighted sum
 // of the four rows and its summation order is a convention of this library.  Sorting by node index makes the
 // order a function of the walker's GRID CELL alone (not of which corner happens to be nearest), so that all the
-// walkers of a cell read the same rows in the same order -- what the walker-tiled kernel shares loads on.
+// walkers of a cell read the same rows in the same order -- what the pair kernel shares loads on.
 // Duplicated nodes (Teff or logg exactly on a node) carry weight 0 on one copy; the sum is the same either way.
 __device__ __forceinline__ void sort4_by_node(int (&node)[4], double (&w)[4]) {
 #define MSX_CSWAP(a, b)                                                             \

@@ -329,6 +329,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // linked: the data flux of this workgroup's segment behind its model values, indexed by the element's own number
     double2 *const lds_lf2 = LK ? reinterpret_cast<double2 *>(reinterpret_cast<double *>(dyn_lds) + 2 * kSegElems) - myseg * kSegElems : nullptr;
 
+    MED_WALL(5);
     MSX_STAMP(P, wk, 0);
     MSX_STAMP(P, wk, 8);
     const double *th_row = theta + wk * ndim;
@@ -652,9 +653,6 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 float2 hh[G];
 #pragma unroll
                 for (int c = 0; c < G; ++c) {
-#ifdef MSX_EXP_HALFROWS  // measurement build only (wrong values): the second star re-uses the first star's loads
-                    if (c0 + c >= 4) { rr[c] = rr[(c0 + c - 4) % G]; hh[c] = hh[(c0 + c - 4) % G]; continue; }
-#endif
                     rr[c] = ld_off(rows_r[c0 + c], o16);
                     hh[c] = RED ? ld_off(rows_h[c0 + c], o8) : make_float2(0.f, 0.f);
                 }
@@ -1038,6 +1036,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         }
         walker_done(V, D, wk, ndim, out, MSX_W_OK, logp, status);
         MSX_STAMP(P, wk, 15);
+        MED_WALL(7);
     }
 }
 

@@ -106,8 +106,11 @@ __device__ __forceinline__ unsigned long long radix_select(const double *model, 
 #ifdef MSX_STAMPS
 __device__ unsigned long long g_med_stamps[65536 * 8];
 #define MED_STAMP(i) do { if (threadIdx.x == 0) g_med_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+// (slots 5 and 7: the 100 MHz wall clock at the walker's first and last stamp -- shader cycles / wall ticks = the clock the CU ran at)
+#define MED_WALL(i) do { if (threadIdx.x == 0) g_med_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define MED_STAMP(i) do { } while (0)
+#define MED_WALL(i) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------

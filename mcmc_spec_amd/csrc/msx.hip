@@ -16,7 +16,7 @@
 // Layout of the translation unit (device code in headers, included below in this order):
 //   dev_types.h        constants, DevProblem (by-value kernel argument), WalkerDesc (LDS)
 //   wave_ops.h         DPP reductions / scans, order-preserving keys
-//   blend.h            the per-pixel model arithmetic shared by the fused and the walker-tiled kernels
+//   blend.h            the per-pixel model arithmetic shared by the fused, linked and pair forms
 //   recipe.h           phase 0: gates, isochrone, brackets, weights, prior and band terms
 //   median.h           exact median selects (block_median, logbin_median, radix fallback)
 //   logprob_kernel.h   the hot kernel and its variants (fused; linked = several workgroups per walker in one launch)
@@ -273,9 +273,15 @@ int launch_conv(msx_ctx *c, const double *d_in, int64_t in_stride, double *d_tmp
 
 // A synchronous entry point has seen the walkers' statuses: MSX_W_HANDOVER anywhere means the linked form's flags are
 // no longer trustworthy on this context (the device-side poison word says the same to every later linked launch).
+// (The pair form's bounded wait -- a spill row's lease never granted -- reports the same status: the launch is over when a
+// synchronous entry point reads it, nobody holds a row, so the leases are cleared for the launches that follow.)
 void note_handover(msx_ctx *c, const int32_t *status, int64_t n) {
     for (int64_t i = 0; i < n; ++i)
-        if (status[i] == MSX_W_HANDOVER) { c->linked_poisoned = true; return; }
+        if (status[i] == MSX_W_HANDOVER) {
+            c->linked_poisoned = true;
+            if (c->d_pair_plan) (void)hipMemsetAsync(c->d_pair_plan + kPairHdrInts, 0, sizeof(int32_t) * kPairSpillRows, c->stream);
+            return;
+        }
 }
 
 int pick_block(const msx_ctx *c, int64_t n, int64_t npix) {
@@ -1776,6 +1782,14 @@ int msx_test_hook(msx_ctx *c, int32_t what, int32_t value) {
     if (what == MSX_HOOK_LINKED_FAULT) {
         if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_test_hook: no problem staged");
         c->P.linked_fault = value != 0;
+        return MSX_OK;
+    }
+    if (what == MSX_HOOK_PAIR_LEASES) {
+        if (!c->problem_staged || !c->d_pair_plan) return fail(c, MSX_ERR_STATE, "msx_test_hook: the staged problem has no pair form");
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipDeviceSynchronize());
+        std::vector<int32_t> v((size_t)kPairSpillRows, value != 0 ? 1 : 0);
+        HIP_TRY(c, hipMemcpy(c->d_pair_plan + kPairHdrInts, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
         return MSX_OK;
     }
     return fail(c, MSX_ERR_INVALID, "msx_test_hook: unknown hook");

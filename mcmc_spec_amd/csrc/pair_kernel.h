@@ -27,11 +27,6 @@
 // the same workgroup.
 #ifndef MSX_PAIR_KERNEL_H
 #define MSX_PAIR_KERNEL_H
-// MSX_PAIR_EXP (measurement builds only, WRONG VALUES): bit 0 skips the fit sweep, bit 1 the chi^2 / candidates
-// sweep, bit 2 the reddening factor, bit 3 the histogram's atomics -- where a pair workgroup's time goes
-#ifndef MSX_PAIR_EXP
-#define MSX_PAIR_EXP 0
-#endif
 
 namespace {
 
@@ -165,7 +160,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
                     const unsigned int fx = (unsigned int)__double2hiint(mm[u]) >> 12;
                     fmin[s] = fx < fmin[s] ? fx : fmin[s];
                     fmax[s] = fx > fmax[s] ? fx : fmax[s];
-                    if (!(MSX_PAIR_EXP & 8)) atomicAdd(&S[s].hist[fx & (unsigned int)(kLogBins - 1)], 1u);
+                    atomicAdd(&S[s].hist[fx & (unsigned int)(kLogBins - 1)], 1u);
                 }
             }
         };
@@ -205,7 +200,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
                     }
                 }
                 double2 m0, m1 = make_double2(0.0, 0.0);
-                constexpr bool kFin = RED && !(MSX_PAIR_EXP & 4);
+                constexpr bool kFin = RED;
                 m0.x = blend_finish(sra[0], sha[0], kl2.x, (double)dk2.x, redcA, kFin && reddenA, e2tab);
                 m0.y = blend_finish(srb[0], shb[0], kl2.y, (double)dk2.y, redcA, kFin && reddenA, e2tab);
                 if (two) {
@@ -240,7 +235,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             if (two) finish_elem(std::integral_constant<int, 1>{}, j_c, m[1][j], f2v, u2v, ec, live);
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (!(MSX_PAIR_EXP & 1)) static_for<0, NT>(fit_trip);
+        static_for<0, NT>(fit_trip);
 
         // ---- the fit sums (canonical sum), running totals of the histograms, value ranges --------------------------
         static_for<0, NSLOT>([&](auto s_c) __attribute__((always_inline)) {
@@ -347,13 +342,14 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             });
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (!(MSX_PAIR_EXP & 2)) static_for<0, NT>(pass_trip);
+        static_for<0, NT>(pass_trip);
         red[0][0][wave][lane] = lane_partial<vk>(acc[0]);
         if (two) red[1][0][wave][lane] = lane_partial<vk>(acc[1]);
         __syncthreads();
 
         // ---- rank: wave s ranks walker s's candidates ------------------------------------------------------------------
         double med[2] = {0.0, 0.0};
+        bool lost[2] = {false, false};  // the spill path's lease was not granted in time
         if (appl[0]) med[0] = logbin_rank<MAXT>(S[0], Q[0], need_two, 0);
         if (two && appl[1]) med[1] = logbin_rank<MAXT>(S[1], Q[1], need_two, 1);
         // vectors the early histogram cannot handle (not positive, >= 8 binades, > 256 equal-bin candidates): the
@@ -398,11 +394,22 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             // A scratch row on LEASE: kPairSpillRows rows serve every launch (a row per walker of a 16,384-walker batch
             // would be 512 MB for a path that real spectra never take).  The workgroup takes row (block mod rows) and
             // waits while an earlier workgroup still holds it -- that one's progress does not depend on this one.
+            // The wait is BOUNDED like every other in-kernel wait (kHandoverTicks of the wall clock): a lease word left at 1
+            // by a launch torn down mid-spill must end as a status, not as a hung GPU.  On expiry the walker fails with
+            // MSX_W_HANDOVER; the synchronous entry points clear the leases when they see it (msx.hip, note_handover).
             const int lease = (int)(blockIdx.x % (unsigned int)kPairSpillRows);
             if (tid == 0) {
-                while (atomicCAS(P.pair_lease + lease, 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
+                const unsigned long long t0 = wall_clock64();
+                bool got = false;
+                for (;;) {
+                    if (atomicCAS(P.pair_lease + lease, 0, 1) == 0) { got = true; break; }
+                    if (wall_clock64() - t0 > kHandoverTicks) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                S[s].meet_state = got ? 1u : 0u;
             }
             __syncthreads();
+            if (S[s].meet_state == 0u) { lost[s] = true; return; }  // (uniform)
             double *row = P.model_scratch + (int64_t)lease * npix;
             auto spill = [&](auto j_c) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_c)::value;
@@ -439,8 +446,8 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
                     const double total = fused_total(P, tot, P.median_flux, med[s], npix, Dw.chi_extra);
                     out = value_of_total(mode, total, Dw.lp);
                 }
-                logp[wk] = out;
-                status[wk] = MSX_W_OK;
+                logp[wk] = lost[s] ? nan_with_status(MSX_W_HANDOVER) : out;
+                status[wk] = lost[s] ? MSX_W_HANDOVER : MSX_W_OK;
             }
         });
     };
@@ -569,10 +576,6 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
             tag = (h >> 24) | 1ull;  // 40 bits, never zero
         }
     }
-#if defined(MSX_PLAN_EXP) && MSX_PLAN_EXP == 1
-    if (tag == 12345ull) plan[7] = 1;
-    return;
-#endif
     // ---- 1. partners inside the wave ----------------------------------------------------------------------------------
     int partner_lane;
     bool leftover;
@@ -597,9 +600,6 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         (void)bases;
     }
     __syncthreads();
-#if defined(MSX_PLAN_EXP) && MSX_PLAN_EXP == 2
-    return;
-#endif
     // ---- 2. the waves' leftovers meet inside the workgroup: the same ballots over the card list, 64 cards per wave, in
     //      rounds (128 cards -> at most one per cell and wave -> one wave -> at most one per cell) -------------------------
     int nc = s_nc;

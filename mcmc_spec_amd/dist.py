@@ -93,8 +93,10 @@ class ShardedLogProb:
         codes = _codes_of(out).reshape(self.world, m).max(axis=1)
         if codes.any():
             first = int(np.nonzero(codes)[0][0])           # the lowest failing rank decides, on every rank
-            if first == self.rank:
+            if first == self.rank and err is not None:
                 raise err
+            # (a local evaluator may also RETURN a tagged NaN without raising -- the device path's own values do: then this
+            # rank builds the class from the code like every other rank)
             c = int(codes[first])
             cls = _ERR_CODES[c - 1] if c <= len(_ERR_CODES) else RuntimeError
             raise cls('walker evaluation failed on rank {} ({}); raised on every rank'.format(first, cls.__name__))

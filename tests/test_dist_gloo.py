@@ -116,6 +116,23 @@ def _worker_errors(rank, world, port, q):
     log.append(('after', f(coords).tolist()))      # the group is still usable: nobody is stuck in a collective
     log.append(('collectives', ncoll[0]))          # ONE per evaluation, failing or not: the error class rides in the NaN
 
+    # (1b) an evaluator that RETURNS the device path's tagged NaN (payload 2 = IndexError in ShardedLogProb's own numbering) without raising, on rank 0:
+    # rank 0 too must raise IndexError (it used to `raise None`)
+    from mcmc_spec_amd.dist import _nan_with_code
+
+    def tagging_eval(block):
+        out = block.sum(axis=1)
+        if rank == 0:
+            out[0] = _nan_with_code(2)
+        return out
+
+    g = ShardedLogProb(tagging_eval, device='cpu')
+    try:
+        g(coords)
+        log.append(('tagged', 'no exception'))
+    except Exception as e:  # noqa: BLE001 - the class is the assertion
+        log.append(('tagged', type(e).__name__))
+
     # (2) bench.py's graph capture: rank 1 fails to capture; nobody may replay (a replay holds collectives)
     replays = []
 
@@ -164,8 +181,9 @@ def test_world2_one_rank_failing_does_not_deadlock_the_other():
         assert log[1] == ('KeyError', True)            # same exception class on both ranks
         assert log[2] == ('after', want)
         assert log[3] == ('collectives', 3)
-        assert log[4] == ('capture', None, 0)          # nobody replayed
-        assert log[5] == ('capture2', 'graph', 1)
+        assert log[4] == ('tagged', 'IndexError')      # on the rank that produced the NaN and on the other
+        assert log[5] == ('capture', None, 0)          # nobody replayed
+        assert log[6] == ('capture2', 'graph', 1)
 
 
 def _worker_chain(rank, world, port, q):

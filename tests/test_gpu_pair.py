@@ -210,6 +210,18 @@ def test_pair_median_exits(shape):
             many[:, 3] *= 1.0 + 1e-4 * np.arange(len(many))
             outs = forms(eng, eng.loglikelihood, many)
             assert same_bits(outs) and np.all(np.isfinite(outs[0]))
+            # ... and a lease nobody gives back (a launch torn down mid-spill): the wait is bounded -- the spilling walkers
+            # end with MSX_W_HANDOVER (a RuntimeError at this level), not with a hung GPU; the synchronous entry point
+            # that saw the status clears the leases, and the next launch is whole again
+            from mcmc_spec_amd import _lib
+            eng.ctx.set_path(_lib.PATH_PAIR)
+            eng.ctx.test_hook(_lib.HOOK_PAIR_LEASES, 1)
+            few = many[:64]
+            _, st = eng.ctx.logprob_batch(few, _lib.MODE_LOGLIKE)
+            assert np.all(st == _lib.W_HANDOVER)
+            lp2, st2 = eng.ctx.logprob_batch(few, _lib.MODE_LOGLIKE)
+            assert np.all(st2 == _lib.W_OK) and np.array_equal(lp2, outs[0][:64])
+            eng.ctx.set_path(_lib.PATH_AUTO)
 
 
 def test_auto_choice_never_changes_values():

@@ -93,6 +93,16 @@ def main():
         print('    median/candidates: median {} max {}'.format(int(np.median(med[:, 6])), int(med[:, 6].max())))
     fin = (out[:, 15] - out[:, 7]).astype(np.int64)
     print('  closing barrier + combine + store: median {} cycles  (walker total {})'.format(int(np.median(fin)), int(np.median(fin + tot))))
+    # the clock the CUs ran at: shader cycles per tick of the 100 MHz wall clock, first stamp -> last stamp of each walker
+    wall = (med[:, 7] - med[:, 5]).astype(np.int64)
+    ok = wall > 0
+    if ok.any():
+        mhz = (out[ok, 15] - out[ok, 0]).astype(np.float64) / wall[ok] * 100.0
+        print('  shader clock during the walker chain: median {:.0f} MHz (min {:.0f}, max {:.0f}); walker chain {:.2f} us median, {:.2f} us max'.format(
+            float(np.median(mhz)), float(mhz.min()), float(mhz.max()), float(np.median(wall[ok])) / 100.0, float(wall[ok].max()) / 100.0))
+        w0, w1 = med[ok, 5].astype(np.int64), med[ok, 7].astype(np.int64)
+        print('  wall clock, first walker start -> last walker end: {:.2f} us; starts spread over {:.2f} us, ends over {:.2f} us'.format(
+            (w1.max() - w0.min()) / 100.0, (w0.max() - w0.min()) / 100.0, (w1.max() - w1.min()) / 100.0))
     span = int(out[:, 15].max() - out[:, 0].min())
     print('  first start -> last end: {} cycles'.format(span))
 
