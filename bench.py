@@ -279,6 +279,12 @@ def main():
     force_gather = os.environ.get('MSX_BENCH_FORCE_GATHER') == '1'  # measure collective overhead on one GPU
     replicas = args.config == 5                                      # independent problems: no collective at all
     if world > 1 or force_gather:
+        if force_gather and 'RANK' not in os.environ:   # the one-GPU rehearsal outside any launcher: a one-rank group
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+                s_.bind(('127.0.0.1', 0))
+                free_port = s_.getsockname()[1]
+            os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port))
         dist.init_process_group('nccl', device_id=dev)
 
     n = args.walkers

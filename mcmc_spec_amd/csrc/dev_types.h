@@ -150,7 +150,17 @@ struct WalkerDesc {
 // The recipe's small tables, gathered into ONE block so that a single preloaded pointer reaches them all (fixed
 // offsets: the register-resident recipe takes at most 256 isochrone points, 64 Teff x 32 logg nodes; the presence
 // mask is one uint32 per Teff node, bit g = node (t, g) is in the grid).
-constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPresent = 5120, kRecipeBlockBytes = 5376;
+constexpr int kRbIsoT = 0, kRbIsoG = 2048, kRbTeff = 4096, kRbLogg = 4608, kRbPresent = 5120;
+// ... and once more PACKED for the wave form's lanes (load_recipe_regs): what lane l wants of an entry sits side by side,
+// pads included, so that the kernel's prologue is a handful of unconditional 16-byte loads and no arithmetic --
+//   kRbIsoPack   [256] {x_i, x_i+1 (+inf past the end), y_i, slope_i = (y_i+1 - y_i) / (x_i+1 - x_i) (0 for the last entry)}
+//                      (entries >= niso: {+inf, +inf, 0, 0}; the slope is formed on the host, IEEE division like the
+//                      device's `/`: the same bits as the planner's one-thread form computes for itself)
+//   kRbTeffPack  [64] {node_l, node_l+1} (+inf pads)      kRbLoggPack [64] likewise
+//   kRbMaskPack  [64] {presence bits of Teff node l, of node l + 1} (0 pads)
+constexpr int kRbIsoPack = 5376, kRbTeffPack = kRbIsoPack + 256 * 32, kRbLoggPack = kRbTeffPack + 64 * 16,
+              kRbMaskPack = kRbLoggPack + 64 * 16, kRecipeBlockBytes = kRbMaskPack + 64 * 8;
+static_assert(kRbIsoPack % 16 == 0 && kRecipeBlockBytes == 16128, "recipe block layout");
 constexpr int kSegElems = 4096;     // table elements (= 8192 pixels) per segment of the canonical sum / of the linked form
 constexpr int kSegBins = 2048;      // (= kLogBins, median.h)
 constexpr unsigned long long kHandoverTicks = 2000000ull;  // in-kernel waits (the linked form's meetings, the overlapped sampler's versions) give up after 20 ms of the 100 MHz wall clock

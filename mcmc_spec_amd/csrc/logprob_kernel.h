@@ -292,6 +292,16 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
 #ifdef MSX_STAMPS
     if (threadIdx.x == 0) msx_stamp_off = LK && myseg != ((MSX_STAMPS == 2) ? 0 : nsegs - 1);  // (one workgroup's stamps per walker)
 #endif
+    // theta FIRST: the kernel's first vector load, requested before the recipe's tables (whose consumers -- the uniform
+    // first / last entries below -- wait for them): the walker's critical chain starts when theta arrives, and a load
+    // issued behind those waits would only leave then (rounds 1-3 did that: ~0.9 k cycles of the chain).  Lane k takes
+    // coordinate k (one VECTOR load: a scalar load would share its counter with the kernel-argument fetches below and be
+    // waited for together with them).  The sampler builds its proposal below instead -- from its record, requested here.
+    double theta_lane = 0.0;
+    if (fast && !smp_on && (threadIdx.x >> 6) < NS && (threadIdx.x & 63) < 2 * NS + 2 && wk < n)
+        theta_lane = theta[wk * (2 * NS + 2) + (threadIdx.x & 63)];
+    SmpRec rc = {0, 0, 0.0, 0u, 0u};
+    if (smp_on && wk < n) rc = smp_rec[wk];
     RecipeRegs RR;
     if (fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
@@ -307,13 +317,6 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             return;
         }
     }
-    // theta, requested before anything that waits for the kernel-argument segment (the recipe waves; the sampler
-    // builds its proposal below instead)
-    // (one VECTOR load, lane k takes coordinate k: a scalar load would share its counter with the kernel-argument
-    // fetches below and be waited for together with them)
-    double theta_lane = 0.0;
-    if (fast && !smp_on && (threadIdx.x >> 6) < NS && (threadIdx.x & 63) < ndim)
-        theta_lane = theta[wk * ndim + (threadIdx.x & 63)];
     // [npix]; linked: LDS holds this workgroup's segment only, indexed by the pixel's own number all the same
     double *model = GM ? P.model_scratch + wk * P.npix : reinterpret_cast<double *>(dyn_lds) - (LK ? myseg * (2 * kSegElems) : 0);
     const int tid = threadIdx.x;
@@ -348,7 +351,6 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // forms the proposal itself, lane k coordinate k, straight into the register the recipe reads: no LDS round
         // trip, no barrier.  Wave 0 also leaves it in LDS for the phases after phase 0; a non-recipe wave meanwhile
         // fetches what the accept step will need at the very end.
-        const SmpRec rc = smp_rec[wk];
         // Overlapped half-steps: this workgroup may have been dispatched while the half-step(s) before it are still
         // running.  Every wave that reads the ensemble -- the recipe waves (both rows) and the wave that fetches the
         // accept step's inputs (the walker's own entries) -- first waits until the walkers it reads have reached the

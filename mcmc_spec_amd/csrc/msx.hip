@@ -70,7 +70,7 @@ struct msx_ctx {
     // grid
     int64_t nwl = 0;
     int nt = 0, ng = 0;
-    std::vector<double> h_wl;
+    std::vector<double> h_wl, h_teff, h_logg;  // host copies of the wavelength axis and the node lists
     double *d_grid = nullptr, *d_wl = nullptr, *d_kgrid = nullptr, *d_teff = nullptr, *d_logg = nullptr;
     uint8_t *d_present = nullptr;
     bool grid_staged = false;
@@ -549,6 +549,8 @@ int msx_stage_grid(msx_ctx *c, const double *wl, int64_t nwl, const double *teff
     const int64_t nn = (int64_t)nt * ng;
     c->nwl = nwl; c->nt = nt; c->ng = ng;
     c->h_wl.assign(wl, wl + nwl);
+    c->h_teff.assign(teff_nodes, teff_nodes + nt);
+    c->h_logg.assign(logg_nodes, logg_nodes + ng);
     HIP_TRY(c, hipMalloc((void **)&c->d_grid, sizeof(double) * nn * nwl));
     HIP_TRY(c, hipMemcpy(c->d_grid, flux, sizeof(double) * nn * nwl, hipMemcpyHostToDevice));
     int rc;
@@ -842,6 +844,30 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
                 if (pres[(size_t)(t * P.ng + g)]) pmask[(size_t)t] |= 1u << g;
         HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbPresent, pmask.data(), sizeof(uint32_t) * pmask.size(),
                                   hipMemcpyHostToDevice, c->stream));
+        // the packed copies for the wave form's lanes (dev_types.h): entry + right neighbour, slopes, pads
+        std::vector<unsigned char> pack((size_t)(kRecipeBlockBytes - kRbIsoPack), 0);
+        {
+            double *iso = reinterpret_cast<double *>(pack.data());
+            for (int i = 0; i < 4 * kWave; ++i) {
+                const bool in = i < P.niso, nx = i + 1 < P.niso;
+                const double x = in ? p->iso_teff[i] : INFINITY, y = in ? p->iso_logg[i] : 0.0;
+                const double xn = nx ? p->iso_teff[i + 1] : INFINITY, yn = nx ? p->iso_logg[i + 1] : 0.0;
+                iso[4 * i] = x; iso[4 * i + 1] = xn; iso[4 * i + 2] = y;
+                iso[4 * i + 3] = nx ? (yn - y) / (xn - x) : 0.0;  // np.interp's slope (IEEE division, like the device's)
+            }
+            double *tp = reinterpret_cast<double *>(pack.data() + (kRbTeffPack - kRbIsoPack));
+            double *gp = reinterpret_cast<double *>(pack.data() + (kRbLoggPack - kRbIsoPack));
+            uint32_t *mp = reinterpret_cast<uint32_t *>(pack.data() + (kRbMaskPack - kRbIsoPack));
+            for (int l = 0; l < kWave; ++l) {
+                tp[2 * l] = l < P.nt ? c->h_teff[(size_t)l] : INFINITY;
+                tp[2 * l + 1] = l + 1 < P.nt ? c->h_teff[(size_t)l + 1] : INFINITY;
+                gp[2 * l] = l < P.ng ? c->h_logg[(size_t)l] : INFINITY;
+                gp[2 * l + 1] = l + 1 < P.ng ? c->h_logg[(size_t)l + 1] : INFINITY;
+                mp[2 * l] = l < P.nt ? pmask[(size_t)l] : 0u;
+                mp[2 * l + 1] = l + 1 < P.nt ? pmask[(size_t)l + 1] : 0u;
+            }
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_recipe_block + kRbIsoPack, pack.data(), pack.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     // Scratch, sized once here so that no launch ever allocates or synchronises -- and only for the forms the staged

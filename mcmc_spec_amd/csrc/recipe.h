@@ -449,31 +449,22 @@ struct RecipeRegs {
 };
 __device__ __forceinline__ void load_recipe_regs(RecipeRegs &R, const unsigned char *__restrict__ rblk, int niso, int nt, int ng,
                                                  int lane) {
-    const double *__restrict__ iso_t = reinterpret_cast<const double *>(rblk + kRbIsoT);
-    const double *__restrict__ iso_g = reinterpret_cast<const double *>(rblk + kRbIsoG);
-    const double *__restrict__ teff_nodes = reinterpret_cast<const double *>(rblk + kRbTeff);
-    const double *__restrict__ logg_nodes = reinterpret_cast<const double *>(rblk + kRbLogg);
-    const unsigned int *__restrict__ pmask = reinterpret_cast<const unsigned int *>(rblk + kRbPresent);
-    double yn[4];
+    // the PACKED copies of the tables (dev_types.h, kRb*Pack; built by msx_stage_problem): every lane's entry with its right
+    // neighbour, the isochrone's slopes and all pads ready-made -- eleven unconditional loads, nothing to compute, so the
+    // recipe's chain starts the moment theta (requested BEFORE these, logprob_kernel) arrives
+    const double4 *__restrict__ iso = reinterpret_cast<const double4 *>(rblk + kRbIsoPack);
+    const double2 *__restrict__ tp = reinterpret_cast<const double2 *>(rblk + kRbTeffPack);
+    const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(rblk + kRbLoggPack);
+    const uint2 *__restrict__ mp = reinterpret_cast<const uint2 *>(rblk + kRbMaskPack);
+    double4 e[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + kWave * k;
-        R.isot[k] = i < niso ? iso_t[i] : INFINITY;
-        R.isog[k] = i < niso ? iso_g[i] : 0.0;
-        R.isot_n[k] = i + 1 < niso ? iso_t[i + 1] : INFINITY;
-        yn[k] = i + 1 < niso ? iso_g[i + 1] : 0.0;
-    }
-    R.tn = lane < nt ? teff_nodes[lane] : INFINITY;
-    R.tn_n = lane + 1 < nt ? teff_nodes[lane + 1] : INFINITY;
-    R.gn = lane < ng ? logg_nodes[lane] : INFINITY;
-    R.gn_n = lane + 1 < ng ? logg_nodes[lane + 1] : INFINITY;
-    R.m0 = lane < nt ? pmask[lane] : 0u;
-    R.m1 = lane + 1 < nt ? pmask[lane + 1] : 0u;
+    for (int k = 0; k < 4; ++k) e[k] = iso[lane + kWave * k];
+    const double2 t2 = tp[lane], g2 = gp[lane];
+    const uint2 m2 = mp[lane];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + kWave * k;
-        R.slope[k] = i + 1 < niso ? (yn[k] - R.isog[k]) / (R.isot_n[k] - R.isot[k]) : 0.0;  // np.interp's slope
-    }
+    for (int k = 0; k < 4; ++k) { R.isot[k] = e[k].x; R.isot_n[k] = e[k].y; R.isog[k] = e[k].z; R.slope[k] = e[k].w; }
+    R.tn = t2.x; R.tn_n = t2.y; R.gn = g2.x; R.gn_n = g2.y;
+    R.m0 = m2.x; R.m1 = m2.y;
     R.iso_lo = pick4(R.isot, 0);
     R.iso_hi = pick4(R.isot, niso - 1);
     R.t_first = readlane_f64(R.tn, 0);
