@@ -342,14 +342,21 @@ def main():
         if fn(*(table or calls)[i % nprob][i % nbatch][i & 1]) != 0:
             raise RuntimeError(eng.ctx.lib.msx_last_error(engines[i % nprob].ctx.h).decode())
 
-    # The collective: one RCCL all-gather of n float64 per rank per step through torch.distributed (c10d ->
-    # RCCL over xGMI).  (The library's own communicator, msx_comm_*, measured slower per step on one GPU and is
-    # opt-in: MSX_BENCH_COLLECTIVE=rccl.)
+    # The collective: ONE RCCL all-gather of n float64 per rank per step.  Two routes to the same RCCL:
+    #   msx_comm (default)  the library's own communicator (msx_comm_init: ncclCommInitRank from the copy of RCCL torch has
+    #                       mapped; id broadcast through torch.distributed), ncclAllGather on the communicator's own stream,
+    #                       forked from / joined to the launch stream by events -- plain HIP + RCCL calls, so the step loop
+    #                       (kernel -> all-gather, double-buffered) can be captured into a hipGraph;
+    #   torch.distributed   (MSX_BENCH_COLLECTIVE=torch, or when the communicator cannot be built) c10d's
+    #                       all_gather_into_tensor, EAGER ONLY: c10d's watchdog thread polls the events of the works it
+    #                       tracks, and a work recorded while a stream captures makes that poll abort the process ("operation
+    #                       not permitted on an event last recorded in a capturing stream" -- seen here under
+    #                       torch.distributed.run on the one-GPU rehearsal, intermittently).  Never captured.
     collective = 'none'
     h = eng.ctx.h
     if use_gather:
-        collective = 'torch.distributed'
-        if os.environ.get('MSX_BENCH_COLLECTIVE', 'torch') == 'rccl':
+        collective = 'torch.distributed (eager)'
+        if os.environ.get('MSX_BENCH_COLLECTIVE', 'rccl') == 'rccl':
             try:
                 idt = torch.zeros(128, dtype=torch.uint8, device=dev)
                 if rank == 0:
@@ -363,22 +370,19 @@ def main():
         ok_t = torch.tensor([1 if collective.startswith('msx_comm') else 0], device=dev)
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)  # every rank must agree on the path
         if int(ok_t.item()) == 0:
-            collective = 'torch.distributed'
+            collective = 'torch.distributed (eager)'
     direct = collective.startswith('msx_comm')
     ag = eng.ctx.lib.msx_comm_allgather_dev
     wt = eng.ctx.lib.msx_comm_wait_slot
     pending = [False, False]
-    if direct:
-        ag_calls = [(h, C.c_void_p(logp[b].data_ptr()), C.c_void_p(gathered[b].data_ptr()), n, C.c_void_p(sptr), b)
-                    for b in range(2)]
 
-    def gather(i):
+    def gather(i, sp=sptr):
         b = i & 1
         if direct:
-            if ag(*ag_calls[b]) != 0:
+            if ag(h, C.c_void_p(logp[b].data_ptr()), C.c_void_p(gathered[b].data_ptr()), n, C.c_void_p(sp), b) != 0:
                 raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
             if args.no_overlap:
-                wt(h, b, C.c_void_p(sptr))
+                wt(h, b, C.c_void_p(sp))
             else:
                 pending[b] = True
             return
@@ -388,20 +392,20 @@ def main():
         else:
             works[b] = w
 
-    def reuse_guard(i):
+    def reuse_guard(i, sp=sptr):
         b = i & 1
         if direct:
             if pending[b]:  # stream-level wait (no host block): step i-2's all-gather read logp[b]
-                wt(h, b, C.c_void_p(sptr))
+                wt(h, b, C.c_void_p(sp))
                 pending[b] = False
         elif works[b] is not None:
             works[b].wait()
             works[b] = None
 
-    def drain():
+    def drain(sp=sptr):
         for b in range(2):
             if direct and pending[b]:
-                wt(h, b, C.c_void_p(sptr))
+                wt(h, b, C.c_void_p(sp))
                 pending[b] = False
             if works[b] is not None:
                 works[b].wait()
@@ -485,7 +489,8 @@ def main():
     # The captured run covers as much of the timed region as possible: one replay costs the host ~10-16 us (the
     # guide's graph-replay floor), which a 20-step run (what the driver times) would otherwise pay several times.
     # Step i of a replay uses problem i mod nprob, theta batch i mod nbatch, output buffer i mod 2: any even chunk.
-    if want_graph and not direct and args.steps >= 4:
+    # (with a collective in the loop only the direct-RCCL route is captured: see above)
+    if want_graph and (direct or not use_gather) and args.steps >= 4:
         # (kernel-only runs: the first four steps go out as plain launches, so that the GPU is already busy while the
         # host prepares the graph launch -- 25-40 us that a 20-step run would otherwise spend with the GPU idle; same-box
         # means of three 20-step runs: 19.7 us per step with none, 19.1 with two, 18.5 with four, 18.4-18.6 with 8 / 12)
@@ -501,13 +506,14 @@ def main():
             g_ = torch.cuda.CUDAGraph()
             # thread_local: calls made by other threads (c10d's watchdog) must not invalidate the capture
             with torch.cuda.graph(g_, stream=torch.cuda.Stream(dev), capture_error_mode='thread_local'):
-                tab = calls_for(torch.cuda.current_stream(dev).cuda_stream)
+                cs = torch.cuda.current_stream(dev).cuda_stream
+                tab = calls_for(cs)
                 for i in range(chunk):
-                    reuse_guard(i)
+                    reuse_guard(i, cs)
                     launch(i, tab)
                     if use_gather:
-                        gather(i)
-                drain()
+                        gather(i, cs)
+                drain(cs)   # (every fork of the capture -- the communicator's stream -- is joined again)
             return g_
 
         def do_replay(g_):
