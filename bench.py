@@ -375,19 +375,20 @@ def main():
     ag = eng.ctx.lib.msx_comm_allgather_dev
     wt = eng.ctx.lib.msx_comm_wait_slot
     pending = [False, False]
+    overlap = not args.no_overlap   # the all-gather of step i next to the kernel of step i + 1 (else: one dependent chain)
 
     def gather(i, sp=sptr):
         b = i & 1
         if direct:
             if ag(h, C.c_void_p(logp[b].data_ptr()), C.c_void_p(gathered[b].data_ptr()), n, C.c_void_p(sp), b) != 0:
                 raise RuntimeError(eng.ctx.lib.msx_last_error(h).decode())
-            if args.no_overlap:
+            if not overlap:
                 wt(h, b, C.c_void_p(sp))
             else:
                 pending[b] = True
             return
         w = dist.all_gather_into_tensor(gathered[b], logp[b], async_op=True)
-        if args.no_overlap:
+        if not overlap:
             w.wait()
         else:
             works[b] = w
@@ -417,23 +418,84 @@ def main():
     # launches); the default 200-step run is long enough not to care, the driver's 20-step run is not.
     # (issued right before the timed region, after the graph capture: capturing leaves the GPU idle for milliseconds)
     ramp = int(os.environ.get('MSX_BENCH_RAMP', '1500'))
-    # N > 1, which variant next to the collective?  The N = 1 variant needs every CU for itself (123 KB of LDS each): if
-    # RCCL's kernel cannot share a CU with it, a displaced walker costs a second round; the <= 128-VGPR variant leaves
-    # room but is the slower kernel (it has no LDS for the staged pixel vectors: DESIGN.md section 4).  Whether RCCL's
-    # kernel fits beside a workgroup cannot be known from here, so both are timed -- 40 steps each of the very loop that
-    # follows, collective included -- and the ranks agree on the one whose SLOWEST rank is faster.  Setup, untimed.
+    # The step is launch-bound on the host next to a ~15 us kernel, so a run of `chunk` steps (kernel -> all-gather,
+    # double-buffered exactly as above) is captured into one hipGraph and replayed; the timed region still executes
+    # exactly K steps (K // chunk replays, the remainder eagerly).  Capture only is inside the try: the ranks FIRST agree
+    # whether every one of them captured, and only then does anybody replay (a replay holds `chunk` collectives: a rank
+    # that failed to capture must not meet it with an all-reduce).  MSX_BENCH_GRAPH=0 gives the eager loop;
+    # MSX_BENCH_FAIL_CAPTURE_RANK=r makes rank r fail on purpose; the ordering itself is
+    # mcmc_spec_amd.benchutil.capture_agreed (tests/test_dist_gloo.py).
+    # The captured run covers as much of the timed region as possible: one replay costs the host ~10-16 us (the
+    # guide's graph-replay floor), which a 20-step run (what the driver times) would otherwise pay several times.
+    # Step i of a replay uses problem i mod nprob, theta batch i mod nbatch, output buffer i mod 2: any even chunk.
+    # (with a collective in the loop only the direct-RCCL route is captured: see above)
+    graph, chunk, head = None, 0, 0
+    want_graph = os.environ.get('MSX_BENCH_GRAPH', '1') == '1'
+    can_graph = want_graph and (direct or not use_gather) and args.steps >= 4
+    from mcmc_spec_amd.benchutil import capture_agreed
+    if can_graph:
+        # (kernel-only runs: the first four steps go out as plain launches, so that the GPU is already busy while the
+        # host prepares the graph launch -- 25-40 us that a 20-step run would otherwise spend with the GPU idle; same-box
+        # 20-step runs this round: 15.4-16.0 us per step with four, 16.2-16.9 with none, 16.4-16.6 all eager)
+        head = int(os.environ.get('MSX_BENCH_HEAD', '4')) if (not use_gather and args.steps >= 8 and os.environ.get('MSX_BENCH_NO_HEAD') != '1') else 0
+        head = max(0, min(head, args.steps - 4))
+        chunk = min(args.steps - head, int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '200'))) // 2 * 2
+
+    def do_capture():
+        if os.environ.get('MSX_BENCH_FAIL_CAPTURE_RANK') == str(rank):
+            raise RuntimeError('capture failure requested for this rank')
+        torch.cuda.synchronize(dev)
+        g_ = torch.cuda.CUDAGraph()
+        # thread_local: calls made by other threads (c10d's watchdog) must not invalidate the capture
+        with torch.cuda.graph(g_, stream=torch.cuda.Stream(dev), capture_error_mode='thread_local'):
+            cs = torch.cuda.current_stream(dev).cuda_stream
+            tab = calls_for(cs)
+            for i in range(chunk):
+                reuse_guard(i, cs)
+                launch(i, tab)
+                if use_gather:
+                    gather(i, cs)
+            drain(cs)   # (every fork of the capture -- the communicator's stream -- is joined again)
+        return g_
+
+    def do_replay(g_):
+        g_.replay()
+        torch.cuda.synchronize(dev)
+
+    def all_min(flag):
+        if not (world > 1 or force_gather):
+            return flag
+        ok_t = torch.tensor([flag], device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        return int(ok_t.item())
+
+    # N > 1: which kernel variant next to the collective, and the collective NEXT TO the following launch or BEHIND it?
+    #  * The N = 1 variant needs every CU for itself (123 KB of LDS each): if RCCL's kernel cannot share a CU with it, a
+    #    displaced walker costs a second round; the <= 128-VGPR variant leaves room but is the slower kernel (no LDS for the
+    #    staged pixel vectors: DESIGN.md section 4).
+    #  * Overlapping the all-gather of step i with the launch of step i + 1 hides the collective's latency -- unless its
+    #    kernel displaces a walker (one-GPU rehearsal, one-rank communicator: 23.5 us per step overlapped, 16.6 as one
+    #    dependent chain kernel -> all-gather -> kernel; across eight GPUs the collective takes longer and the balance
+    #    may tip the other way).
+    # Neither can be known from here, so the candidates are TIMED during set-up -- each as the very loop that follows
+    # (its hipGraph where the loop is captured, two replays; else 40 eager steps), collective included -- and the ranks
+    # agree on the one whose SLOWEST rank is fastest.  A candidate with a walker error status on any rank is out whatever
+    # its time: a launch that fails is the fastest one (a timed-out linked form returns MSX_W_HANDOVER after one load).
     block_tuned = None
     if use_gather and not args.block and os.environ.get('MSX_BENCH_TUNE_BLOCK', '1') == '1':
-        # (long spectra: the same question for the LINKED form, whose workgroups fill every CU and wait for each other,
-        # against the fused kernel, which leaves half the CUs free)
         if args.npix < 8192:
-            cands = [('shared (<= 128 VGPRs, two per CU)', _lib.BLOCK_512_SHARED, _lib.PATH_AUTO),
-                     ('own CU (pixel vectors staged in LDS)', 0, _lib.PATH_AUTO)]
-        else:
-            cands = [('fused (one workgroup per walker)', 0, _lib.PATH_FUSED), ('automatic (linked while walkers x segments <= #CUs)', 0, _lib.PATH_AUTO)]
-        tms, errs = [], []
-        for _, cb, cpath in cands:
-            block = cb
+            cands = [('own CU (pixel vectors staged in LDS), all-gather behind the launch', 0, _lib.PATH_AUTO, False),
+                     ('own CU (pixel vectors staged in LDS), all-gather next to the following launch', 0, _lib.PATH_AUTO, True),
+                     ('shared (<= 128 VGPRs, two per CU), all-gather next to the following launch', _lib.BLOCK_512_SHARED, _lib.PATH_AUTO, True)]
+        else:  # (long spectra: the LINKED form's workgroups fill every CU and wait for each other; the fused kernel leaves half the CUs free)
+            cands = [('automatic (linked while walkers x segments <= #CUs), all-gather behind the launch', 0, _lib.PATH_AUTO, False),
+                     ('automatic (linked while walkers x segments <= #CUs), all-gather next to the following launch', 0, _lib.PATH_AUTO, True),
+                     ('fused (one workgroup per walker), all-gather next to the following launch', 0, _lib.PATH_FUSED, True)]
+        if args.no_overlap:
+            cands = [c_ for c_ in cands if not c_[3]]
+        tms, errs, graphs = [], [], []
+        for _, cb, cpath, cov in cands:
+            block, overlap = cb, cov
             for e in engines:
                 e.ctx.set_path(cpath)
             calls = calls_for(sptr)
@@ -443,93 +505,57 @@ def main():
                 gather(i)
             drain()
             torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for i in range(40):
-                reuse_guard(i)
-                launch(i)
-                gather(i)
-            drain()
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            tms.append(e0.elapsed_time(e1) * 1e3 / 40)
-            # a launch that FAILS is the fastest one (a timed-out linked form returns MSX_W_HANDOVER for every walker after
-            # one load): a candidate with any walker error status on any rank is out, whatever its time
-            errs.append(float((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item()))
             for b_ in range(2):
                 status[b_].zero_()
+            g_c = capture_agreed(do_capture, do_replay, all_min, rank) if can_graph else None
+            if can_graph and g_c is None:
+                works[0] = works[1] = None
+                pending[0] = pending[1] = False
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            if g_c is not None:
+                g_c.replay()
+                g_c.replay()
+                nst = 2 * chunk
+            else:
+                nst = 40
+                for i in range(nst):
+                    reuse_guard(i)
+                    launch(i)
+                    gather(i)
+                drain()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            tms.append(e0.elapsed_time(e1) * 1e3 / nst)
+            errs.append(float((status[0] > _lib.W_REJECT).sum().item() + (status[1] > _lib.W_REJECT).sum().item()))
+            graphs.append(g_c)
         t_all = torch.tensor(tms, dtype=torch.float64, device=dev)
         e_all = torch.tensor(errs, dtype=torch.float64, device=dev)
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(e_all, op=dist.ReduceOp.MAX)
         t_rank = torch.where(e_all > 0, torch.full_like(t_all, float('inf')), t_all)
         pick = int(torch.argmin(t_rank).item())
-        block = cands[pick][1]
+        block, overlap = cands[pick][1], cands[pick][3]
         for e in engines:
             e.ctx.set_path(cands[pick][2])
         calls = calls_for(sptr)
+        graph = graphs[pick]
+        for b_ in range(2):
+            status[b_].zero_()
         block_tuned = {'candidates_us_per_step': {cands[k][0]: float(t_all[k].item()) for k in range(len(cands))},
-                       'candidates_walker_errors': {cands[k][0]: int(e_all[k].item()) for k in range(len(cands))}, 'taken': cands[pick][0]}
+                       'candidates_walker_errors': {cands[k][0]: int(e_all[k].item()) for k in range(len(cands))},
+                       'timed_as': 'hipGraph replays' if graph is not None else 'eager loop', 'taken': cands[pick][0]}
     for i in range(args.warmup):
         reuse_guard(i)
         launch(i)
         if use_gather:
             gather(i)
     drain()
-
-    # The step is launch-bound on the host next to a ~20 us kernel (and, N > 1, a collective issue of ~14 us), so a
-    # run of `chunk` steps (kernel -> all-gather, double-buffered exactly as above) is captured into one hipGraph
-    # and replayed; the timed region still executes exactly K steps (K // chunk replays, the remainder eagerly).
-    # Capture only is inside the try: the ranks FIRST agree whether every one of them captured, and only then does
-    # anybody replay (a replay holds `chunk` collectives: a rank that failed to capture must not meet it with an
-    # all-reduce).  MSX_BENCH_GRAPH=0 gives the eager loop; MSX_BENCH_FAIL_CAPTURE_RANK=r makes rank r fail on
-    # purpose; the ordering itself is mcmc_spec_amd.benchutil.capture_agreed (tests/test_dist_gloo.py).
-    graph, chunk = None, 0
-    want_graph = os.environ.get('MSX_BENCH_GRAPH', '1') == '1'
-    # The captured run covers as much of the timed region as possible: one replay costs the host ~10-16 us (the
-    # guide's graph-replay floor), which a 20-step run (what the driver times) would otherwise pay several times.
-    # Step i of a replay uses problem i mod nprob, theta batch i mod nbatch, output buffer i mod 2: any even chunk.
-    # (with a collective in the loop only the direct-RCCL route is captured: see above)
-    if want_graph and (direct or not use_gather) and args.steps >= 4:
-        # (kernel-only runs: the first four steps go out as plain launches, so that the GPU is already busy while the
-        # host prepares the graph launch -- 25-40 us that a 20-step run would otherwise spend with the GPU idle; same-box
-        # means of three 20-step runs: 19.7 us per step with none, 19.1 with two, 18.5 with four, 18.4-18.6 with 8 / 12)
-        head = int(os.environ.get('MSX_BENCH_HEAD', '4')) if (not use_gather and args.steps >= 8 and os.environ.get('MSX_BENCH_NO_HEAD') != '1') else 0
-        head = max(0, min(head, args.steps - 4))
-        chunk = min(args.steps - head, int(os.environ.get('MSX_BENCH_GRAPH_CHUNK', '200'))) // 2 * 2
-        from mcmc_spec_amd.benchutil import capture_agreed
-
-        def do_capture():
-            if os.environ.get('MSX_BENCH_FAIL_CAPTURE_RANK') == str(rank):
-                raise RuntimeError('capture failure requested for this rank')
-            torch.cuda.synchronize(dev)
-            g_ = torch.cuda.CUDAGraph()
-            # thread_local: calls made by other threads (c10d's watchdog) must not invalidate the capture
-            with torch.cuda.graph(g_, stream=torch.cuda.Stream(dev), capture_error_mode='thread_local'):
-                cs = torch.cuda.current_stream(dev).cuda_stream
-                tab = calls_for(cs)
-                for i in range(chunk):
-                    reuse_guard(i, cs)
-                    launch(i, tab)
-                    if use_gather:
-                        gather(i, cs)
-                drain(cs)   # (every fork of the capture -- the communicator's stream -- is joined again)
-            return g_
-
-        def do_replay(g_):
-            g_.replay()
-            torch.cuda.synchronize(dev)
-
-        def all_min(flag):
-            if not (world > 1 or force_gather):
-                return flag
-            ok_t = torch.tensor([flag], device=dev)
-            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-            return int(ok_t.item())
-
+    if can_graph and block_tuned is None:
         graph = capture_agreed(do_capture, do_replay, all_min, rank)
         if graph is None:
             works[0] = works[1] = None
+            pending[0] = pending[1] = False
     # HIP events on the launch stream bracket runs of `ev_run` consecutive launches inside the timed region
     # (an event pair around every single launch would put two extra packets between back-to-back kernels
     # and inflate what it measures); kernel_ms = elapsed / ev_run, i.e. duration + the stream's launch gap
@@ -642,6 +668,26 @@ def main():
         unramped = {'ms_per_step': dt_cold / args.steps * 1e3, 'value': n * world * args.steps / dt_cold,
                     'note': 'same {} steps after 1 s of idle + the {} warm-up steps, no untimed launches before the '
                             'timed region'.format(args.steps, args.warmup)}
+    # ---- beside the headline: the clock the CUs ran at under this kernel's load ------------------------------------
+    # (rank 0; untimed.)  Boxes of one pool differ: the same build has read 14.5 and 16.6 us per kernel in 20-step runs on
+    # two leases of one afternoon.  A few launches with clock stamps (msx_probe_launch: thread 0 of every walker's
+    # workgroup reads the 100 MHz wall clock and the shader-cycle counter at its first and last line), issued behind a
+    # burst of plain launches so that the GPU is in its sustained-load state, say whether that is the clock.
+    clock_probe = None
+    if rank == 0 and not replicas and os.environ.get('MSX_BENCH_NO_PROBE') != '1':
+        try:
+            pr = []
+            for k in range(5):
+                for i in range(200):
+                    launch(i)
+                pr.append(engines[0].ctx.probe_launch(thetas[0].data_ptr(), n, ndim, logp[0].data_ptr(), status[0].data_ptr(), sptr,
+                                                      _lib.MODE_LOGPOST, block))
+            clock_probe = {k_: float(np.median([p_[k_] for p_ in pr])) for k_ in pr[0]}
+            clock_probe['note'] = ('median of 5 probe launches, each behind 200 plain launches: shader clock while the walkers ran '
+                                   '(cycle counter / 100 MHz wall clock), a walker\'s own time first line -> last line, and first '
+                                   'walker\'s start -> last walker\'s end inside one launch')
+        except Exception as exc:  # noqa: BLE001 - a diagnostic, never fatal
+            clock_probe = {'error': str(exc)}
     # ---- N > 1: where a step's time goes (an untimed, eager pass after the timed region) ------------------------
     diag = None
     if use_gather:
@@ -759,8 +805,8 @@ def main():
                         else 'replicas, no collective')) if replicas else (
             'binary (T1=3850/T2=3025) {}-pixel spectrum{}, {} walkers per GPU per launch, logposterior (prior gate + '
             'likelihood){}'.format(args.npix, ' + 6-band photometry' if args.phot else ' + 2 contrast terms', n,
-                                   (', RCCL all-gather of log-probs' + ('' if args.no_overlap else
-                                                                      ' overlapped with the next launch'))
+                                   (', RCCL all-gather of log-probs' + (' overlapped with the next launch' if overlap else
+                                                                      ' before the next launch'))
                                    if world > 1 else ''))
         out = {
             'metric': 'walker log-likelihood evals/sec (whole node)',
@@ -786,6 +832,8 @@ def main():
             out['value'] = None
         if unramped is not None:
             out['unramped'] = unramped
+        if clock_probe is not None:
+            out['clock_probe'] = clock_probe
         if diag is not None:
             out['multi_gpu_diag'] = diag
         out['cpu_baseline'] = None

@@ -272,6 +272,14 @@ int msx_stream_copy_gbps(msx_ctx *ctx, int64_t bytes, int32_t iters, double *gbp
  * 132 instead of 148 bytes per pixel of a binary)                                                                  */
 int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
 
+/* One launch of the fused / linked form over n walkers like msx_logprob_batch_dev -- with clock stamps: thread 0 of every
+ * walker's workgroup (the first 4096 walkers) reads the 100 MHz wall clock and the shader-cycle counter at its first and
+ * last line.  Synchronises; out4 = {median shader clock in MHz while the walkers ran, median and maximum of a walker's own
+ * time in us, first walker's start -> last walker's end in us}.  What a short timed region cannot tell apart by itself: a
+ * box whose GPU clocks lower under this load from a launch that waits.                                              */
+int msx_probe_launch(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
+                     int32_t *d_status, void *hip_stream, int32_t block_threads, double *out4);
+
 /* the planner's counts for the pair form's last launch (a sub-batch): out2[0] = pairs, out2[1] = walkers evaluated alone;
  * synchronises */
 int msx_pair_stats(msx_ctx *ctx, int64_t *out2);

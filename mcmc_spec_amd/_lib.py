@@ -92,6 +92,7 @@ def load():
         'msx_stage_problem': (C.c_int, [vp, C.POINTER(MsxProblem)]),
         'msx_logprob_batch': (C.c_int, [vp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_logprob_batch_dev': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32]),
+        'msx_probe_launch': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, _dp]),
         'msx_set_path': (C.c_int, [vp, C.c_int32]),
         'msx_opt_init': (C.c_int, [vp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_opt_step': (C.c_int, [vp, _dp, C.POINTER(C.c_int32), C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
@@ -130,7 +131,7 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
+            'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped']
@@ -254,6 +255,13 @@ class Context:
         self.check(self.lib.msx_logprob_batch_dev(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim),
                                                   C.c_void_p(d_logp_ptr), C.c_void_p(d_status_ptr),
                                                   C.c_void_p(stream_ptr), int(block_threads)))
+
+    def probe_launch(self, d_theta_ptr, n, ndim, d_logp_ptr, d_status_ptr, stream_ptr, mode=MODE_LOGPOST, block_threads=0):
+        """One launch with clock stamps (msx_probe_launch): {'shader_mhz', 'walker_us_median', 'walker_us_max', 'span_us'}."""
+        out = np.zeros(4)
+        self.check(self.lib.msx_probe_launch(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim), C.c_void_p(d_logp_ptr),
+                                             C.c_void_p(d_status_ptr), C.c_void_p(stream_ptr), int(block_threads), dptr(out)))
+        return {'shader_mhz': float(out[0]), 'walker_us_median': float(out[1]), 'walker_us_max': float(out[2]), 'span_us': float(out[3])}
 
     def set_path(self, path):
         """PATH_AUTO / PATH_FUSED / PATH_PAIR / PATH_LINKED: which form of the hot path launches take (same bits either

@@ -112,10 +112,15 @@ struct DevProblem {
     int32_t smp_overlap;
     int64_t smp_stride;
     uint32_t *smp_ver;                      // [nw] updates of each walker so far
+    // clock probe (msx_probe_launch; bit 21 of the packed launch word): thread 0 of a walker's workgroup leaves the 100 MHz
+    // wall clock and the shader-cycle counter at its first and last line -- [walker][4] for the first kProbeWalkers
+    // walkers: the clock the CUs ran at under THIS kernel's load, and the walker's own time inside the launch
+    unsigned long long *clk_probe;
 #ifdef MSX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
 #endif
 };
+constexpr int kProbeWalkers = 4096;
 
 #ifdef MSX_STAMPS
 __shared__ int msx_stamp_off;  // linked form: one of a walker's workgroups writes the stamps

@@ -60,6 +60,7 @@ __device__ __forceinline__ double value_of_total(int mode, double total, double 
 // recognised as read-only by the compiler, which then keeps a private copy of all 1.2 KB of it in scratch
 // (tests/test_abi.py watches the variants' scratch size).
 struct SmpView {
+    unsigned long long *clk_probe;  // non-null: a probe launch (see DevProblem)
     int32_t smp_on, smp_defer, smp_overlap, linked_fault;
     int64_t smp_stride;
     double *smp_coords, *smp_logp, *smp_chain_row, *smp_lp_row;
@@ -67,8 +68,8 @@ struct SmpView {
     int32_t *smp_worst;
     uint32_t *smp_ver;
 };
-__device__ __forceinline__ SmpView smp_view(const DevProblem &P) {
-    return {P.smp_on, P.smp_defer, P.smp_overlap, P.linked_fault, P.smp_stride, P.smp_coords, P.smp_logp, P.smp_chain_row,
+__device__ __forceinline__ SmpView smp_view(const DevProblem &P, bool probe) {
+    return {probe ? P.clk_probe : nullptr, P.smp_on, P.smp_defer, P.smp_overlap, P.linked_fault, P.smp_stride, P.smp_coords, P.smp_logp, P.smp_chain_row,
             P.smp_lp_row, P.smp_naccept, P.smp_worst, P.smp_ver};
 }
 __device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
@@ -77,6 +78,10 @@ __device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &
     // carries log-probabilities only, and every rank must learn of every rank's failures
     logp[wk] = (st > MSX_W_REJECT) ? nan_with_status(st) : out;
     status[wk] = st;
+    if (P.clk_probe && wk < kProbeWalkers) {
+        P.clk_probe[wk * 4 + 2] = wall_clock64();
+        P.clk_probe[wk * 4 + 3] = (unsigned long long)__builtin_readcyclecounter();
+    }
     if (!P.smp_on) return;
     if (st > MSX_W_REJECT) atomicMax(P.smp_worst, st);
     if (P.smp_defer) return;  // sharded: sampler_apply_kernel finishes the move after the all-gather
@@ -268,14 +273,15 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     //   rblk            the recipe's tables in one block (dev_types.h: isochrone Teff / logg, the grid's node lists and
     //                   per-Teff-node presence bits at fixed offsets; from P.iso_t, P.iso_g, P.teff_nodes, ...)
     //   niso_nt         niso | nt << 16
-    //   ng_mode_fast    ng | mode << 8 | fast << 16 | sampler << 17 | dist_fit << 18 | use_av << 19 | overlap << 20 | segments << 24
+    //   ng_mode_fast    ng | mode << 8 | fast << 16 | sampler << 17 | dist_fit << 18 | use_av << 19 | overlap << 20 | probe << 21 | segments << 24
     //   n               the batch size (ndim is 2 NS + 2, checked by the host)
     //   gate_tmin/tmax  the Teff box of the prior's hard gates (= P.tmin, P.tmax)
     //   theta, smp_rec  device-resident sampler: `theta` is the resident ensemble (= P.smp_coords) and smp_rec the
     //                   half-step's records (= P.smp_rec): the proposal is two dependent loads away from wave start
     const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
     constexpr int ndim = 2 * NS + 2;
-    const SmpView V = smp_view(P);  // (for walker_done)
+    const bool probe = (ng_mode_fast >> 21) & 1;  // msx_probe_launch: clock stamps at the walker's first and last line
+    const SmpView V = smp_view(P, probe);  // (for walker_done)
     __shared__ WalkerDesc D;
     __shared__ BlockScratch S;
     __shared__ double red[3][MAXT / kWave][kWave];  // one partial per lane and quantity (wave_ops.h, canonical sum)
@@ -305,6 +311,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     RecipeRegs RR;
     if (fast && (threadIdx.x >> 6) < NS) load_recipe_regs(RR, rblk, niso, nt, ng, threadIdx.x & 63);
     if (wk >= n) return;
+    if (probe && threadIdx.x == 0 && wk < kProbeWalkers && (!LK || myseg == 0)) {
+        P.clk_probe[wk * 4 + 0] = wall_clock64();
+        P.clk_probe[wk * 4 + 1] = (unsigned long long)__builtin_readcyclecounter();
+    }
     if (LK) {
         // a poisoned context (an earlier launch's meeting timed out, see below): no counter is trusted,
         // every walker of every linked launch fails loudly until the problem is staged again

@@ -139,6 +139,7 @@ struct msx_ctx {
     unsigned char *d_recipe_block = nullptr;  // ... and its tables in one block (dev_types.h), freed with the problem
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
     bool smp_overlap_launch = false;   // the launch being queued is a half-step of an overlapped run: fused form, bit 20
+    bool probe_launch = false;         // ... is msx_probe_launch's: the kernel leaves clock stamps (bit 21)
 };
 static void sampler_free(msx_ctx *c);
 
@@ -936,6 +937,12 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         P.stamps = st;
     }
 #endif
+    {   // the clock probe's stamps (msx_probe_launch)
+        unsigned long long *cp = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&cp, sizeof(unsigned long long) * 4 * kProbeWalkers)); tr.push_back(cp);
+        HIP_TRY(c, hipMemset(cp, 0, sizeof(unsigned long long) * 4 * kProbeWalkers));
+        P.clk_probe = cp;
+    }
     c->problem_staged = true;
     return MSX_OK;
 }
@@ -1012,6 +1019,7 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
                           (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
     bool pair = can_pair && n >= c->pair_min_walkers && pair_worth_it(c);
     if (c->smp_overlap_launch) A.ng_mode_fast |= 1 << 20;
+    if (c->probe_launch) { A.ng_mode_fast |= 1 << 21; pair = false; }  // (the pair form carries no stamps)
     if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_LINKED) pair = false;
     if (c->path == MSX_PATH_PAIR) {
         if (!can_pair) return fail(c, MSX_ERR_STATE, "msx_set_path(PAIR): needs a binary of <= 4096 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
@@ -1038,6 +1046,39 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
             if ((rc = launch_logprob<false>(c, P, A, B, shared512))) return rc;
         }
     }
+    return MSX_OK;
+}
+
+int msx_probe_launch(msx_ctx *c, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
+                     int32_t *d_status, void *hip_stream, int32_t block_threads, double *out4) {
+    if (!c || !out4) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_probe_launch: no problem staged");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t m = std::min<int64_t>(n, kProbeWalkers);
+    HIP_TRY(c, hipMemsetAsync(c->P.clk_probe, 0, sizeof(unsigned long long) * 4 * (size_t)m, (hipStream_t)hip_stream));
+    c->probe_launch = true;
+    const int rc = msx_logprob_batch_dev(c, mode, d_theta, n, ndim, d_logp, d_status, hip_stream, block_threads);
+    c->probe_launch = false;
+    if (rc != MSX_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)hip_stream));
+    std::vector<unsigned long long> h((size_t)(4 * m));
+    HIP_TRY(c, hipMemcpy(h.data(), c->P.clk_probe, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    std::vector<double> mhz, chain;
+    unsigned long long w0 = ~0ull, w1 = 0ull;
+    for (int64_t i = 0; i < m; ++i) {
+        const unsigned long long a = h[(size_t)(4 * i)], ca = h[(size_t)(4 * i + 1)], b = h[(size_t)(4 * i + 2)], cb = h[(size_t)(4 * i + 3)];
+        if (a == 0ull || b <= a) continue;  // (a walker the pair planner or an early exit finished: no stamps)
+        mhz.push_back((double)(cb - ca) / (double)(b - a) * 100.0);  // wall clock: 100 MHz
+        chain.push_back((double)(b - a) / 100.0);
+        w0 = std::min(w0, a); w1 = std::max(w1, b);
+    }
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+    if (mhz.empty()) return MSX_OK;
+    std::sort(mhz.begin(), mhz.end()); std::sort(chain.begin(), chain.end());
+    out4[0] = mhz[mhz.size() / 2];
+    out4[1] = chain[chain.size() / 2];
+    out4[2] = chain.back();
+    out4[3] = (double)(w1 - w0) / 100.0;
     return MSX_OK;
 }
 
