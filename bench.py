@@ -718,32 +718,11 @@ def main():
 
     if rank == 0:
         kern_s = kern_ms * 1e-3
-        # bytes one walker's workgroup requests from the memory system (L2-served), for the variant THIS launch took
-        req = eng.ctx.bytes_per_eval(n if block != _lib.BLOCK_512_SHARED else 10 ** 9)
-        cus = 256
-        # (mirrors pick_block / launch_logprob of csrc/msx.hip)
-        if block in (256, 512):
-            bt = block
-        elif block == _lib.BLOCK_512_SHARED or args.npix >= 8192 or n <= cus:
-            bt = 512
-        elif args.npix <= 2048:
-            bt = 256
-        else:
-            bt = 512 if n <= 2 * cus else 256
-        nseg = (args.npix + 8191) // 8192
-        if block == 0 and 2 <= nseg <= 8 and n * nseg <= cus and os.environ.get('MSX_LINKED', '') != '0' and eng.ctx.bytes_per_eval(n) != eng.ctx.bytes_per_eval(10 ** 9):
-            kernel_name = ('logprob_kernel<NS=2, 512 threads, linked> (one workgroup per walker and 8192-pixel segment; partial sums and '
-                           'histogram counters exchanged inside the launch; the segment\'s data flux staged in LDS; four pixels per lane and trip)')
-        elif bt == 256 and n <= 2 * cus:
-            kernel_name = 'logprob_kernel<NS=2, 256 threads, two per CU> (u / flux staged in LDS where two such workgroups fit a CU; four pixels per lane and trip)'
-        elif bt == 256:
-            kernel_name = 'logprob_kernel<NS=2, 256 threads> (three workgroups per CU)'
-        elif args.npix * 8 <= 70 * 1024 and (n > cus or block == _lib.BLOCK_512_SHARED):
-            kernel_name = 'logprob_kernel<NS=2, 512 threads, SH> (<= 128 VGPRs: two workgroups fit a CU; rows one star at a time)'
-        elif args.npix * 8 * 3 > 130 * 1024:
-            kernel_name = 'logprob_kernel<NS=2, 512 threads> (one workgroup per CU, four pixels per lane and trip)'
-        else:
-            kernel_name = 'logprob_kernel<NS=2, 512 threads, PF> (one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip)'
+        # the variant THIS launch took and the bytes one walker's workgroup requests from the memory system (L2-served):
+        # asked of the library's own launcher (msx_launch_info reads the table the launcher reads -- nothing is mirrored here)
+        info = eng.ctx.launch_info(n, _lib.MODE_LOGPOST, block)
+        req = info['requested_bytes_per_eval']
+        kernel_name = info['kernel']
         # ---- the roofline that bounds THIS design --------------------------------------------------------------
         # The kernel never streams the windowed grid from HBM: staging folds the resample into per-node tables of
         # 12 bytes per pixel (R float64 + H float32, 5.1 MB at config 2) that live in L2 / Infinity Cache, and a
@@ -762,6 +741,7 @@ def main():
             'bound': 'l2->cu', 'achieved': achieved, 'peak': L2_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / L2_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_src,
             'kernel': kernel_name, 'kernel_ms': kern_ms, 'kernel_ms_samples': kern_samples,
+            'kernel_resources': {k_: info[k_] for k_ in ('form', 'threads', 'vgprs', 'static_lds_bytes', 'dynamic_lds_bytes', 'workgroups')},
             'requested_bytes_per_eval': req, 'requested_bytes_per_launch': n * req,
             'per_cu_GBps': req / kern_s / 1e9 if n <= 256 else None,
             'guide_l2_row_gather_GBps': {'per_cu': [66, 73], 'chip': [16800, 18800]},
@@ -787,17 +767,18 @@ def main():
                         'fraction of a bound and exceeds 1; measured HBM traffic is the figure beside it'}
         copy_gbps = eng.ctx.stream_copy_gbps(int(args.copy_gib * (1 << 30)), 10)
         roofline['measured_stream_copy_GBps'] = copy_gbps
-        vj = load_profile('r3_valu.json') or load_profile('r2_valu.json')
+        vj = load_profile('r4_valu.json') or load_profile('r3_valu.json')
+        vj_name = 'profiles/r4_valu.json' if load_profile('r4_valu.json') else 'profiles/r3_valu.json'
         issue_peak = 1024 * 2.4e9 / 4.0   # FP64 wave-instructions per second: 1024 SIMDs, one per 4 clocks, 2.4 GHz
         valu_by_regime = {}
         if vj:
-            for pt in vj['points']:
-                valu_by_regime[(pt['npix'], pt['walkers'])] = pt['valu_insts_per_eval']
-            v = valu_by_regime.get((args.npix, n))
+            for pt in vj['points']:   # (keyed by the form that RAN at the profiled point: 'fused' / 'pair' / 'linked')
+                valu_by_regime[(pt['npix'], pt['walkers'], pt.get('path', 'fused'))] = pt['valu_insts_per_eval']
+            v = valu_by_regime.get((args.npix, n, info['form'].split(' ')[0]))
             if v:
                 roofline['valu'] = {'insts_per_eval': v, 'wave_insts_per_s': v * n / kern_s, 'issue_peak_per_s': issue_peak,
                                     'issue_frac': v * n / kern_s / issue_peak,
-                                    'source': 'profiles/r3_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) x this run\'s kernel time; '
+                                    'source': vj_name + ' (rocprofv3 --pmc SQ_INSTS_VALU) x this run\'s kernel time; '
                                               'peak = 1024 SIMDs x 2.4 GHz / 4 clocks per FP64 wave-instruction'}
         workload = ('BASELINE config 5: KOI targets ({} px each after the (0.55, 0.90) um crop), one independent problem per '
                     'GPU, {} walkers per launch, logposterior with 2 contrast terms; {}'.format(
@@ -813,6 +794,9 @@ def main():
             'value': n * world * args.steps / dt, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            # (what the arithmetic type does not say: two of the staged tables only ever enter multiplied by eps ~ 4e-5 A_V and
+            # are stored in float32 -- csrc/blend.h; every sum, the model vector and the grid's R table are float64)
+            'storage': {'R': 'f64', 'H': 'f32', 'dk': 'f32', 'note': 'R = lo + (hi - lo) t per grid node and pixel; H = hi t and dk = k_hi - k_lo enter the model only as eps * H, eps = 2^(redc dk) - 1: their 2^-24 rounding perturbs a pixel by < 2.4e-12 A_V relative (tests/test_gpu_parity.py, A_V = 3)'},
             'config': {'workload': workload, 'baseline_config': args.config if args.config != 2 or world == 1 else 3,
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': W.get('nwin'),
                        'grid': '26x4x135000 f64 synthetic',
@@ -869,14 +853,20 @@ def main():
                 th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
                 lp_, st_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
                 us = device_time_us(eng, th, lp_, st_, stream, m, max(30, min(60, 400000 // m)))
-                req_m = eng.ctx.bytes_per_eval(m)
-                row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6, 'requested_bytes_per_eval': req_m,
-                       'requested_GBps': m * req_m / us / 1e3, 'frac_of_l2_peak': m * req_m / us / 1e3 / L2_PEAK_GBPS}
-                row['form'] = 'pair (planner + two walkers of one grid cell per workgroup)' if m >= (2304 if args.npix > 3072 else 4096) and args.npix <= 4096 else 'fused'
-                # VALU wave-instructions per evaluation: profiles/r3_sq_*_pair_vs_fused.json (16,384 walkers: fused
-                # 256-thread variant 9,028, pair kernel 8,741)
-                vi = (8741 if row['form'] != 'fused' else 9028) if (m > 1024 and args.npix == 4096) else None
-                if vi:
+                # the form the launches TOOK (msx_last_form: MSX_PATH_AUTO looks at the planner's counts) and what that form
+                # requests per walker -- from the library, like the headline's
+                ran = eng.ctx.last_form()
+                inf_m = eng.ctx.launch_info(m, _lib.MODE_LOGPOST, 0)
+                req_m = inf_m['requested_bytes_per_eval'] if inf_m['form_id'] == ran else None
+                row = {'walkers': m, 'device_us': us, 'evals_per_s': m / us * 1e6, 'form': _lib.FORM_NAMES[ran],
+                       'kernel': inf_m['kernel'].split(' (')[0] if inf_m['form_id'] == ran else None, 'requested_bytes_per_eval': req_m}
+                if req_m:
+                    row.update(requested_GBps=m * req_m / us / 1e3, frac_of_l2_peak=m * req_m / us / 1e3 / L2_PEAK_GBPS)
+                # VALU wave-instructions per evaluation of the nearest profiled point of the same form (profiles/r4_valu.json)
+                cands_v = [(abs(np.log(k_[1] / m)), v_) for k_, v_ in valu_by_regime.items() if k_[0] == args.npix and k_[2] == _lib.FORM_NAMES[ran].split(' ')[0]]
+                if cands_v and min(cands_v)[0] < 0.75:
+                    vi = min(cands_v)[1]
+                    row['valu_insts_per_eval'] = vi
                     row['valu_issue_frac'] = vi * m / (us * 1e-6) / issue_peak
                 sweep.append(row)
             extra['sweep'] = {'npix': args.npix, 'rows': sweep}
@@ -887,12 +877,11 @@ def main():
                 th = torch.from_numpy(synth.draw_walkers(128, seed=3, tmin=W4['tmin'], tmax=W4['tmax'])).to(dev)
                 lp_, st_ = torch.empty(128, dtype=torch.float64, device=dev), torch.empty(128, dtype=torch.int32, device=dev)
                 us = device_time_us(e4, th, lp_, st_, stream, 128, 50)
-                # (MSX_PATH_AUTO's rule, msx.hip auto_takes_linked: walkers x segments <= #CUs)
-                linked = os.environ.get('MSX_LINKED', '') != '0' and 128 * 2 <= e4.ctx.device_info()['cus']
+                inf4 = e4.ctx.launch_info(128, _lib.MODE_LOGPOST, 0)
                 extra['config4_per_gpu_share'] = {'walkers': 128, 'npix': 16384, 'photometry_bands': 6, 'device_us': us,
-                                                  'evals_per_s': 128 / us * 1e6,
-                                                  'form': 'linked (one workgroup per walker and 8192-pixel segment)' if linked else 'fused',
-                                                  'requested_bytes_per_eval': e4.ctx.bytes_per_eval(128)}
+                                                  'evals_per_s': 128 / us * 1e6, 'form': _lib.FORM_NAMES[e4.ctx.last_form()],
+                                                  'kernel': inf4['kernel'].split(' (')[0],
+                                                  'requested_bytes_per_eval': inf4['requested_bytes_per_eval']}
         if extra:
             out['extra'] = extra
         sys.stdout.flush()

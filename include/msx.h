@@ -280,6 +280,17 @@ int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
 int msx_probe_launch(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
                      int32_t *d_status, void *hip_stream, int32_t block_threads, double *out4);
 
+/* What an automatic launch of n walkers in `mode` (block_threads as for msx_logprob_batch_dev) WOULD take, asked of the
+ * library's own launcher (nothing is queued): `name` receives the kernel's name and description, out8 = {form (MSX_FORM_*),
+ * threads per workgroup, VGPRs, static LDS bytes, dynamic LDS bytes, bytes requested from the memory system per walker
+ * (as msx_bytes_per_eval), workgroups of the first sub-batch, walkers of the first sub-batch}.                          */
+#define MSX_FORM_FUSED 0
+#define MSX_FORM_PAIR 1
+#define MSX_FORM_LINKED 2
+int msx_launch_info(msx_ctx *ctx, int32_t mode, int64_t n, int32_t block_threads, char *name, int32_t name_len, int64_t *out8);
+/* the form (MSX_FORM_*) the last launch queued on this context took (MSX_PATH_AUTO looks at the planner's lagging counts) */
+int msx_last_form(msx_ctx *ctx, int32_t *form);
+
 /* the planner's counts for the pair form's last launch (a sub-batch): out2[0] = pairs, out2[1] = walkers evaluated alone;
  * synchronises */
 int msx_pair_stats(msx_ctx *ctx, int64_t *out2);

@@ -20,6 +20,8 @@ W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR, W_HANDOVER = 0, 1, 2, 3,
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
 PATH_AUTO, PATH_FUSED, PATH_PAIR, PATH_LINKED = 0, 1, 2, 4  # include/msx.h MSX_PATH_*
+FORM_FUSED, FORM_PAIR, FORM_LINKED = 0, 1, 2  # include/msx.h MSX_FORM_*
+FORM_NAMES = {0: 'fused', 1: 'pair (planner + two walkers of one grid cell per workgroup)', 2: 'linked (one workgroup per walker and 8192-pixel segment)'}
 HOOK_LINKED_FAULT, HOOK_PAIR_LEASES = 1, 2  # include/msx.h MSX_HOOK_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
@@ -117,6 +119,8 @@ def load():
         'msx_stream_copy_gbps': (C.c_int, [vp, C.c_int64, C.c_int32, _dp]),
         'msx_bytes_per_eval': (C.c_int, [vp, C.c_int64, _ip]),
         'msx_test_hook': (C.c_int, [vp, C.c_int32, C.c_int32]),
+        'msx_launch_info': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_char_p, C.c_int32, _ip]),
+        'msx_last_form': (C.c_int, [vp, C.POINTER(C.c_int32)]),
         'msx_pair_stats': (C.c_int, [vp, _ip]),
         'msx_sampler_overlapped': (C.c_int, [vp, C.POINTER(C.c_int32)]),
     }
@@ -134,7 +138,7 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
-            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped']
+            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_launch_info', 'msx_last_form', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped']
 
 
 def as_f64(a):
@@ -399,6 +403,21 @@ class Context:
         """Bytes the variant an automatic launch of ``n`` walkers takes requests from the memory system, per walker."""
         out = C.c_int64()
         self.check(self.lib.msx_bytes_per_eval(self.h, int(n), C.byref(out)))
+        return out.value
+
+    def launch_info(self, n, mode=MODE_LOGPOST, block_threads=0):
+        """What an automatic launch of ``n`` walkers would take, from the library's own launcher (msx_launch_info)."""
+        out = np.zeros(8, dtype=np.int64)
+        name = C.create_string_buffer(512)
+        self.check(self.lib.msx_launch_info(self.h, int(mode), int(n), int(block_threads), name, 512, iptr(out)))
+        return {'kernel': name.value.decode(), 'form': FORM_NAMES[int(out[0])], 'form_id': int(out[0]), 'threads': int(out[1]),
+                'vgprs': int(out[2]), 'static_lds_bytes': int(out[3]), 'dynamic_lds_bytes': int(out[4]),
+                'requested_bytes_per_eval': int(out[5]), 'workgroups': int(out[6]), 'walkers_per_sub_batch': int(out[7])}
+
+    def last_form(self):
+        """The form (FORM_*) the last launch queued on this context took."""
+        out = C.c_int32()
+        self.check(self.lib.msx_last_form(self.h, C.byref(out)))
         return out.value
 
     def pair_stats(self):

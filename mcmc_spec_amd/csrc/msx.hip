@@ -140,6 +140,7 @@ struct msx_ctx {
     struct SamplerRun *smp = nullptr;  // device-resident sampler in flight (msx_sampler_begin .. _end)
     bool smp_overlap_launch = false;   // the launch being queued is a half-step of an overlapped run: fused form, bit 20
     bool probe_launch = false;         // ... is msx_probe_launch's: the kernel leaves clock stamps (bit 21)
+    int32_t last_form = 0;             // MSX_FORM_* of the last launch queued (msx_last_form)
 };
 static void sampler_free(msx_ctx *c);
 
@@ -339,56 +340,98 @@ bool takes_pf(const msx_ctx *c, int64_t n) {
            owns_cu(c, n) && c->pf_ok && c->use_pf;
 }
 
-// One launch of logprob_kernel<..., LK> over A.n walkers with workgroups of B threads (LK: the linked form, one
-// workgroup per walker and segment; else the fused kernel in the variant the table in pick_block() names).
-template <bool LK>
-int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
-    // (linked: block = (walker / 8) * 8 segments + segment * 8 + walker % 8, see the kernel)
-    const dim3 g((unsigned)(LK ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
+// ---- the variants of logprob_kernel, as a TABLE: the launcher, msx_launch_info (what bench.py prints as the roofline's
+// kernel) and the dynamic-LDS limits all read this one list -- nobody mirrors the choice -------------------------------
+struct Variant {
+    const void *fn;
+    int ns, threads;
+    bool gm, sh, pf, lk;
+    const char *what;
+};
+#define MSX_V(NS_, T_, GM_, SH_, PF_, LK_, WHAT_) \
+    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, WHAT_}
+const Variant kVariants[] = {
+    MSX_V(2, 256, false, false, false, false, "three workgroups per CU"),
+    MSX_V(2, 256, false, true, false, false, "two per CU, four pixels per lane and trip"),
+    MSX_V(2, 256, false, true, true, false, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip"),
+    MSX_V(2, 512, false, false, false, false, "one workgroup per CU, four pixels per lane and trip"),
+    MSX_V(2, 512, false, true, false, false, "<= 128 VGPRs: two workgroups fit a CU; rows one star at a time"),
+    MSX_V(2, 512, false, false, true, false, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip"),
+    MSX_V(3, 256, false, false, false, false, "three workgroups per CU"),
+    MSX_V(3, 512, false, false, false, false, "one workgroup per CU, four pixels per lane and trip"),
+    MSX_V(3, 512, false, false, true, false, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip"),
+    MSX_V(2, 512, false, false, false, true, "one workgroup per walker and 8192-pixel segment; partial sums and histogram counters exchanged inside the launch; the segment's data flux staged in LDS; four pixels per lane and trip"),
+    MSX_V(3, 512, false, false, false, true, "one workgroup per walker and 8192-pixel segment; partial sums and histogram counters exchanged inside the launch; the segment's data flux staged in LDS; four pixels per lane and trip"),
+    MSX_V(2, 512, true, false, false, false, "model vector in global memory (spectra beyond the LDS), sub-batched"),
+    MSX_V(3, 512, true, false, false, false, "model vector in global memory (spectra beyond the LDS), sub-batched"),
+};
+#undef MSX_V
+const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk) {
+    for (const Variant &v : kVariants)
+        if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk) return &v;
+    return nullptr;
+}
+struct VariantChoice {
+    const Variant *v;
+    size_t dyn_lds;
+};
+// Which variant a launch of n walkers with workgroups of B threads takes (LK: the linked form, one workgroup per walker
+// and segment; else the fused kernel in the variant the table in pick_block() names), and its dynamic LDS.
+VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, int B, bool shared512, bool LK) {
     // dynamic LDS: the model vector (linked: one segment of it, and the segment's data flux behind it)
     const size_t lds = LK ? sizeof(double) * (size_t)(2 * kSegElems) + sizeof(double2) * (size_t)kSegElems
                           : sizeof(double) * (size_t)P.npix + (size_t)c->pad_lds;
-#define MSX_LEAD_ARGS (P.smp_on ? (const double *)P.smp_coords : A.theta), (const unsigned char *)c->d_recipe_block, A.niso_nt, \
-                      A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, P.smp_rec
-#define MSX_GO(NS_, U_, T_, GM_, CP_, PF_, LDS_)                                                                   \
-    hipLaunchKernelGGL((logprob_kernel<NS_, U_, T_, GM_, CP_, PF_, LK>), g, dim3(T_), (LDS_), A.s, MSX_LEAD_ARGS, P, \
-                       A.logp, A.status)
     // PF adds u and the data flux in the tables' pair layout
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
-    if constexpr (LK) {
-        if (P.nspec == 2) MSX_GO(2, 2, 512, false, false, false, lds); else MSX_GO(3, 2, 512, false, false, false, lds);
-    } else if (c->model_in_global) {
-        // spectra longer than the LDS: the model vector lives in the global scratch (the kernel writes it there itself)
-        if (P.nspec == 2) MSX_GO(2, 2, 512, true, false, false, 0); else MSX_GO(3, 2, 512, true, false, false, 0);
-    } else {
-        // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
-        const bool own_cu = owns_cu(c, A.n);
-        // binaries between one and two walkers per CU: the <= 128-VGPR variant, two workgroups per CU.  With a CU to
-        // itself a workgroup takes the quad-walking variants (pixel statics staged in LDS when they fit): 256 walkers x
-        // 4096 px 16.7-16.9 us against 17.0-17.1 for the <= 128-VGPR variant; MSX_NO_SH2=0 in the environment forces the latter
-        const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024 && c->force_sh2;
-        const bool pf = B == 512 && !shared512 && !sh2 && takes_pf(c, A.n);
-        const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
-        if (P.nspec == 2) {
-            // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
-            // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
-            const bool q256 = c->q256 > 0 || (c->q256 < 0 && A.n <= 2 * (int64_t)c->prop.multiProcessorCount);
-            // (... with u and the data flux staged in LDS when two such workgroups still fit a CU)
-            if (B == 256 && q256 && c->pf256_ok && c->use_pf) MSX_GO(2, 2, 256, false, true, true, lds_pf);
-            else if (B == 256 && q256) MSX_GO(2, 2, 256, false, true, false, lds);
-            else if (B == 256) MSX_GO(2, 2, 256, false, false, false, lds);
-            else if (pf) MSX_GO(2, 2, 512, false, false, true, lds_pf);
-            else if (sh) MSX_GO(2, 2, 512, false, true, false, lds);   // two workgroups per CU
-            else MSX_GO(2, 2, 512, false, false, false, lds);
-        } else {  // triples: twelve corners do not fit the shared variant's 128 VGPRs -- it is the plain one
-            if (B == 256) MSX_GO(3, 2, 256, false, false, false, lds);
-            else if (pf) MSX_GO(3, 2, 512, false, false, true, lds_pf);
-            else MSX_GO(3, 2, 512, false, false, false, lds);
-        }
+    const int ns = P.nspec == 2 ? 2 : 3;
+    if (LK) return {find_variant(ns, 512, false, false, false, true), lds};
+    // spectra longer than the LDS: the model vector lives in the global scratch (the kernel writes it there itself)
+    if (c->model_in_global) return {find_variant(ns, 512, true, false, false, false), 0};
+    // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
+    const bool own_cu = owns_cu(c, n);
+    // binaries between one and two walkers per CU: the <= 128-VGPR variant, two workgroups per CU.  With a CU to
+    // itself a workgroup takes the quad-walking variants (pixel statics staged in LDS when they fit): 256 walkers x
+    // 4096 px 16.7-16.9 us against 17.0-17.1 for the <= 128-VGPR variant; MSX_NO_SH2=0 in the environment forces the latter
+    const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024 && c->force_sh2;
+    const bool pf = B == 512 && !shared512 && !sh2 && takes_pf(c, n);
+    const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
+    if (ns == 2) {
+        // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
+        // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
+        const bool q256 = c->q256 > 0 || (c->q256 < 0 && n <= 2 * (int64_t)c->prop.multiProcessorCount);
+        // (... with u and the data flux staged in LDS when two such workgroups still fit a CU)
+        if (B == 256 && q256 && c->pf256_ok && c->use_pf) return {find_variant(2, 256, false, true, true, false), lds_pf};
+        if (B == 256 && q256) return {find_variant(2, 256, false, true, false, false), lds};
+        if (B == 256) return {find_variant(2, 256, false, false, false, false), lds};
+        if (pf) return {find_variant(2, 512, false, false, true, false), lds_pf};
+        if (sh) return {find_variant(2, 512, false, true, false, false), lds};   // two workgroups per CU
+        return {find_variant(2, 512, false, false, false, false), lds};
     }
-#undef MSX_GO
-#undef MSX_LEAD_ARGS
-    HIP_TRY(c, hipGetLastError());
+    // triples: twelve corners do not fit the shared variant's 128 VGPRs -- it is the plain one
+    if (B == 256) return {find_variant(3, 256, false, false, false, false), lds};
+    if (pf) return {find_variant(3, 512, false, false, true, false), lds_pf};
+    return {find_variant(3, 512, false, false, false, false), lds};
+}
+
+// One launch of the chosen variant over A.n walkers.
+template <bool LK>
+int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, bool shared512) {
+    const VariantChoice ch = choose_variant(c, P, A.n, B, shared512, LK);
+    if (!ch.v) return fail(c, MSX_ERR_STATE, "no kernel variant for this launch");
+    // (linked: block = (walker / 8) * 8 segments + segment * 8 + walker % 8, see the kernel)
+    const dim3 g((unsigned)(LK ? ((A.n + 7) & ~7ll) * c->nseg : A.n));
+    // the kernel's arguments, in its own order (the leading 14 dwords arrive preloaded in SGPRs: logprob_kernel)
+    const double *a_theta = P.smp_on ? (const double *)P.smp_coords : A.theta;
+    const unsigned char *a_rblk = (const unsigned char *)c->d_recipe_block;
+    int a_niso_nt = A.niso_nt, a_word = A.ng_mode_fast;
+    int64_t a_n = A.n;
+    double a_tmin = P.tmin, a_tmax = P.tmax;
+    const SmpRec *a_rec = P.smp_rec;
+    DevProblem a_P = P;
+    double *a_logp = A.logp;
+    int32_t *a_status = A.status;
+    void *args[] = {&a_theta, &a_rblk, &a_niso_nt, &a_word, &a_n, &a_tmin, &a_tmax, &a_rec, &a_P, &a_logp, &a_status};
+    HIP_TRY(c, hipLaunchKernel(ch.v->fn, g, dim3((unsigned)ch.v->threads), args, ch.dyn_lds, A.s));
     return MSX_OK;
 }
 
@@ -408,10 +451,52 @@ bool auto_takes_linked(const msx_ctx *c, int64_t n) {
 // synchronising, so it may lag.  While it says "spread" the fused kernel runs, and every 32nd qualifying launch goes
 // through the pair form anyway to look again.  (The choice is frozen into a captured hipGraph like any launch
 // parameter.)  Values never depend on it.
-bool pair_worth_it(msx_ctx *c) {
+bool pair_worth_it(msx_ctx *c, bool peek = false) {
     const int32_t np = ((volatile int32_t *)c->h_pair_stats)[0], ns = ((volatile int32_t *)c->h_pair_stats)[1];
     const bool pays = 4 * (int64_t)ns < 3 * (int64_t)np;
+    if (peek) return pays;  // (msx_launch_info: what the next launch would take, without counting as one)
     return pays || (++c->pair_auto_launches % 32) == 0;
+}
+
+// Which FORM of the path a launch of n walkers in `mode` takes (msx_logprob_batch_dev decides with this; msx_launch_info
+// and msx_bytes_per_eval ask with peek = true).  err != MSX_OK: an explicit msx_set_path that the staged problem cannot take.
+struct FormChoice {
+    bool linked = false, pair = false;
+    int err = MSX_OK;
+    const char *msg = "";
+};
+FormChoice decide_form(msx_ctx *c, int64_t n, int mode, bool peek) {
+    FormChoice f;
+    const DevProblem &Pc = c->P;
+    const bool fast = c->recipe_fast;
+    const bool lp_mode = mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ;
+    // linked (logprob_kernel<..., LK>): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel segment); the
+    // walker's workgroups exchange their segments' partial sums and counters inside the kernel and each makes the chi^2 /
+    // median pass over its own segment, so a launch of <= #CUs / segments walkers uses segments x as many CUs and every
+    // workgroup's chain of latencies is 8192 pixels long.  Only the likelihood / posterior / chi^2 modes of a problem
+    // with a spectrum term and the register-resident recipe.  MSX_PATH_AUTO takes it while walkers x segments <= #CUs
+    // (one workgroup per CU: they wait for each other).  MSX_LINKED=0 / 1 in the environment: never / whenever possible.
+    // A context on which a meeting has once timed out is POISONED until the problem is staged again: AUTO takes the
+    // fused form, an explicit MSX_PATH_LINKED is refused (and the kernel itself fails every walker, for callers of
+    // the device entry point who never looked at the statuses).
+    const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum && lp_mode;
+    f.linked = can_link && auto_takes_linked(c, n) && !c->smp_overlap_launch;
+    if (c->path == MSX_PATH_LINKED) {
+        if (!can_link) { f.err = MSX_ERR_STATE; f.msg = "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode"; return f; }
+        if (c->linked_poisoned) { f.err = MSX_ERR_STATE; f.msg = "msx_set_path(LINKED): a hand-over timed out on this context (MSX_W_HANDOVER); stage the problem again"; return f; }
+        f.linked = true;
+    }
+    // pair (pair_kernel.h): many walkers -- two walkers of one grid cell per workgroup share one set of row loads
+    const bool can_pair = c->pair_rows > 0 && fast && !Pc.smp_on && Pc.nspec == 2 && lp_mode;
+    f.pair = can_pair && n >= c->pair_min_walkers && pair_worth_it(c, peek);
+    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_LINKED) f.pair = false;
+    if (c->path == MSX_PATH_PAIR) {
+        if (!can_pair) { f.err = MSX_ERR_STATE; f.msg = "msx_set_path(PAIR): needs a binary of <= 4096 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode"; return f; }
+        f.pair = true;
+    }
+    if (c->probe_launch) f.pair = false;  // (the pair form carries no clock stamps)
+    if (f.pair) f.linked = false;
+    return f;
 }
 
 // The pair form over A.n walkers (pair_kernel.h): the variant compiled for the smallest trip count that covers the
@@ -446,23 +531,18 @@ int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
 // Every variant that takes dynamic LDS may be launched with up to the CU's 160 KiB minus its own static LDS.
 // The limit is a property of the FUNCTION in this process, not of a context: it is raised once, to the maximum,
 // so that contexts staged with different spectrum lengths can never lower it under one another.
-template <typename K>
-hipError_t raise_one(K kernel) {
+hipError_t raise_one(const void *kernel) {
     hipFuncAttributes at;
-    hipError_t e = hipFuncGetAttributes(&at, (const void *)kernel);
+    hipError_t e = hipFuncGetAttributes(&at, kernel);
     if (e != hipSuccess) return e;
     const int room = (160 * 1024 - (int)at.sharedSizeBytes) & ~15;
-    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room);
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room);
 }
 hipError_t raise_all() {
     hipError_t e = hipSuccess;
-#define MSX_R(...) if (e == hipSuccess) e = raise_one(logprob_kernel<__VA_ARGS__>)
-    MSX_R(2, 2, 256, false, false, false); MSX_R(2, 2, 256, false, true, false); MSX_R(2, 2, 256, false, true, true);
-    MSX_R(2, 2, 512, false, false, false); MSX_R(2, 2, 512, false, true, false); MSX_R(2, 2, 512, false, false, true);
-    MSX_R(3, 2, 256, false, false, false); MSX_R(3, 2, 512, false, false, false); MSX_R(3, 2, 512, false, false, true);
-    MSX_R(2, 2, 512, false, false, false, true); MSX_R(3, 2, 512, false, false, false, true);  // linked
-#undef MSX_R
-    if (e == hipSuccess) e = raise_one(broaden_conv_kernel);
+    for (const Variant &v : kVariants)
+        if (e == hipSuccess && !v.gm) e = raise_one(v.fn);
+    if (e == hipSuccess) e = raise_one((const void *)broaden_conv_kernel);
     return e;
 }
 constexpr int kMaxDevices = 64;
@@ -995,36 +1075,13 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     A.ng_mode_fast = (int)std::min<int64_t>(Pc.ng, 0xff) | (mode << 8) | ((fast ? 1 : 0) << 16) | ((Pc.smp_on ? 1 : 0) << 17) |
                      ((Pc.dist_fit ? 1 : 0) << 18) | ((Pc.use_av ? 1 : 0) << 19);
 
-    // ---- which form of the path -------------------------------------------------------------------------
-    // linked (logprob_kernel<..., LK>): few walkers x long spectrum -- one workgroup per (walker, 8192-pixel segment); the
-    // walker's workgroups exchange their segments' partial sums and counters inside the kernel and each makes the chi^2 /
-    // median pass over its own segment, so a launch of <= #CUs / segments walkers uses segments x as many CUs and every
-    // workgroup's chain of latencies is 8192 pixels long.  Only the likelihood / posterior / chi^2 modes of a problem
-    // with a spectrum term and the register-resident recipe.  MSX_PATH_AUTO takes it while walkers x segments <= #CUs
-    // (one workgroup per CU: they wait for each other).  MSX_LINKED=0 / 1 in the environment: never / whenever possible.
-    // A context on which a meeting has once timed out is POISONED until the problem is staged again: AUTO takes the
-    // fused form, an explicit MSX_PATH_LINKED is refused (and the kernel itself fails every walker, for callers of
-    // this entry point who never looked at the statuses).
-    const bool can_link = c->d_seg_flag != nullptr && fast && !Pc.no_spectrum &&
-                          (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool linked = can_link && auto_takes_linked(c, n) && !c->smp_overlap_launch;
-    if (c->path == MSX_PATH_LINKED) {
-        if (!can_link) return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): needs a spectrum of 2..8 segments of 8192 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
-        if (c->linked_poisoned)
-            return fail(c, MSX_ERR_STATE, "msx_set_path(LINKED): a hand-over timed out on this context (MSX_W_HANDOVER); stage the problem again");
-        linked = true;
-    }
-    // pair (pair_kernel.h): many walkers -- two walkers of one grid cell per workgroup share one set of row loads
-    const bool can_pair = c->pair_rows > 0 && fast && !Pc.smp_on && Pc.nspec == 2 &&
-                          (mode == MSX_MODE_LOGLIKE || mode == MSX_MODE_LOGPOST || mode == MSX_MODE_CHISQ);
-    bool pair = can_pair && n >= c->pair_min_walkers && pair_worth_it(c);
+    // ---- which form of the path (decide_form) ---------------------------------------------------------------
+    const FormChoice form = decide_form(c, n, mode, false);
+    if (form.err != MSX_OK) return fail(c, form.err, form.msg);
+    const bool linked = form.linked, pair = form.pair;
     if (c->smp_overlap_launch) A.ng_mode_fast |= 1 << 20;
-    if (c->probe_launch) { A.ng_mode_fast |= 1 << 21; pair = false; }  // (the pair form carries no stamps)
-    if (c->path == MSX_PATH_FUSED || c->path == MSX_PATH_LINKED) pair = false;
-    if (c->path == MSX_PATH_PAIR) {
-        if (!can_pair) return fail(c, MSX_ERR_STATE, "msx_set_path(PAIR): needs a binary of <= 4096 pixels, the register-resident recipe and a likelihood / posterior / chi^2 mode");
-        pair = true;
-    }
+    if (c->probe_launch) A.ng_mode_fast |= 1 << 21;
+    c->last_form = pair ? MSX_FORM_PAIR : linked ? MSX_FORM_LINKED : MSX_FORM_FUSED;
     // sub-batches: the linked form's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
     // hold scratch_rows walkers; the pair form's spill rows pair_rows
     const int64_t step = pair ? c->pair_rows : (linked || c->model_in_global) ? c->scratch_rows : n;
@@ -1806,29 +1863,89 @@ int msx_stream_copy_gbps(msx_ctx *c, int64_t bytes, int32_t iters, double *gbps_
     return MSX_OK;
 }
 
+// bytes the form / variant an automatic launch of n walkers takes requests from the memory system, per walker
+static int64_t requested_bytes_of(msx_ctx *c, int64_t n, const FormChoice &f, const Variant *v) {
+    const int64_t npix = c->P.npix;
+    // the pair form: two walkers per set of loads -- rows, extinction terms, the fit sweep's data flux / u, the pass's three
+    // vectors -- + the planner's record
+    if (f.pair) return npix * (12 * 8 + 12 + 16 + 24) / 2 + (int64_t)sizeof(PairRec) + 8 * 6 + 12;
+    //   blend: 12-B {R f64, H f32} per corner + {k_lo f64, dk f32} + data flux, u (f64)        per pixel
+    //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
+    const bool pf = v && v->pf;
+    int64_t b = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
+    // the linked form: every segment's workgroup reads theta and writes its partials (counters, sums, range; chi^2 sum
+    // and candidates: <= 64 of them as a rule), reads the other segments' partials, and one of them their candidates
+    if (f.linked) {
+        const int64_t S = c->nseg, part = 4 * kSegBins + 64, fin = 16 + 8 * 64;
+        b += (S - 1) * (8 * (2 * c->P.nspec + 2)) + S * (part + fin) + S * (S - 1) * part + (S - 1) * fin;
+    }
+    return b;
+}
+
 int msx_bytes_per_eval(msx_ctx *c, int64_t n, int64_t *requested_bytes) {
     if (!c || !requested_bytes || n < 1) return MSX_ERR_INVALID;
     if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_bytes_per_eval: no problem staged");
-    const int64_t npix = c->P.npix;
-    // what the variant an automatic launch of n walkers takes requests from the memory system, per walker:
-    //   blend: 12-B {R f64, H f32} per corner + {k_lo f64, dk f32} + data flux, u (f64)        per pixel
-    //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
-    const bool linked = auto_takes_linked(c, n);
-    const int64_t cus_ = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-    const bool q256pf = !linked && pick_block(c, n, npix) == 256 && c->P.nspec == 2 && c->pf256_ok && c->use_pf &&
-                        (c->q256 > 0 || (c->q256 < 0 && n <= 2 * cus_));
-    const bool pf = q256pf || (!linked && pick_block(c, n, npix) == 512 && takes_pf(c, n));
-    *requested_bytes = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
-    // the linked form: every segment's workgroup reads theta and writes its partials (counters, sums, range; chi^2 sum
-    // and candidates: <= 64 of them as a rule), reads the other segments' partials, and one of them their candidates
-    if (linked) {
-        const int64_t S = c->nseg, part = 4 * kSegBins + 64, fin = 16 + 8 * 64;
-        *requested_bytes += (S - 1) * (8 * (2 * c->P.nspec + 2)) + S * (part + fin) + S * (S - 1) * part + (S - 1) * fin;
+    const FormChoice f = decide_form(c, n, MSX_MODE_LOGPOST, true);
+    if (f.err != MSX_OK) return fail(c, f.err, f.msg);
+    const int64_t m = f.pair ? std::min<int64_t>(n, c->pair_rows) : (f.linked || c->model_in_global) && c->scratch_rows ? std::min<int64_t>(n, c->scratch_rows) : n;
+    const VariantChoice ch = choose_variant(c, c->P, m, f.linked ? 512 : pick_block(c, m, c->P.npix), false, f.linked);
+    *requested_bytes = requested_bytes_of(c, n, f, ch.v);
+    return MSX_OK;
+}
+
+int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, char *name, int32_t name_len, int64_t *out8) {
+    if (!c || !out8 || n < 1) return MSX_ERR_INVALID;
+    if (!c->problem_staged) return fail(c, MSX_ERR_STATE, "msx_launch_info: no problem staged");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool shared512 = block_threads == MSX_BLOCK_512_SHARED;
+    if (shared512) block_threads = 512;
+    if (block_threads != 0 && block_threads != 256 && block_threads != 512)
+        return fail(c, MSX_ERR_INVALID, "block_threads must be 0, 256, 512 or MSX_BLOCK_512_SHARED");
+    const FormChoice f = decide_form(c, n, mode, true);
+    if (f.err != MSX_OK) return fail(c, f.err, f.msg);
+    // (the first sub-batch stands for the launch: sub-batches only differ in their walker count)
+    const int64_t m = f.pair ? std::min<int64_t>(n, c->pair_rows) : (f.linked || c->model_in_global) && c->scratch_rows ? std::min<int64_t>(n, c->scratch_rows) : n;
+    std::string nm;
+    const void *fn = nullptr;
+    int64_t threads = 0, dyn = 0, grid = 0;
+    const Variant *v = nullptr;
+    if (f.pair) {
+        const bool nt2 = c->P.npair <= 2 * 512;
+        fn = nt2 ? (const void *)logprob_pair_kernel<512, 2, true> : (const void *)logprob_pair_kernel<512, 4, true>;
+        nm = std::string("pair_plan_kernel + logprob_pair_kernel<512 threads, ") + (nt2 ? "2" : "4") +
+             " element trips per lane> (planner: one thread per walker; two walkers of one grid cell per workgroup, one set of row loads, model values in registers; two workgroups per CU)";
+        threads = 512; grid = m;
+    } else {
+        const int B = f.linked ? 512 : block_threads > 0 ? block_threads : pick_block(c, m, c->P.npix);
+        const VariantChoice ch = choose_variant(c, c->P, m, B, shared512, f.linked);
+        if (!ch.v) return fail(c, MSX_ERR_STATE, "no kernel variant for this launch");
+        v = ch.v;
+        fn = v->fn;
+        threads = v->threads; dyn = (int64_t)ch.dyn_lds;
+        grid = f.linked ? ((m + 7) & ~7ll) * c->nseg : m;
+        nm = std::string("logprob_kernel<NS=") + std::to_string(v->ns) + ", " + std::to_string(v->threads) + " threads" +
+             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + "> (" + v->what + ")";
     }
-    // the pair form (MSX_PATH_AUTO from pair_min_walkers on, for an ensemble that pairs): two walkers per set of loads --
-    // rows, extinction terms, the fit sweep's data flux / u, the pass's three vectors -- + the planner's record
-    if (c->pair_rows > 0 && c->P.nspec == 2 && n >= c->pair_min_walkers && c->path != MSX_PATH_FUSED && c->path != MSX_PATH_LINKED)
-        *requested_bytes = npix * (12 * 8 + 12 + 16 + 24) / 2 + (int64_t)sizeof(PairRec) + 8 * 6 + 12;
+    hipFuncAttributes at;
+    HIP_TRY(c, hipFuncGetAttributes(&at, fn));
+    out8[0] = f.pair ? MSX_FORM_PAIR : f.linked ? MSX_FORM_LINKED : MSX_FORM_FUSED;
+    out8[1] = threads;
+    out8[2] = at.numRegs;
+    out8[3] = (int64_t)at.sharedSizeBytes;
+    out8[4] = dyn;
+    out8[5] = requested_bytes_of(c, n, f, v);
+    out8[6] = grid;
+    out8[7] = m;
+    if (name && name_len > 0) {
+        strncpy(name, nm.c_str(), (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return MSX_OK;
+}
+
+int msx_last_form(msx_ctx *c, int32_t *form) {
+    if (!c || !form) return MSX_ERR_INVALID;
+    *form = c->last_form;
     return MSX_OK;
 }
 

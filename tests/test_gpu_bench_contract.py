@@ -56,3 +56,37 @@ def test_bench_launches_its_own_ranks_and_passes_the_line_through():
     assert j['n_gpus'] == 1 and j['n_ranks_seen'] == 1 and j['gather_verified'] is True
     assert j['walker_error_statuses'] == 0 and j['value'] > 0
     assert j['config']['collective'] != 'none' and 'multi_gpu_diag' in j
+
+
+def test_the_rooflines_kernel_name_comes_from_the_library():
+    """bench.py prints what msx_launch_info says -- the launcher's own variant table -- and mirrors nothing: no kernel
+    name is spelt out in bench.py, and the line's name / resources equal the library's answer for the same staged problem."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'logprob_kernel<' not in src and 'pick_block' not in src
+    j = _run('--no-cpu-baseline')
+    sys.path.insert(0, ROOT)
+    import bench
+    from mcmc_spec_amd import _lib
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    bench.build_workload(eng, 4096, False)
+    info = eng.ctx.launch_info(256, _lib.MODE_LOGPOST, 0)
+    r = j['roofline']
+    assert r['kernel'] == info['kernel'] and r['kernel'].startswith('logprob_kernel<NS=2, 512 threads, PF>')
+    assert r['requested_bytes_per_eval'] == info['requested_bytes_per_eval'] == eng.ctx.bytes_per_eval(256)
+    assert r['kernel_resources']['vgprs'] == info['vgprs'] and r['kernel_resources']['form'] == 'fused'
+    assert j['storage'] == {k: j['storage'][k] for k in j['storage']} and j['storage']['R'] == 'f64' and j['storage']['H'] == 'f32' and j['storage']['dk'] == 'f32'
+    assert j['clock_probe']['shader_mhz'] > 500 and 5 < j['clock_probe']['walker_us_median'] < j['roofline']['kernel_ms'] * 1e3
+    # the forms: what a launch WOULD take (launch_info) is what it TOOK (last_form), for the batch sizes of the sweep
+    import torch
+    from mcmc_spec_amd import synth
+    dev = torch.device('cuda', 0)
+    for m in (128, 2048, 4096):
+        th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=3000.0, tmax=5500.0)).to(dev)
+        lp, st = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
+        would = eng.ctx.launch_info(m)
+        for _ in range(3):   # (MSX_PATH_AUTO's evidence is the planner's count of an earlier launch)
+            eng.ctx.logprob_batch_dev(th.data_ptr(), m, 6, lp.data_ptr(), st.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        assert eng.ctx.last_form() == would['form_id'], (m, would)
+    assert eng.ctx.launch_info(4096)['form'].startswith('pair') and eng.ctx.launch_info(2048)['form'] == 'fused'

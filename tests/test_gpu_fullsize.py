@@ -32,7 +32,17 @@ def test_full_size_matches_oracle_and_cpu_broadening(work):
     from mcmc_spec_amd import synth
     from oracle import mft6_oracle as orc
     eng, W, npix, phot = work
-    th = synth.draw_walkers(4, seed=11, tmin=W['tmin'], tmax=W['tmax'])
+    # 64 walkers of the benched ensemble against the oracle (4 ms each), among them the corners of the path:
+    th = synth.draw_walkers(64, seed=11, tmin=W['tmin'], tmax=W['tmax'])
+    th[1, 2] = 1e-12                    # A_V -> 0+ : reddened with a factor that rounds to 1 (mft6.py:1161 takes the branch)
+    th[2, 2] = 0.0                      # A_V = 0 exactly: the unreddened branch
+    th[3, 0] = 3800.0                   # Teff on a grid node: both Teff brackets are that node (mft6.py:441-443)
+    th[4, 1] = 3000.0                   # ... the FIRST node, where the prior's box ends
+    th[5, 0], th[5, 1] = 3900.0, 3100.0  # both stars on nodes
+    th[6, 0] = 3849.999999999           # a hair below the midpoint between two nodes / (7) above it: nearest node flips
+    th[7, 0] = 3850.000000001
+    th[8, 3] = 0.04                     # a walker the prior box rejects (R1 < 0.05, mft6.py:1227): -inf, its neighbours untouched
+    th[9, 5] = 1.0                      # ... and one by the parallax bound
     got = eng.logposterior(th)
     specs = synth.grid_to_specs(W['teffs'], W['loggs'], W['wl'], W['flux'])
     specs = orc.broaden_specs_window(specs, W['win'], W['resolution'])
@@ -46,7 +56,14 @@ def test_full_size_matches_oracle_and_cpu_broadening(work):
     want = np.array([orc.logposterior(list(t), W['fr'], 2, W['data'], W['err'], W['r'], specs, W['ctm'], W['ptm'],
                                       W['tmi'], W['tma'], W['tmin'], W['tmax'], W['matrix'], avp, prior=W['prior'],
                                       bandlib=bl) for t in th])
-    assert rel_err(got, want).max() < TIGHT
+    assert np.isneginf(want[8]) and np.isneginf(want[9]) and np.array_equal(np.isneginf(got), np.isneginf(want))
+    fin = np.isfinite(want)
+    assert fin.sum() == 62 and rel_err(got[fin], want[fin]).max() < TIGHT
+    # the likelihood alone (no prior terms to dominate the sum) holds the same bar
+    ll = eng.loglikelihood(th[fin][:16])
+    want_ll = np.array([orc.loglikelihood(list(t), W['fr'], 2, W['data'], W['err'], W['r'], specs, W['ctm'], W['ptm'], W['tmi'],
+                                          W['tma'], W['matrix'], bandlib=bl) for t in th[fin][:16]])
+    assert rel_err(ll, want_ll).max() < TIGHT
     # the device-broadened node equals the CPU restatement of mft6.py:366-378 (incl. edge patches)
     node = eng.ctx.read_node(8, 2)
     assert rel_err(node, specs['{}, {}'.format(int(W['teffs'][8]), float(W['loggs'][2]))]).max() < 1e-12
@@ -97,3 +114,21 @@ def test_broadening_is_linear_and_preserves_flat_spectra():
     flat = ctx.broaden(wl, np.ones_like(wl), 1700)
     assert np.max(np.abs(flat[500:-500] - 1.0)) < 1e-13
     assert np.all(flat[:5] == flat[5]) and np.all(flat[-10:] == flat[-11])  # mft6.py:129-130
+
+
+def test_device_ccm89_matches_the_papers_table3():
+    """ccm89_kernel (A7: the staged extinction curve) against Cardelli, Clayton & Mathis 1989, Table 3 -- the same rows
+    tests/test_oracle_golden.py holds the oracle to."""
+    from mcmc_spec_amd._lib import Context
+    from test_oracle_golden import check_ccm89_against_table3
+    ctx = Context(0)
+    check_ccm89_against_table3(lambda wl, rv: ctx.ccm89_k(wl, rv))
+
+
+def test_device_broadening_of_a_gaussian_line_is_the_analytic_convolution():
+    """broaden_conv_kernel + broaden_patch_kernel (A3) on the one case with a closed form: a Gaussian line of width s
+    comes out with width sqrt(s^2 + sigma^2) and its equivalent width (tests/test_oracle_golden.py: the oracle likewise)."""
+    from mcmc_spec_amd._lib import Context
+    from test_oracle_golden import check_broadened_gaussian_line
+    ctx = Context(0)
+    check_broadened_gaussian_line(lambda wl, f, r: ctx.broaden(wl, f, r))

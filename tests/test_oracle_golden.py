@@ -108,6 +108,72 @@ def test_ccm89_known_values():
     assert np.all(f < 1) and f[0] < f[1]
 
 
+# Cardelli, Clayton & Mathis 1989, Table 3: the standard bands' x (1 / micron), a(x), b(x) and A(lambda) / A(V) at
+# R_V = 3.1 -- the one published set of numbers for the law `extinction.ccm89` evaluates (mft6.py:62-63).  The B row of
+# the table is inconsistent with the paper's own polynomial (1.337 against 1.3226: known); H, K, L are the table's
+# rounding of the IR power law.  tests/test_gpu_parity.py holds the device's ccm89_kernel to the same rows.
+CCM89_TABLE3 = {  # band: (x, a, b, A/A_V)
+    'U': (2.78, 0.9530, 1.9090, 1.569), 'B': (2.27, 0.9982, 1.0495, 1.337), 'V': (1.82, 1.0000, 0.0000, 1.000),
+    'R': (1.43, 0.8686, -0.3660, 0.751), 'I': (1.11, 0.6800, -0.6239, 0.479), 'J': (0.80, 0.4008, -0.3679, 0.282),
+    'H': (0.63, 0.2693, -0.2473, 0.190), 'K': (0.46, 0.1615, -0.1483, 0.114), 'L': (0.29, 0.0800, -0.0734, 0.056),
+}
+
+
+def check_ccm89_against_table3(k_of_wl_rv):
+    """`k_of_wl_rv(wl_angstrom, r_v)` -> a + b / r_v.  A mistyped polynomial coefficient fails here: the optical
+    polynomials are sampled at y = x - 1.82 = 0.96, 0.45, 0, -0.39, -0.71 and the IR power law at three more points."""
+    for band, (x, a, b, k31) in CCM89_TABLE3.items():
+        wl = np.array([1e4 / x])
+        k1, k2 = float(k_of_wl_rv(wl, 3.1)[0]), float(k_of_wl_rv(wl, 5.0)[0])
+        tol = 2e-2 if band == 'B' else 3e-3
+        assert abs(k1 - k31) < tol, (band, k1, k31)
+        bb = (k1 - k2) / (1 / 3.1 - 1 / 5.0)      # a + b / R_V at two R_V pins a and b separately
+        aa = k1 - bb / 3.1
+        if band in 'UVRIJ':                        # (rows whose a, b columns the paper's formulas reproduce to the table's digits)
+            assert abs(aa - a) < 1.5e-3 and abs(bb - b) < 1.5e-3, (band, aa, a, bb, b)
+        else:
+            assert abs(aa - a) < (5e-3 if band != 'B' else 2e-2) and abs(bb - b) < (5e-3 if band != 'B' else 6e-2), (band, aa, a, bb, b)
+
+
+def test_ccm89_matches_the_papers_table3():
+    check_ccm89_against_table3(lambda wl, rv: orc.ccm89(wl, 1.0, rv))
+    # continuity of the law where its branches meet (x = 1.1: IR power law | optical polynomial)
+    lo, hi = orc.ccm89(np.array([1e4 / (1.1 - 1e-9)]), 1.0, 3.1)[0], orc.ccm89(np.array([1e4 / (1.1 + 1e-9)]), 1.0, 3.1)[0]
+    assert abs(lo - hi) < 2e-3
+
+
+def gaussian_line_case(resolution=1700.0, s=1.4, depth=0.55):
+    """A Gaussian absorption line of width s on a flat continuum, and what a Gaussian instrumental profile of
+    sigma = mean(wl) / R / (2 sqrt(2 ln 2)) must turn it into: the same line with width sqrt(s^2 + sigma^2) and its
+    equivalent width preserved (depth x s / sqrt(s^2 + sigma^2)) -- the analytic convolution, exact up to the kernel's
+    truncation at 5 sigma (erfc(5 / sqrt 2) = 5.7e-7) and the 0.2 A sampling (s / dx = 7: negligible)."""
+    wl = np.arange(6400.0, 8400.0, 0.2)
+    l0 = 7400.0
+    flux = 1.0 - depth * np.exp(-0.5 * ((wl - l0) / s) ** 2)
+    sigma = np.mean(wl) / resolution / (2 * np.sqrt(2 * np.log(2)))
+    w = np.hypot(s, sigma)
+    want = 1.0 - depth * (s / w) * np.exp(-0.5 * ((wl - l0) / w) ** 2)
+    return wl, flux, want, sigma
+
+
+def check_broadened_gaussian_line(broaden_fn):
+    wl, flux, want, sigma = gaussian_line_case()
+    got = np.asarray(broaden_fn(wl, flux, 1700.0))
+    mid = slice(500, -500)                                  # away from the zero-padded, patched edges (mft6.py:129-130)
+    assert np.max(np.abs(got[mid] - want[mid])) < 5e-6      # of a line 0.33 deep after broadening
+    # second moment of the broadened line = s^2 + sigma^2 (what "Gaussian of width sigma" means), to 1e-4
+    d = 1.0 - got[mid]
+    x = wl[mid] - 7400.0
+    assert abs(np.sum(d * x * x) / np.sum(d) - (1.4 ** 2 + sigma ** 2)) < 1e-4 * (1.4 ** 2 + sigma ** 2)
+    # ... and the equivalent width is the unbroadened line's
+    assert abs(np.sum(d) - np.sum(1.0 - flux[mid])) < 1e-5 * np.sum(d)
+
+
+def test_broadening_of_a_gaussian_line_is_the_analytic_convolution():
+    """pyasl.instrBroadGaussFast restated (mft6.py:124-152): pinned to the one case with a closed form."""
+    check_broadened_gaussian_line(lambda wl, f, r: orc.broaden(wl, f, r)[1])
+
+
 def test_triple_system_ndim8():
     c = golden_case('C')
     g = c.g
