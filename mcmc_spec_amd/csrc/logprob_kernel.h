@@ -561,6 +561,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
         static_assert(!PF || kQuad, "PF: u and the data flux come from LDS (staged in phase 0; the quad trips read them there)");
         const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
+        unsigned int fxs[U] = {0u, 0u};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (ok[u]) {
@@ -573,9 +574,10 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 const unsigned int fx = (unsigned int)__double2hiint(m) >> 12;
                 fmin_ = fx < fmin_ ? fx : fmin_;
                 fmax_ = fx > fmax_ ? fx : fmax_;
-                if (early) atomicAdd(&S.hist[fx & (unsigned int)(kLogBins - 1)], 1u);
+                fxs[u] = fx;
             }
         }
+        if (early) hist_add_pair(S.hist, fxs[0], ok[0], fxs[1], ok[1]);  // (odd lanes in the other order: median.h)
       };
       // The trips of this segment, compiled twice: with the reddening terms (H rows, k, dk, the exp2) and without
       // (A_V <= 0: R rows only).  `redden` is uniform over the workgroup; as a run-time flag inside the loop it cost a

@@ -153,6 +153,7 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
             const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
             const bool ok[2] = {live && pa < npix, live && pb < npix};
             const double mm[2] = {m2.x, m2.y}, ff[2] = {f2.x, f2.y}, uu[2] = {u2.x, u2.y};
+            unsigned int fxs[2] = {0u, 0u};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (ok[u]) {
@@ -160,9 +161,10 @@ logprob_pair_kernel(const double *theta, const unsigned char *__restrict__ rblk,
                     const unsigned int fx = (unsigned int)__double2hiint(mm[u]) >> 12;
                     fmin[s] = fx < fmin[s] ? fx : fmin[s];
                     fmax[s] = fx > fmax[s] ? fx : fmax[s];
-                    atomicAdd(&S[s].hist[fx & (unsigned int)(kLogBins - 1)], 1u);
+                    fxs[u] = fx;
                 }
             }
+            hist_add_pair(S[s].hist, fxs[0], ok[0], fxs[1], ok[1]);  // (odd lanes in the other order: median.h)
         };
         {
             auto trip = [&](auto j_c) __attribute__((always_inline)) {
