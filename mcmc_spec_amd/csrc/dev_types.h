@@ -111,7 +111,14 @@ struct DevProblem {
     // double-buffered by version parity (smp_coords = [2][nw][ndim], smp_stride = nw * ndim) and published per walker
     int32_t smp_overlap;
     int64_t smp_stride;
-    uint32_t *smp_ver;                      // [nw] updates of each walker so far
+    uint32_t *smp_ver;                      // [nw] (rounds 2-3: the version word behind the data; unused since the granules)
+    // ... handed over as TAGGED GRANULES: what a move reads of a walker -- its coordinates, its log-probability, its
+    // acceptance count -- lives once more in smp_gran[version & 1][walker][kGranPerWalker], every 8-byte word {32 bits of
+    // payload | the walker's version}, written by ONE agent-scope store each.  A reader polls the words it wants until they
+    // carry the version the move is defined on: the load that sees the tag has the data -- no flag behind the data, no wait
+    // for store acknowledgements on the writer's side, no acquire + second round trip on the reader's.
+    unsigned long long *smp_gran;
+    int64_t smp_gwalkers;                   // nw (words per parity buffer = nw * kGranPerWalker)
     // clock probe (msx_probe_launch; bit 21 of the packed launch word): thread 0 of a walker's workgroup leaves the 100 MHz
     // wall clock and the shader-cycle counter at its first and last line -- [walker][4] for the first kProbeWalkers
     // walkers: the clock the CUs ran at under THIS kernel's load, and the walker's own time inside the launch
@@ -121,6 +128,12 @@ struct DevProblem {
 #endif
 };
 constexpr int kProbeWalkers = 4096;
+// granules of one walker (smp_gran): coordinate d = words 2 d (high half) and 2 d + 1 (low half); then the log-probability's
+// two halves and the low 32 bits of the acceptance count
+constexpr int kGranPerWalker = 2 * MSX_MAX_DIM + 4, kGranLogp = 2 * MSX_MAX_DIM, kGranNacc = 2 * MSX_MAX_DIM + 2;
+__host__ __device__ inline unsigned long long granule(unsigned int payload, unsigned int version) {
+    return ((unsigned long long)payload << 32) | (unsigned long long)version;
+}
 
 #ifdef MSX_STAMPS
 __shared__ int msx_stamp_off;  // linked form: one of a walker's workgroups writes the stamps

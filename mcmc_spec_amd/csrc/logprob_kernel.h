@@ -66,11 +66,12 @@ struct SmpView {
     double *smp_coords, *smp_logp, *smp_chain_row, *smp_lp_row;
     int64_t *smp_naccept;
     int32_t *smp_worst;
-    uint32_t *smp_ver;
+    unsigned long long *smp_gran;
+    int64_t smp_gwalkers;
 };
 __device__ __forceinline__ SmpView smp_view(const DevProblem &P, bool probe) {
     return {probe ? P.clk_probe : nullptr, P.smp_on, P.smp_defer, P.smp_overlap, P.linked_fault, P.smp_stride, P.smp_coords, P.smp_logp, P.smp_chain_row,
-            P.smp_lp_row, P.smp_naccept, P.smp_worst, P.smp_ver};
+            P.smp_lp_row, P.smp_naccept, P.smp_worst, P.smp_gran, P.smp_gwalkers};
 }
 __device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &D, int64_t wk, int ndim, double out, int st,
                             double *__restrict__ logp, int32_t *__restrict__ status) {
@@ -89,24 +90,39 @@ __device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &
     const double lnpdiff = (D.smp_zfac + out) - D.smp_old;
     const bool acc = D.smp_logu < lnpdiff;
     if (P.smp_overlap) {
-        // Overlapped half-steps: the next half-step's workgroups are already resident and wait for THIS walker's next
-        // version.  The state goes out with agent-scope stores (through the L2, like the linked form's partials), into
-        // the coordinate buffer of the new version's parity -- accepted or not: the other buffer still holds what
-        // workgroups of the half-steps in flight may be reading -- and then the version itself.
-        double *row = P.smp_coords + (int64_t)((D.smp_ver + 1u) & 1u) * P.smp_stride + s * ndim;
+        // Overlapped half-steps: the next half-step's workgroups are already resident and poll for THIS walker's next
+        // version.  What they read goes out as tagged granules (DevProblem::smp_gran): every word {32 bits | new version}
+        // by one agent-scope store (through the L2, like the linked form's partials), into the buffer of the new version's
+        // parity -- accepted or not: the other buffer still holds what workgroups of the half-steps in flight may be
+        // reading.  No wait for the stores' acknowledgements and no flag behind them: a word that shows the version IS the
+        // data.  (Rounds 1-3: data, vmcnt(0), then a version word; the reader polled the word, acquired and fetched the
+        // data -- two more trips through the fabric per hand-over.)
+        const unsigned int nv = D.smp_ver + 1u;
+        const double newlp = acc ? out : D.smp_old;
+        const long long nacc = D.smp_nacc + (acc ? 1 : 0);
+        // (test hook: nobody publishes, so every wait of the following half-steps runs into its bound)
+        if (!P.linked_fault) {
+            unsigned long long *g = P.smp_gran + ((int64_t)(nv & 1u) * P.smp_gwalkers + s) * kGranPerWalker;
+            for (int d = 0; d < ndim; ++d) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(acc ? D.theta[d] : D.smp_sv[d]);
+                publish_u64(g + 2 * d, granule((unsigned int)(b >> 32), nv));
+                publish_u64(g + 2 * d + 1, granule((unsigned int)b, nv));
+            }
+            const unsigned long long lb = (unsigned long long)__double_as_longlong(newlp);
+            publish_u64(g + kGranLogp, granule((unsigned int)(lb >> 32), nv));
+            publish_u64(g + kGranLogp + 1, granule((unsigned int)lb, nv));
+            publish_u64(g + kGranNacc, granule((unsigned int)nacc, nv));
+        }
+        // ... and the plain arrays the host reads when the chunk is over (nobody on the device waits for these)
+        double *row = P.smp_coords + (int64_t)(nv & 1u) * P.smp_stride + s * ndim;
         for (int d = 0; d < ndim; ++d) {
             const double v = acc ? D.theta[d] : D.smp_sv[d];
-            publish_u64(reinterpret_cast<unsigned long long *>(row + d), (unsigned long long)__double_as_longlong(v));
+            row[d] = v;
             P.smp_chain_row[s * ndim + d] = v;
         }
-        if (acc) {
-            publish_u64(reinterpret_cast<unsigned long long *>(P.smp_logp + s), (unsigned long long)__double_as_longlong(out));
-            publish_u64(reinterpret_cast<unsigned long long *>(P.smp_naccept + s), (unsigned long long)(D.smp_nacc + 1));
-        }
-        P.smp_lp_row[s] = acc ? out : D.smp_old;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (test hook: nobody publishes, so every wait of the following half-steps runs into its bound)
-        if (!P.linked_fault) __hip_atomic_store(P.smp_ver + s, D.smp_ver + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.smp_logp[s] = newlp;
+        P.smp_naccept[s] = nacc;
+        P.smp_lp_row[s] = newlp;
         return;
     }
     if (acc) {
@@ -366,33 +382,72 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // accept step's inputs (the walker's own entries) -- first waits until the walkers it reads have reached the
         // versions the move is defined on (bounded: then the chunk reports MSX_W_HANDOVER), acquires, and takes version
         // v of a walker from coordinate buffer v & 1.
-        int64_t own_off = 0, par_off = 0;
-        if (overlap && wave <= NS) {
-            const unsigned long long t0 = wall_clock64();
-            // (no s_sleep between the looks; the clock is read at every one.  Measured against a 64-cycle sleep per look and
-            // against reading the clock every 16th look only: 30.6-31.2 us per iteration at 256 walkers in every run,
-            // where those two gave 30.7-33.4 and 30.9-34.7 -- the run-to-run spread of the chain is larger than the
-            // differences between them.)
-            for (;;) {
-                const unsigned int vo = __hip_atomic_load(P.smp_ver + rc.si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int vp = wave < NS ? __hip_atomic_load(P.smp_ver + rc.ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rc.ver_partner;
-                // (versions only grow; a walker is never more than one version ahead of what this move wants)
-                if ((int)(vo - rc.ver_own) >= 0 && (int)(vp - rc.ver_partner) >= 0) break;
-                if (wall_clock64() - t0 > kHandoverTicks) {
-                    if (lane == 0) atomicMax(P.smp_worst, MSX_W_HANDOVER);
-                    break;
+        if (overlap) {
+            // TAGGED GRANULES (DevProblem::smp_gran): lane l of a recipe wave watches word l of the walker's own record
+            // (l < 2 ndim: the two halves of coordinate l / 2) or of its partner's (the next 2 ndim lanes); the wave that
+            // fetches the accept step's inputs watches the walker's log-probability and acceptance count.  A lane polls its
+            // word until it carries the version the move is defined on -- version v of a walker lives in buffer v & 1 --
+            // and then HAS the data: the words are put together with readlanes, no second load.
+            if (wave <= NS) {
+                constexpr int NG = 2 * ndim;
+                const bool rw = wave < NS;
+                const bool mine = rw ? lane < 2 * NG : lane < 3;
+                const bool par = rw && lane >= NG;
+                const int gi = rw ? (par ? lane - NG : lane) : (kGranLogp + lane);
+                const unsigned int want = par ? rc.ver_partner : rc.ver_own;
+                const unsigned long long *gp = P.smp_gran + ((int64_t)(want & 1u) * P.smp_gwalkers + (par ? rc.ci : rc.si)) * kGranPerWalker + (mine ? gi : 0);
+                unsigned long long g = 0ull;
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    if (mine) g = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (versions only grow, and a walker is never more than one version ahead of what this move wants: the
+                    // buffer of that parity holds this version or the one two before it)
+                    if (__ballot(!mine || (unsigned int)g == want) == ~0ull) break;
+                    if (wall_clock64() - t0 > kHandoverTicks) {
+                        if (lane == 0) atomicMax(P.smp_worst, MSX_W_HANDOVER);
+                        break;
+                    }
+                }
+                const int piece = (int)(unsigned int)(g >> 32);
+                if (rw) {
+#pragma clang fp contract(off)
+                    // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
+                    // the device-resident and the host-driven sampler stay in lock-step.  Lane k < ndim puts coordinate k
+                    // together from the four lanes that hold its halves (one cross-lane permute each) and is then exactly
+                    // where the plain load of the other paths leaves it.
+                    const int s_hi = __shfl(piece, 2 * lane), s_lo = __shfl(piece, 2 * lane + 1);
+                    const int c_hi = __shfl(piece, NG + 2 * lane), c_lo = __shfl(piece, NG + 2 * lane + 1);
+                    if (lane < ndim) {
+                        const double sv = __hiloint2double(s_hi, s_lo), cv = __hiloint2double(c_hi, c_lo);
+                        const double diff = cv - sv;
+                        const double prod = diff * rc.zz;
+                        const double qv = cv - prod;
+                        theta_lane = qv;
+                        if (wave == 0) {
+                            D.theta[lane] = qv;
+                            D.smp_sv[lane] = sv;
+                            P.smp_q[wk * ndim + lane] = qv;  // (kept for inspection; nothing reads it back)
+                        }
+                    }
+                } else {
+                    const double old = __hiloint2double(__builtin_amdgcn_readlane(piece, 0), __builtin_amdgcn_readlane(piece, 1));
+                    const unsigned int na = (unsigned int)__builtin_amdgcn_readlane(piece, 2);
+                    if (lane == 0) {
+                        D.smp_s = rc.si;
+                        D.smp_ver = rc.ver_own;
+                        D.smp_old = old;
+                        D.smp_nacc = (int64_t)na;   // (the low 32 bits travel; the host's 64-bit count is the plain array's)
+                        D.smp_zfac = P.smp_zfac[wk];
+                        D.smp_logu = P.smp_logu[wk];
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            own_off = (int64_t)(rc.ver_own & 1u) * P.smp_stride;
-            par_off = (int64_t)(rc.ver_partner & 1u) * P.smp_stride;
-        }
-        if (wave < NS && lane < ndim) {
+        } else if (wave < NS && lane < ndim) {
 #pragma clang fp contract(off)
             // no FMA contraction: the proposal must have the bits NumPy's `c - (c - s) * z` produces so that
             // the device-resident and the host-driven sampler stay in lock-step
-            const double sv = theta[own_off + (int64_t)rc.si * ndim + lane];
-            const double cv = theta[par_off + (int64_t)rc.ci * ndim + lane];
+            const double sv = theta[(int64_t)rc.si * ndim + lane];
+            const double cv = theta[(int64_t)rc.ci * ndim + lane];
             const double diff = cv - sv;
             const double prod = diff * rc.zz;
             const double qv = cv - prod;

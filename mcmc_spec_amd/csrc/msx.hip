@@ -1260,6 +1260,7 @@ struct SamplerRun {
     hipEvent_t hs_done[4] = {nullptr, nullptr, nullptr, nullptr}, chunk_open = nullptr, s2_done = nullptr;
     int64_t steps_done = 0;         // iterations queued so far = every walker's version when they are done
     uint32_t *d_ver = nullptr;
+    unsigned long long *d_gran = nullptr;  // [2][nw][kGranPerWalker] the hand-over's tagged granules (dev_types.h)
     struct Slot {
         char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
         hipEvent_t in_ready = nullptr, kernels_done = nullptr, out_ready = nullptr;
@@ -1324,8 +1325,10 @@ int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_
     r->mode = mode; r->ndim = ndim; r->nw = nw; r->ns = nw / 2; r->cap_steps = max_chunk_steps;
     const int64_t ns = r->ns;
     // (two coordinate buffers, two half-steps' worth of per-launch outputs: overlapped half-steps)
+    const size_t gran_words = (size_t)(2 * nw * kGranPerWalker);
+    std::vector<unsigned long long> hg;  // (lives until the stream has been synchronised below)
     const size_t state_bytes = sizeof(double) * (size_t)(2 * nw * ndim + nw + 2 * ns * ndim + 2 * ns) + sizeof(int64_t) * (size_t)nw +
-                               sizeof(int32_t) * (size_t)(2 * ns) + sizeof(uint32_t) * (size_t)nw + 64;
+                               sizeof(int32_t) * (size_t)(2 * ns) + sizeof(uint32_t) * (size_t)nw + 64 + sizeof(unsigned long long) * gran_words;
     hipError_t e = hipMalloc((void **)&r->d_state, state_bytes);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_state, 0, state_bytes, c->stream);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking);
@@ -1348,7 +1351,27 @@ int msx_sampler_begin(msx_ctx *c, int32_t mode, int64_t nw, int32_t ndim, int64_
         r->d_coords = (double *)r->d_state; r->d_logp = r->d_coords + 2 * nw * ndim; r->d_q = r->d_logp + nw;
         r->d_newlp = r->d_q + 2 * ns * ndim; r->d_nacc = (int64_t *)(r->d_newlp + 2 * ns); r->d_wst = (int32_t *)(r->d_nacc + nw);
         r->d_ver = (uint32_t *)(r->d_wst + 2 * ns);
+        r->d_gran = (unsigned long long *)(((uintptr_t)(r->d_ver + nw) + 15) & ~(uintptr_t)15);
         e = hipMemcpyAsync(r->d_coords, coords, sizeof(double) * nw * ndim, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) {
+        // the granules of version 0 (buffer 0); buffer 1 carries a version nobody asks for until it is written
+        hg.assign(gran_words, granule(0u, 0xffffffffu));
+        for (int64_t w = 0; w < nw; ++w) {
+            unsigned long long *g = hg.data() + (size_t)w * kGranPerWalker;
+            for (int d = 0; d < ndim; ++d) {
+                unsigned long long b;
+                memcpy(&b, &coords[w * ndim + d], 8);
+                g[2 * d] = granule((unsigned int)(b >> 32), 0u);
+                g[2 * d + 1] = granule((unsigned int)b, 0u);
+            }
+            unsigned long long lb;
+            memcpy(&lb, &logp[w], 8);
+            g[kGranLogp] = granule((unsigned int)(lb >> 32), 0u);
+            g[kGranLogp + 1] = granule((unsigned int)lb, 0u);
+            g[kGranNacc] = granule((unsigned int)(naccept ? naccept[w] : 0), 0u);
+        }
+        e = hipMemcpyAsync(r->d_gran, hg.data(), sizeof(unsigned long long) * gran_words, hipMemcpyHostToDevice, c->stream);  // (behind the memset)
     }
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_logp, logp, sizeof(double) * nw, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
@@ -1470,6 +1493,7 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     P.smp_on = 1;
     P.smp_coords = r->d_coords; P.smp_logp = r->d_logp; P.smp_q = r->d_q; P.smp_naccept = r->d_nacc; P.smp_worst = cp->d_worst;
     P.smp_overlap = r->overlap == 1; P.smp_stride = nw * ndim; P.smp_ver = r->d_ver;
+    P.smp_gran = r->d_gran; P.smp_gwalkers = nw;
     if (r->overlap == 1) {  // the second stream's launches of this chunk come after the chunk's inputs and the cleared status
         HIP_TRY(c, hipEventRecord(r->chunk_open, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(r->s2, r->chunk_open, 0));

@@ -59,15 +59,18 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
     """Every variant of the hot kernel must keep its working set in registers.  (The problem struct is a by-value
     kernel argument: a helper that stops being inlined makes the compiler copy all 1.2 KB of it into per-lane
     scratch, which doubled the kernel time once; every such helper is force-inlined.)  The variants capped at
-    168 / 128 VGPRs by their occupancy target (256 threads; 512 threads sharing a CU) may park a few dwords; nothing
-    else may."""
+    168 / 128 VGPRs by their occupancy target (256 threads; 512 threads sharing a CU) may park a few dwords; the others
+    may at most carry a small frame slot that NO instruction touches (the register allocator leaves one behind when a
+    variant at the 256-VGPR / 102-SGPR limits spills scalars into vector lanes): not one scratch instruction."""
     src = os.path.join(ROOT, 'mcmc_spec_amd', 'csrc', 'msx.hip')
     with tempfile.TemporaryDirectory() as d:
-        out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+        asm = os.path.join(d, 't.s')
+        out = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
                               '-mllvm', '-amdgpu-kernarg-preload-count=8',
-                              '-Rpass-analysis=kernel-resource-usage', '-o', os.path.join(d, 't.so'), src],
+                              '-Rpass-analysis=kernel-resource-usage', '-o', asm, src],
                              capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-2000:]
+        assert out.returncode == 0, out.stderr[-2000:]
+        text = open(asm).read()
     lines = out.stderr.splitlines()
     seen = 0
     for i, ln in enumerate(lines):
@@ -75,7 +78,12 @@ def test_hot_kernel_variants_do_not_spill_to_scratch():
             block = '\n'.join(lines[i:i + 14])
             m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', block)
             capped = 'Li256E' in ln or 'Li512ELb0ELb1E' in ln   # 256 threads, or 512 with SH (shared CU)
-            assert m and int(m.group(1)) <= (64 if capped else 0), block
+            assert m and int(m.group(1)) <= 64, block          # (the struct in scratch is > 1 KB)
+            if not capped:
+                name = re.search(r'Function Name: (\S+)', ln).group(1)
+                body = text[text.index('\n' + name + ':'):]
+                body = body[:body.index('.Lfunc_end')]
+                assert 'scratch_' not in body, name            # no instruction reads or writes scratch
             seen += 1
     assert seen >= 15   # binary + triple; 256 / 512 threads; global-model, shared-CU, LDS-staged variants; linked; pair + planner
 
