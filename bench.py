@@ -828,16 +828,22 @@ def main():
             # baseline: the chain's launches are issued by this host thread, and the baseline's pools leave the host busy
             from mcmc_spec_amd.sampler import DeviceEnsembleSampler
             p0 = synth.draw_walkers(args.walkers, seed=9, tmin=W['tmin'], tmax=W['tmax'])
-            smp = DeviceEnsembleSampler(args.walkers, p0.shape[1], eng, seed=1, chunk=100)
-            smp.run_mcmc(p0, 400, store=False)   # (clocks, the chunk sizes' ramp, the host's random-number threads)
             nit = 3000
-            t0 = time.perf_counter()
-            smp.run_mcmc(p0, nit, store=False)
-            dt = time.perf_counter() - t0
-            extra['dependent_chain'] = {'walkers': args.walkers, 'iterations': nit, 'us_per_iteration': dt / nit * 1e6,
-                                        'evals_per_s': args.walkers * nit / dt, 'overlapped_half_steps': bool(smp.overlapped),
-                                        'acceptance': float(smp.acceptance_fraction.mean()),
-                                        'note': 'wall time of run_mcmc, host randomness and chain download included'}
+            chain = {}
+            # 'device': the library draws the move's randomness on the GPU (counter-based generator, one launch per chunk,
+            # nothing uploaded); 'host': NumPy draws it, two threads, pipelined one chunk ahead -- the stream the host loop shares
+            for rng_mode in ('device', 'host'):
+                smp = DeviceEnsembleSampler(args.walkers, p0.shape[1], eng, seed=1, chunk=100, rng=rng_mode)
+                smp.run_mcmc(p0, 400, store=False)   # (clocks, the chunk sizes' ramp, the host's random-number threads)
+                t0 = time.perf_counter()
+                smp.run_mcmc(p0, nit, store=False)
+                dt_c = time.perf_counter() - t0
+                chain[rng_mode] = {'us_per_iteration': dt_c / nit * 1e6, 'evals_per_s': args.walkers * nit / dt_c,
+                                   'acceptance': float(smp.acceptance_fraction.mean()), 'overlapped_half_steps': bool(smp.overlapped)}
+            extra['dependent_chain'] = dict(chain['device'], walkers=args.walkers, iterations=nit, randomness='device (counter-based generator)',
+                                            host_randomness=chain['host'],
+                                            note='wall time of run_mcmc (chain download included); consecutive half-steps overlap on two '
+                                                 'streams, a walker is handed over as tagged 8-byte words (include/msx.h)')
         if want_cpu:
             th_cpu = synth.draw_walkers(8192, seed=77, tmin=W['tmin'], tmax=W['tmax'])
             g, st = eng.ctx.logprob_batch(th_cpu, _lib.MODE_LOGPOST)

@@ -217,16 +217,29 @@ int msx_sampler_begin(msx_ctx *ctx, int32_t mode, int64_t nw, int32_t ndim, int6
 int msx_sampler_shard(msx_ctx *ctx, int32_t rank, int32_t world);
 int msx_sampler_enqueue(msx_ctx *ctx, int32_t slot /* 0|1 */, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
                         const int32_t *partner, const double *zz, const double *zfac, const double *logu);
+/* The chunk's randomness drawn ON THE DEVICE instead of coming from the host: a counter-based generator (SplitMix64's
+ * output function over counters made of (seed, absolute iteration of the run, stream, index)) yields, per iteration, the
+ * random split of the ensemble into two halves (walkers sorted by a 64-bit key) and, per half-step and walker, the stretch
+ * factor z = ((a - 1) u + 1)^2 / a, the partner floor(u ns) in the complementary half and ln u of the accept draw -- the
+ * quantities msx_sampler_enqueue takes from the host (emcee's stretch move; mft6.py:1491-1494 drives it).  One launch per
+ * chunk, no upload; every rank of a sharded run draws the same numbers from the same seed.  Up to 4096 walkers.
+ * msx_sampler_draw returns the same stream to the host (arrays [nsteps][2][nw/2] as for msx_sampler_enqueue; `partner`
+ * indexes the complementary half): the host loop fed with it reproduces the device-drawn chain bit for bit
+ * (tests/test_gpu_overlap.py), and mcmc_spec_amd/sampler.py::counter_draws restates the generator in NumPy.           */
+int msx_sampler_enqueue_drawn(msx_ctx *ctx, int32_t slot, int64_t nsteps, uint64_t seed, double a);
+int msx_sampler_draw(msx_ctx *ctx, uint64_t seed, double a, int64_t first_iter, int64_t nsteps, int64_t nw, int32_t ndim,
+                     int32_t *sidx, int32_t *cidx, int32_t *partner, double *zz, double *zfac, double *logu);
 int msx_sampler_collect(msx_ctx *ctx, int32_t slot, double *chain_out, double *logp_out, int64_t *naccept,
                         int32_t *worst_status);
 int msx_sampler_end(msx_ctx *ctx, double *coords, double *logp);
 /* OVERLAPPED half-steps (one GPU, unsharded, a half-step of at most #CUs / 2 walkers through the fused kernel with one
  * workgroup per CU -- config 2's 256 walkers): consecutive half-steps go to two streams and run concurrently; a walker's
  * workgroup waits inside the kernel (bounded: 20 ms, then the chunk's worst_status is MSX_W_HANDOVER) until the two
- * walkers its move reads have reached the versions the move is defined on, the coordinates are double-buffered by
- * version parity and each finished walker publishes its new version -- so a half-step's launch, start-up and slowest
- * walker no longer sit between two dependent evaluations (256 walkers x 4096 px: 32.4 us per iteration; 34.3 against
- * 38.0 with plain launches when it was measured side by side).
+ * walkers its move reads have reached the versions the move is defined on; what a move reads of a walker is handed over
+ * as 8-byte words {32 bits of payload | version}, each written by one agent-scope store and double-buffered by version
+ * parity, so the load that sees the version has the data -- a half-step's launch, start-up and slowest walker no longer
+ * sit between two dependent evaluations (256 walkers x 4096 px: 28 us per iteration; 31.3 with a version word behind the
+ * data, 38.0 with plain launches).
  * Same chain, bit for bit.  Chosen by the first msx_sampler_enqueue of a run; MSX_SMP_OVERLAP=0 in the environment:
  * never.  *out = 1 if the run begun on ctx takes it, 0 if not, -1 before its first chunk.                           */
 int msx_sampler_overlapped(msx_ctx *ctx, int32_t *out);

@@ -106,6 +106,9 @@ def load():
         'msx_sampler_enqueue': (C.c_int, [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32), _dp, _dp, _dp]),
         'msx_sampler_collect': (C.c_int, [vp, C.c_int32, _dp, _dp, _ip, C.POINTER(C.c_int32)]),
+        'msx_sampler_enqueue_drawn': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_uint64, C.c_double]),
+        'msx_sampler_draw': (C.c_int, [vp, C.c_uint64, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),
         'msx_sampler_end': (C.c_int, [vp, _dp, _dp]),
         'msx_make_composite': (C.c_int, [vp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, _dp,
                                          C.POINTER(C.c_int32)]),
@@ -136,7 +139,7 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
             'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
-            'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
+            'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_enqueue_drawn', 'msx_sampler_draw', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_launch_info', 'msx_last_form', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped']
 
@@ -340,6 +343,23 @@ class Context:
                                                 arrs[1].ctypes.data_as(i32p), arrs[2].ctypes.data_as(i32p),
                                                 dptr(dbl[0]), dptr(dbl[1]), dptr(dbl[2])))
         return nsteps
+
+    def sampler_enqueue_drawn(self, slot, nsteps, seed, a=2.0):
+        """Queue one chunk whose randomness the device draws itself (msx_sampler_enqueue_drawn)."""
+        self.check(self.lib.msx_sampler_enqueue_drawn(self.h, int(slot), int(nsteps), int(seed) & 0xffffffffffffffff, float(a)))
+        return int(nsteps)
+
+    def sampler_draw(self, seed, a, first_iter, nsteps, nw, ndim):
+        """The device generator's stream for iterations [first_iter, first_iter + nsteps): (sidx, cidx, partner, zz, zfac,
+        logu), each (nsteps, 2, nw/2) -- what EnsembleSampler._draw_steps returns."""
+        i32p = C.POINTER(C.c_int32)
+        shp = (int(nsteps), 2, int(nw) // 2)
+        ints = [np.empty(shp, dtype=np.int32) for _ in range(3)]
+        dbl = [np.empty(shp) for _ in range(3)]
+        self.check(self.lib.msx_sampler_draw(self.h, int(seed) & 0xffffffffffffffff, float(a), int(first_iter), int(nsteps), int(nw), int(ndim),
+                                             ints[0].ctypes.data_as(i32p), ints[1].ctypes.data_as(i32p), ints[2].ctypes.data_as(i32p),
+                                             dptr(dbl[0]), dptr(dbl[1]), dptr(dbl[2])))
+        return tuple(ints) + tuple(dbl)
 
     def sampler_collect(self, slot, nsteps):
         """Wait for the chunk in `slot`: (chain [nsteps][nw][ndim], logp [nsteps][nw], naccept [nw], worst)."""

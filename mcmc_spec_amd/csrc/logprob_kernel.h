@@ -1146,6 +1146,99 @@ __global__ void sampler_apply_kernel(DevProblem P, const double *__restrict__ ne
     P.smp_lp_row[si] = acc ? out : old;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stretch move's randomness, drawn ON THE DEVICE (emcee's move as mft6.py:1491-1494 drives it): a
+// COUNTER-BASED generator -- every number is a pure function of (seed, iteration, stream, index), so a chunk is one
+// launch, any rank of a sharded run draws the same numbers without a broadcast, and the host can restate the stream
+// (mcmc_spec_amd/sampler.py::counter_draws) to check it.  The generator is SplitMix64's output function over the
+// counter sequence seed * K + (ctr + 1) * gamma (Steele, Lea & Flood 2014: the stream a SplitMix64 instance produces).
+// One workgroup per iteration:
+//   stream 0      one 64-bit key per walker; the walkers sorted by (key, index) are the iteration's random permutation,
+//                 its first half the first half-step's walkers, its second half their complementary ensemble (and the
+//                 other way round for the second half-step) -- emcee's randomised split
+//   streams 1..6  per half-step h and position j: u_z -> z = ((a - 1) u_z + 1)^2 / a, u_p -> partner floor(u_p ns),
+//                 u_a -> ln u_a of the accept draw
+// and writes the chunk's arrays exactly as the host-fed entry point uploads them (msx.hip, chunk_prepare).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned long long counter_mix64(unsigned long long seed, unsigned long long it, unsigned int stream,
+                                                           unsigned int index) {
+    const unsigned long long ctr = (it << 28) + ((unsigned long long)stream << 24) + (unsigned long long)index;
+    unsigned long long x = seed * 0xD1342543DE82EF95ull + (ctr + 1ull) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+__host__ __device__ inline double counter_uniform(unsigned long long seed, unsigned long long it, unsigned int stream, unsigned int index) {
+    return (double)(counter_mix64(seed, it, stream, index) >> 11) * (1.0 / 9007199254740992.0);  // [0, 1), 53 bits
+}
+constexpr int kDrawMaxWalkers = 4096;  // (key, index) pairs of one iteration sorted in LDS: 48 KB
+constexpr int kDrawThreads = 256;
+// resolve != 0: `partner` receives cidx[partner] (the ensemble index of the complementary walker: what the kernels read);
+// 0: the raw index into the complementary half (what the host loop consumes)
+__global__ void __launch_bounds__(kDrawThreads)
+sampler_draw_kernel(unsigned long long seed, double a, int64_t first_iter, int64_t nw, int32_t ndim, int32_t resolve, int32_t overlap,
+                    int32_t *__restrict__ sidx, int32_t *__restrict__ cidx, int32_t *__restrict__ partner, double *__restrict__ zz,
+                    double *__restrict__ zfac, double *__restrict__ logu, SmpRec *__restrict__ rec) {
+    __shared__ unsigned long long key[kDrawMaxWalkers];
+    __shared__ int32_t idx[kDrawMaxWalkers];
+    const int64_t st = blockIdx.x;  // iteration of the chunk
+    const unsigned long long it = (unsigned long long)(first_iter + st);
+    const int ns = (int)(nw / 2);
+    int npad = 1;
+    while (npad < nw) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += kDrawThreads) {
+        key[i] = i < nw ? counter_mix64(seed, it, 0u, (unsigned int)i) : ~0ull;  // (pads sort last: index >= nw breaks the tie)
+        idx[i] = i;
+    }
+    __syncthreads();
+    // bitonic sort of (key, index), ascending
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npad; i += kDrawThreads) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long ka = key[i], kb = key[l];
+                    const int32_t ia = idx[i], ib = idx[l];
+                    const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
+                    const bool up = (i & k) == 0;
+                    if (a_gt_b == up) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // the two half-steps of this iteration
+    const int64_t base = st * 2 * ns;
+    for (int t = threadIdx.x; t < 2 * ns; t += kDrawThreads) {
+#pragma clang fp contract(off)
+        const int h = t / ns, j = t - h * ns;
+        const int32_t s_w = idx[h * ns + j];                    // the moving walker
+        const int32_t *comp = idx + (1 - h) * ns;               // the complementary half
+        const double uz = counter_uniform(seed, it, 1u + 3u * (unsigned int)h, (unsigned int)j);
+        const double up = counter_uniform(seed, it, 2u + 3u * (unsigned int)h, (unsigned int)j);
+        const double ua = counter_uniform(seed, it, 3u + 3u * (unsigned int)h, (unsigned int)j);
+        const double t1 = (a - 1.0) * uz + 1.0;
+        const double z = (t1 * t1) / a;                         // emcee: ((a - 1) u + 1)^2 / a
+        int pj = (int)(up * (double)ns);
+        pj = pj < ns - 1 ? pj : ns - 1;
+        const int64_t o = base + t;
+        sidx[o] = s_w;
+        cidx[o] = comp[j];
+        partner[o] = resolve ? comp[pj] : pj;
+        zz[o] = z;
+        zfac[o] = ((double)ndim - 1.0) * log(z);
+        logu[o] = log(ua);                                      // (u = 0: -inf, accepted by nothing -- like log(random()))
+        if (rec) {
+            SmpRec r;
+            r.si = s_w; r.ci = comp[pj]; r.zz = z;
+            r.ver_own = overlap ? (uint32_t)it : 0u;
+            r.ver_partner = overlap ? (uint32_t)(it + (unsigned long long)h) : 0u;
+            rec[o] = r;
+        }
+    }
+}
+
 }  // namespace
 
 #endif  // MSX_LOGPROB_KERNEL_H

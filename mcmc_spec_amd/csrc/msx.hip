@@ -1419,12 +1419,18 @@ struct ChunkPtrs {
     int32_t *d_worst = nullptr;
 };
 
+// (draw != nullptr: the chunk's randomness is drawn on the device -- sampler_draw_kernel, keyed by draw->seed and the
+// run's absolute iteration numbers -- instead of coming from the host's arrays)
+struct DeviceDraw { unsigned long long seed; double a; };
 static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t *sidx, const int32_t *cidx,
-                         const int32_t *partner, const double *zz, const double *zfac, const double *logu, ChunkPtrs *cp) {
+                         const int32_t *partner, const double *zz, const double *zfac, const double *logu, ChunkPtrs *cp,
+                         const DeviceDraw *draw = nullptr) {
     SamplerRun *r = c->smp;
     if (!r) return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: call msx_sampler_begin first");
-    if (slot < 0 || slot > 1 || nsteps < 1 || nsteps > r->cap_steps || !sidx || !cidx || !partner || !zz || !zfac || !logu)
+    if (slot < 0 || slot > 1 || nsteps < 1 || nsteps > r->cap_steps || (!draw && (!sidx || !cidx || !partner || !zz || !zfac || !logu)))
         return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue: bad arguments");
+    if (draw && (r->nw > kDrawMaxWalkers || !(draw->a > 1.0)))
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_enqueue_drawn: the device generator takes up to 4096 walkers and a stretch scale a > 1");
     if (r->failed)
         return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue: an earlier enqueue failed part-way; end this run (msx_sampler_end) and begin again");
     SamplerRun::Slot &sl = r->slot[slot];
@@ -1432,6 +1438,25 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     HIP_TRY(c, hipSetDevice(c->device));
     const int64_t ns = r->ns, nw = r->nw, nh = nsteps * 2 * ns;
     const int ndim = r->ndim;
+    // Overlapped half-steps?  Decided once per run, here (sharding is set up after msx_sampler_begin): an unsharded run
+    // whose half-step takes the fused kernel (one workgroup per walker) and fills at most HALF the CUs -- two half-steps
+    // are resident together, and a workgroup that waits for a walker of the half-step before it must never keep that
+    // walker's workgroup off the chip.  MSX_SMP_OVERLAP=0 in the environment: never.
+    if (r->overlap < 0) {
+        const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+        const char *e = getenv("MSX_SMP_OVERLAP");
+        r->overlap = !(e && e[0] == '0') && !r->sharded && 2 * ns <= cus && !c->model_in_global && c->recipe_fast &&
+                     c->path != MSX_PATH_LINKED && c->path != MSX_PATH_PAIR && !auto_takes_linked(c, ns);
+    }
+    if (draw) {
+        // the chunk's arrays, written where the host-fed path uploads them: [zz | zfac | logu | sidx | cidx | partner | records]
+        double *g_zz = (double *)sl.d_in, *g_zfac = g_zz + nh, *g_logu = g_zfac + nh;
+        int32_t *g_sidx = (int32_t *)(g_logu + nh), *g_cidx = g_sidx + nh, *g_partner = g_cidx + nh;
+        SmpRec *g_rec = (SmpRec *)(g_partner + nh);
+        hipLaunchKernelGGL(sampler_draw_kernel, dim3((unsigned)nsteps), dim3(kDrawThreads), 0, c->stream, draw->seed, draw->a, r->steps_done,
+                           nw, (int32_t)ndim, 1, (int32_t)(r->overlap == 1), g_sidx, g_cidx, g_partner, g_zz, g_zfac, g_logu, g_rec);
+        HIP_TRY(c, hipGetLastError());
+    } else {
     // pinned staging, doubles first: [zz | zfac | logu | sidx | cidx | partner]
     double *hz = (double *)sl.h_in;
     int32_t *hi = (int32_t *)(hz + 3 * nh);
@@ -1445,17 +1470,6 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     // resolve partner -> ensemble index of the complementary walker here, so that the kernel's proposal needs
     // two dependent loads (index, coordinates) instead of three
     for (int64_t i = 0; i < nh; ++i) hi[2 * nh + i] = hi[nh + (i / ns) * ns + hi[2 * nh + i]];
-    // ... and the proposal's inputs once more as one record per walker (the kernel's first load)
-    // Overlapped half-steps?  Decided once per run, here (sharding is set up after msx_sampler_begin): an unsharded run
-    // whose half-step takes the fused kernel (one workgroup per walker) and fills at most HALF the CUs -- two half-steps
-    // are resident together, and a workgroup that waits for a walker of the half-step before it must never keep that
-    // walker's workgroup off the chip.  MSX_SMP_OVERLAP=0 in the environment: never.
-    if (r->overlap < 0) {
-        const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-        const char *e = getenv("MSX_SMP_OVERLAP");
-        r->overlap = !(e && e[0] == '0') && !r->sharded && 2 * ns <= cus && !c->model_in_global && c->recipe_fast &&
-                     c->path != MSX_PATH_LINKED && c->path != MSX_PATH_PAIR && !auto_takes_linked(c, ns);
-    }
     if (r->overlap == 1) {
         // the version protocol rests on every walker moving exactly once per iteration: the two half-steps' walkers must
         // be a permutation of the ensemble (emcee's random split is; checked here because a violation would not fail
@@ -1481,6 +1495,7 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     HIP_TRY(c, hipMemcpyAsync(sl.d_in, sl.h_in, r->in_bytes(nsteps), hipMemcpyHostToDevice, r->up));
     HIP_TRY(c, hipEventRecord(sl.in_ready, r->up));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.in_ready, 0));
+    }
     cp->nh = nh;
     cp->d_zz = (double *)sl.d_in; cp->d_zfac = cp->d_zz + nh; cp->d_logu = cp->d_zfac + nh;
     cp->d_sidx = (int32_t *)(cp->d_logu + nh); cp->d_cidx = cp->d_sidx + nh; cp->d_partner = cp->d_cidx + nh;
@@ -1609,6 +1624,53 @@ int msx_sampler_enqueue(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t 
             if (rc == MSX_OK) rc = chunk_half_apply(c);
         }
     return chunk_finish(c, slot, nsteps, cp, rc);
+}
+
+int msx_sampler_enqueue_drawn(msx_ctx *c, int32_t slot, int64_t nsteps, uint64_t seed, double a) {
+    if (!c) return MSX_ERR_INVALID;
+    if (c->smp && c->smp->sharded && c->smp->world > 1) {
+        if (!c->loop_peers.empty())
+            return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue_drawn: the ranks of a loopback group advance together (msx_sampler_enqueue_group)");
+        if (!c->rccl_comm || c->comm_world != c->smp->world)
+            return fail(c, MSX_ERR_STATE, "msx_sampler_enqueue_drawn: the run is sharded over a communicator that no longer exists");
+    }
+    ChunkPtrs cp;
+    const DeviceDraw dd = {(unsigned long long)seed, a};
+    int rc = chunk_prepare(c, slot, nsteps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &cp, &dd);
+    if (rc != MSX_OK) return rc;
+    for (int64_t st = 0; st < nsteps && rc == MSX_OK; ++st)
+        for (int half = 0; half < 2 && rc == MSX_OK; ++half) {
+            rc = chunk_half_eval(c, cp, st, half);
+            if (rc == MSX_OK && c->smp->sharded) rc = chunk_half_gather_rccl(c);
+            if (rc == MSX_OK) rc = chunk_half_apply(c);
+        }
+    return chunk_finish(c, slot, nsteps, cp, rc);
+}
+
+int msx_sampler_draw(msx_ctx *c, uint64_t seed, double a, int64_t first_iter, int64_t nsteps, int64_t nw, int32_t ndim,
+                     int32_t *sidx, int32_t *cidx, int32_t *partner, double *zz, double *zfac, double *logu) {
+    if (!c || !sidx || !cidx || !partner || !zz || !zfac || !logu || nsteps < 1 || nw < 2 || (nw & 1) || nw > kDrawMaxWalkers ||
+        first_iter < 0 || ndim < 1 || !(a > 1.0))
+        return fail(c, MSX_ERR_INVALID, "msx_sampler_draw: bad arguments (an even number of walkers, at most 4096; a > 1)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t nh = nsteps * nw;
+    char *d = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d, (size_t)nh * (3 * sizeof(double) + 3 * sizeof(int32_t))));
+    double *g_zz = (double *)d, *g_zfac = g_zz + nh, *g_logu = g_zfac + nh;
+    int32_t *g_sidx = (int32_t *)(g_logu + nh), *g_cidx = g_sidx + nh, *g_partner = g_cidx + nh;
+    hipLaunchKernelGGL(sampler_draw_kernel, dim3((unsigned)nsteps), dim3(kDrawThreads), 0, c->stream, (unsigned long long)seed, a, first_iter, nw,
+                       ndim, 0, 0, g_sidx, g_cidx, g_partner, g_zz, g_zfac, g_logu, (SmpRec *)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(zz, g_zz, sizeof(double) * nh, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(zfac, g_zfac, sizeof(double) * nh, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(logu, g_logu, sizeof(double) * nh, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(sidx, g_sidx, sizeof(int32_t) * nh, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cidx, g_cidx, sizeof(int32_t) * nh, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(partner, g_partner, sizeof(int32_t) * nh, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, MSX_ERR_HIP, std::string("msx_sampler_draw: ") + hipGetErrorString(e));
+    return MSX_OK;
 }
 
 int msx_sampler_enqueue_group(msx_ctx **ctxs, int32_t world, int32_t slot, int64_t nsteps, const int32_t *sidx,

@@ -29,9 +29,55 @@ class State:
         return iter((self.coords, self.log_prob, self.random_state))
 
 
+def counter_draws(seed, a, ndim, first_iter, m, nwalkers):
+    """NumPy restatement of the DEVICE generator (csrc/logprob_kernel.h, sampler_draw_kernel): the randomness of
+    iterations ``first_iter .. first_iter + m - 1`` of a run keyed by ``seed`` -- every number a pure function of (seed,
+    iteration, stream, index) through SplitMix64's output function.  Returns what ``EnsembleSampler._draw_steps`` returns:
+    ``sidx, cidx, partner`` (int32) and ``zz, zfac, logu`` (float64), each (m, 2, nwalkers / 2).  Indices and ``zz`` equal
+    the device's bit for bit; ``zfac`` / ``logu`` go through NumPy's ``log`` instead of the device's (last-place
+    differences), which is why the device-drawn chain is checked against the host loop fed with ``msx_sampler_draw``'s
+    arrays, and this restatement against those arrays (tests/test_gpu_overlap.py)."""
+    nw, ns = int(nwalkers), int(nwalkers) // 2
+    u64 = np.uint64
+    seed = u64(int(seed) & 0xffffffffffffffff)
+
+    def mix(it, stream, index):
+        with np.errstate(over='ignore'):
+            ctr = (it.astype(u64) << u64(28)) + (u64(stream) << u64(24)) + index.astype(u64)
+            x = seed * u64(0xD1342543DE82EF95) + (ctr + u64(1)) * u64(0x9E3779B97F4A7C15)
+            x ^= x >> u64(30); x *= u64(0xBF58476D1CE4E5B9)
+            x ^= x >> u64(27); x *= u64(0x94D049BB133111EB)
+            x ^= x >> u64(31)
+        return x
+
+    def uniform(it, stream, index):
+        return (mix(it, stream, index) >> u64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    it = (np.arange(m, dtype=np.int64) + int(first_iter))[:, None]
+    keys = mix(np.broadcast_to(it, (m, nw)), 0, np.broadcast_to(np.arange(nw)[None, :], (m, nw)))
+    perm = np.argsort(keys, axis=1, kind='stable').astype(np.int32)      # sorted by (key, index)
+    halves = perm.reshape(m, 2, ns)
+    sidx, cidx = halves, halves[:, ::-1]
+    j = np.broadcast_to(np.arange(ns)[None, :], (m, ns))
+    itb = np.broadcast_to(it, (m, ns))
+    uz, up, ua = (np.stack([uniform(itb, k + 3 * h, j) for h in (0, 1)], axis=1) for k in (1, 2, 3))
+    t1 = (float(a) - 1.0) * uz + 1.0
+    zz = (t1 * t1) / float(a)
+    partner = np.minimum((up * ns).astype(np.int32), ns - 1)
+    with np.errstate(divide='ignore'):
+        logu = np.log(ua)
+    zfac = (float(ndim) - 1.0) * np.log(zz)
+    return np.ascontiguousarray(sidx), np.ascontiguousarray(cidx), partner, zz, zfac, logu
+
+
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim, log_prob_fn, args=None, kwargs=None, a=2.0, vectorize=False, pool=None,
-                 threads=None, seed=None):
+                 threads=None, seed=None, draws=None):
+        """``draws(first_iteration, m)`` (optional) replaces the sampler's own generators: it returns the randomness of
+        ``m`` iterations in ``_draw_steps``' layout -- e.g. ``lambda i, m: ctx.sampler_draw(seed, a, i, m, nwalkers, ndim)``
+        makes this host loop walk the chain the device-resident sampler draws for itself (``rng='device'``)."""
+        self._draws = draws
+        self._drawn = 0
         if nwalkers < 2 * ndim or nwalkers % 2:
             raise ValueError('the stretch move needs an even number of walkers >= 2*ndim')
         if threads is not None:
@@ -104,6 +150,10 @@ class EnsembleSampler:
         the accept draw.  Returns ``sidx, cidx, partner`` (int32) and ``zz, zfac, logu`` (float64), each of
         shape (m, 2, nwalkers/2); ``zfac = (ndim-1) ln z``.  Shared by the host loop and the device-resident
         loop; everything is vectorised over the m iterations (the host must stay ahead of a 23 us kernel)."""
+        if self._draws is not None:
+            out = self._draws(self._drawn, m)
+            self._drawn += m
+            return out
         return self._draw_split(m) + self._draw_moves(m)
 
     def _draw_split(self, m):
@@ -207,7 +257,7 @@ class DeviceEnsembleSampler(EnsembleSampler):
     ``engine`` is a staged ``mcmc_spec_amd.engine.Engine``; ``mode`` selects ``'logposterior'`` or
     ``'loglikelihood'`` as the target density."""
 
-    def __init__(self, nwalkers, ndim, engine, mode='logposterior', a=2.0, seed=None, chunk=64, shard=None):
+    def __init__(self, nwalkers, ndim, engine, mode='logposterior', a=2.0, seed=None, chunk=64, shard=None, rng='host'):
         """``shard = (rank, world)`` runs the SHARDED form: every rank holds the whole ensemble on
         its GPU, evaluates block ``rank`` of each half-step's proposals, one RCCL all-gather of the new
         log-probabilities crosses xGMI and every rank applies the accept rule for all walkers on the device.
@@ -215,6 +265,16 @@ class DeviceEnsembleSampler(EnsembleSampler):
         holds the same chain, bit-identical to the unsharded one.  ``world > 1`` needs the engine's RCCL
         communicator (``mcmc_spec_amd.dist.init_engine_comm``)."""
         from . import _lib
+        # rng = 'host' (default): the randomness is drawn by this object's NumPy generators, exactly the calls of
+        # EnsembleSampler -- same seed, same chain as the host loop.  rng = 'device': the library draws it on the GPU with a
+        # counter-based generator keyed by `seed` (msx_sampler_enqueue_drawn: one launch per chunk, nothing uploaded, every
+        # rank of a sharded run draws the same numbers); the chain is then the one the host loop walks when it is fed
+        # `ctx.sampler_draw(seed, a, first_iteration, m, nwalkers, ndim)` (EnsembleSampler(draws=...)).  Up to 4096 walkers.
+        if rng not in ('host', 'device'):
+            raise ValueError("rng must be 'host' or 'device'")
+        self.rng_mode = rng
+        self.device_seed = int(seed if seed is not None and not isinstance(seed, np.random.SeedSequence) else
+                               np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]) & 0xffffffffffffffff
         self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
         self.overlapped = None   # set by the first chunk of a run: did its half-steps overlap (include/msx.h)?
         self.engine = engine
@@ -244,7 +304,11 @@ class DeviceEnsembleSampler(EnsembleSampler):
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
+        device_rng = self.rng_mode == 'device'
+
         def submit(pool, m):
+            if device_rng:
+                return None
             return (pool.submit(self._draw_split, m), pool.submit(self._draw_moves, m)) if m > 0 else None
 
         def next_size(prev, left):
@@ -266,11 +330,14 @@ class DeviceEnsembleSampler(EnsembleSampler):
                 slot = 0
                 while left > 0 or queued:
                     if left > 0:
-                        arrays = [x for f in fut for x in f.result()]
+                        arrays = None if device_rng else [x for f in fut for x in f.result()]
                         left -= m
                         m_next = next_size(m, left) if left > 0 else 0
                         fut = submit(pool, m_next)
-                        ctx.sampler_enqueue(slot, *arrays)
+                        if device_rng:
+                            ctx.sampler_enqueue_drawn(slot, m, self.device_seed, self.a)
+                        else:
+                            ctx.sampler_enqueue(slot, *arrays)
                         self.overlapped = ctx.sampler_overlapped() == 1   # (half-steps on two streams: include/msx.h)
                         queued.append((slot, m))
                         slot ^= 1

@@ -156,3 +156,56 @@ def test_overlapped_half_steps_of_a_triple_system():
     assert dev.overlapped is True
     assert np.array_equal(dev.get_chain(), host.get_chain()) and np.array_equal(dev.get_log_prob(), host.get_log_prob(), equal_nan=True)
     assert np.array_equal(ds.coords, hs.coords)
+
+
+# ---- the stretch move's randomness drawn on the device (msx_sampler_enqueue_drawn) --------------------
+def test_device_generator_is_the_counter_stream_its_numpy_restatement_describes():
+    """sampler_draw_kernel against mcmc_spec_amd.sampler.counter_draws: the split (walkers sorted by a 64-bit key), the
+    partners and z bit for bit; the two logarithms to the last place or two (device log vs NumPy's).  Every iteration is a
+    permutation of the ensemble, a chunk started at iteration k equals rows k.. of a chunk started at 0, and odd sizes
+    (18 walkers: the sort pads to 32) work like powers of two."""
+    from mcmc_spec_amd.sampler import counter_draws
+    eng, W = _config2()
+    for nw, ndim, seed in ((256, 6, 17), (18, 6, 2**63 + 5), (2048, 8, 3)):
+        got = eng.ctx.sampler_draw(seed, 2.0, 0, 7, nw, ndim)
+        want = counter_draws(seed, 2.0, ndim, 0, 7, nw)
+        for g, w in zip(got[:4], want[:4]):           # sidx, cidx, partner, zz
+            assert np.array_equal(g, w)
+        for g, w in zip(got[4:], want[4:]):           # zfac = (ndim - 1) ln z, logu = ln u
+            assert np.allclose(g, w, rtol=4e-16, atol=1e-300)
+        s = np.concatenate([got[0][:, 0], got[0][:, 1]], axis=1)
+        assert np.array_equal(np.sort(s, axis=1), np.broadcast_to(np.arange(nw), s.shape))
+        assert np.array_equal(got[1], got[0][:, ::-1])
+        later = eng.ctx.sampler_draw(seed, 2.0, 3, 4, nw, ndim)
+        assert all(np.array_equal(a, b[3:]) for a, b in zip(later, got))
+        assert got[2].min() >= 0 and got[2].max() < nw // 2 and np.all(got[3] >= 0.5) and np.all(got[3] <= 2.0) and np.all(got[5] <= 0)
+    # the uniforms behind z are uniform: mean 1/2, variance 1/12 over 7 x 2048 draws (a = 2: z = (u + 1)^2 / 2)
+    u = np.sqrt(2.0 * got[3]) - 1.0
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+
+
+@pytest.mark.parametrize('nw,nsteps,chunk', [(256, 40, 16), (18, 11, 4)])
+def test_device_drawn_chain_is_the_host_loop_fed_with_the_device_stream(nw, nsteps, chunk):
+    """rng='device': nothing is drawn or uploaded by the host.  The chain must be, bit for bit, the one the HOST loop walks
+    over the same posterior when it is fed the generator's own numbers (msx_sampler_draw) -- overlapped half-steps and
+    chunk boundaries included; a second sampler with the same seed repeats it, another seed does not."""
+    from mcmc_spec_amd import synth
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    eng, W = _config2()
+    p0 = synth.draw_walkers(nw, seed=9 + nw, tmin=W['tmin'], tmax=W['tmax'])
+    seed = 2024
+    dev = DeviceEnsembleSampler(nw, 6, eng, seed=seed, chunk=chunk, rng='device')
+    ds = dev.run_mcmc(p0, nsteps)
+    host = EnsembleSampler(nw, 6, eng.logposterior, vectorize=True,
+                           draws=lambda i, m: eng.ctx.sampler_draw(seed, 2.0, i, m, nw, 6))
+    hs = host.run_mcmc(p0, nsteps)
+    assert dev.overlapped is True
+    assert np.array_equal(dev.get_chain(), host.get_chain()) and np.array_equal(dev.get_log_prob(), host.get_log_prob())
+    assert np.array_equal(ds.coords, hs.coords) and np.array_equal(dev.acceptance_fraction, host.acceptance_fraction)
+    assert 0.1 < dev.acceptance_fraction.mean() < 0.9
+    again = DeviceEnsembleSampler(nw, 6, eng, seed=seed, chunk=chunk + 3, rng='device')   # (the chunking does not matter)
+    again.run_mcmc(p0, nsteps)
+    assert np.array_equal(again.get_chain(), dev.get_chain())
+    other = DeviceEnsembleSampler(nw, 6, eng, seed=seed + 1, chunk=chunk, rng='device')
+    other.run_mcmc(p0, nsteps)
+    assert not np.array_equal(other.get_chain(), dev.get_chain())
