@@ -312,6 +312,8 @@ class DeviceEnsembleSampler(EnsembleSampler):
             return (pool.submit(self._draw_split, m), pool.submit(self._draw_moves, m)) if m > 0 else None
 
         def next_size(prev, left):
+            if self.rng_mode == 'device':   # (nothing to wait for on the host: whole chunks from the start)
+                return min(left, self.chunk)
             return min(left, self.chunk, max(8, 2 * prev))
 
         ctx = self.engine.ctx
