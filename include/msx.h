@@ -243,6 +243,13 @@ int msx_sampler_end(msx_ctx *ctx, double *coords, double *logp);
  * Same chain, bit for bit.  Chosen by the first msx_sampler_enqueue of a run; MSX_SMP_OVERLAP=0 in the environment:
  * never.  *out = 1 if the run begun on ctx takes it, 0 if not, -1 before its first chunk.                           */
 int msx_sampler_overlapped(msx_ctx *ctx, int32_t *out);
+/* ... and the caller's say: overlap = -1 (default) lets the rule above decide, 0 never overlaps (plain launches, one
+ * half-step after the other).  The rule counts on this context's launches having the device to themselves -- two
+ * half-steps of 128 walkers need all 256 CUs at once -- and never takes the overlap on a context that holds a
+ * communicator.  On a device shared with other work use 0: a waiting workgroup whose producer cannot get a CU ends, after
+ * the 20 ms bound, as MSX_W_HANDOVER for the chunk, and the run has to be started again (the chain up to the last
+ * collected chunk stands).  Takes effect at the next msx_sampler_begin.                                                */
+int msx_sampler_policy(msx_ctx *ctx, int32_t overlap);
 
 /* ---- A4-A6: make_composite (mft6.py:651-831, plot=False) -------------------------------------- */
 /* teff/logg/rad are [nspec]; use_distance = 0 mirrors `distance=False` (mft6.py:701-703).         */

@@ -126,6 +126,7 @@ def load():
         'msx_last_form': (C.c_int, [vp, C.POINTER(C.c_int32)]),
         'msx_pair_stats': (C.c_int, [vp, _ip]),
         'msx_sampler_overlapped': (C.c_int, [vp, C.POINTER(C.c_int32)]),
+        'msx_sampler_policy': (C.c_int, [vp, C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library skew, fail loudly
@@ -141,7 +142,7 @@ EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'm
             'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_enqueue_drawn', 'msx_sampler_draw', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
-            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_launch_info', 'msx_last_form', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped']
+            'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_launch_info', 'msx_last_form', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped', 'msx_sampler_policy']
 
 
 def as_f64(a):
@@ -325,6 +326,10 @@ class Context:
         out = C.c_int32()
         self.check(self.lib.msx_sampler_overlapped(self.h, C.byref(out)))
         return out.value
+
+    def sampler_policy(self, overlap=-1):
+        """-1: overlap consecutive half-steps when the library's rule allows (default); 0: never (a device shared with other work)."""
+        self.check(self.lib.msx_sampler_policy(self.h, int(overlap)))
 
     def sampler_shard(self, rank, world):
         """Shard the run begun by sampler_begin over `world` ranks (msx_sampler_shard); world > 1 needs comm_init."""

@@ -141,6 +141,7 @@ struct msx_ctx {
     bool smp_overlap_launch = false;   // the launch being queued is a half-step of an overlapped run: fused form, bit 20
     bool probe_launch = false;         // ... is msx_probe_launch's: the kernel leaves clock stamps (bit 21)
     int32_t last_form = 0;             // MSX_FORM_* of the last launch queued (msx_last_form)
+    int32_t smp_overlap_policy = -1;   // msx_sampler_policy: -1 = overlap half-steps when the rule allows, 0 = never
 };
 static void sampler_free(msx_ctx *c);
 
@@ -1445,7 +1446,13 @@ static int chunk_prepare(msx_ctx *c, int32_t slot, int64_t nsteps, const int32_t
     if (r->overlap < 0) {
         const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
         const char *e = getenv("MSX_SMP_OVERLAP");
-        r->overlap = !(e && e[0] == '0') && !r->sharded && 2 * ns <= cus && !c->model_in_global && c->recipe_fast &&
+        // (Not on a context that holds a communicator: RCCL's kernels take CUs this rule counts on.  Two half-steps of
+        // config 2's ensemble need every CU of the chip -- one workgroup each -- so anything else resident on the device
+        // (another process, another context's launches) can keep a waiting workgroup's producer off the chip: the wait is
+        // bounded, the chunk then ends with MSX_W_HANDOVER and the run is lost -- msx_sampler_policy(ctx, 0) or
+        // MSX_SMP_OVERLAP=0 gives the plain launches on a device that is shared.)
+        r->overlap = !(e && e[0] == '0') && c->smp_overlap_policy != 0 && !r->sharded && !c->rccl_comm && c->loop_peers.empty() &&
+                     2 * ns <= cus && !c->model_in_global && c->recipe_fast &&
                      c->path != MSX_PATH_LINKED && c->path != MSX_PATH_PAIR && !auto_takes_linked(c, ns);
     }
     if (draw) {
@@ -1764,6 +1771,12 @@ int msx_sampler_end(msx_ctx *c, double *coords, double *logp) {
     if (e == hipSuccess && logp) e = hipMemcpy(logp, r->d_logp, sizeof(double) * r->nw, hipMemcpyDeviceToHost);
     sampler_free(c);
     if (e != hipSuccess) return fail(c, MSX_ERR_HIP, std::string("msx_sampler_end: ") + hipGetErrorString(e));
+    return MSX_OK;
+}
+
+int msx_sampler_policy(msx_ctx *c, int32_t overlap) {
+    if (!c || (overlap != -1 && overlap != 0)) return fail(c, MSX_ERR_INVALID, "msx_sampler_policy: -1 (automatic) or 0 (never overlap half-steps)");
+    c->smp_overlap_policy = overlap;
     return MSX_OK;
 }
 

@@ -257,7 +257,7 @@ class DeviceEnsembleSampler(EnsembleSampler):
     ``engine`` is a staged ``mcmc_spec_amd.engine.Engine``; ``mode`` selects ``'logposterior'`` or
     ``'loglikelihood'`` as the target density."""
 
-    def __init__(self, nwalkers, ndim, engine, mode='logposterior', a=2.0, seed=None, chunk=64, shard=None, rng='host'):
+    def __init__(self, nwalkers, ndim, engine, mode='logposterior', a=2.0, seed=None, chunk=64, shard=None, rng='host', overlap=None):
         """``shard = (rank, world)`` runs the SHARDED form: every rank holds the whole ensemble on
         its GPU, evaluates block ``rank`` of each half-step's proposals, one RCCL all-gather of the new
         log-probabilities crosses xGMI and every rank applies the accept rule for all walkers on the device.
@@ -270,6 +270,11 @@ class DeviceEnsembleSampler(EnsembleSampler):
         # counter-based generator keyed by `seed` (msx_sampler_enqueue_drawn: one launch per chunk, nothing uploaded, every
         # rank of a sharded run draws the same numbers); the chain is then the one the host loop walks when it is fed
         # `ctx.sampler_draw(seed, a, first_iteration, m, nwalkers, ndim)` (EnsembleSampler(draws=...)).  Up to 4096 walkers.
+        # overlap = None: consecutive half-steps run concurrently when the library's rule allows (an unsharded run whose two
+        # half-steps fit the chip together: include/msx.h, msx_sampler_policy); False: plain launches -- the choice for a
+        # GPU shared with other work, where a waiting workgroup's producer may not get a CU (the chunk then fails with
+        # MSX_W_HANDOVER after a bounded wait, a RuntimeError here, and the run has to be started again).
+        self.overlap_policy = -1 if overlap is None or overlap else 0
         if rng not in ('host', 'device'):
             raise ValueError("rng must be 'host' or 'device'")
         self.rng_mode = rng
@@ -321,6 +326,7 @@ class DeviceEnsembleSampler(EnsembleSampler):
         if left <= 0:
             return
         base_acc = self._accepted.copy()
+        ctx.sampler_policy(self.overlap_policy)
         ctx.sampler_begin(self._mode, coords, logp, self.chunk)
         if self.shard is not None:
             ctx.sampler_shard(*self.shard)

@@ -61,6 +61,15 @@ def test_overlapped_half_steps_walk_the_host_chain(nw, nsteps, chunk, monkeypatc
     host3, hs3, dev3, ds3 = _chains(eng, p0, nsteps, 17, chunk)
     assert dev3.overlapped is False
     assert np.array_equal(dev3.get_chain(), dev.get_chain()) and np.array_equal(ds3.log_prob, ds.log_prob)
+    monkeypatch.delenv('MSX_SMP_OVERLAP')
+    # ... and by the caller's say (msx_sampler_policy: a device shared with other work): plain launches, same chain
+    from mcmc_spec_amd.sampler import DeviceEnsembleSampler
+    dev4 = DeviceEnsembleSampler(nw, 6, eng, seed=17, chunk=chunk, overlap=False)
+    dev4.run_mcmc(p0, nsteps)
+    assert dev4.overlapped is False and np.array_equal(dev4.get_chain(), dev.get_chain())
+    dev5 = DeviceEnsembleSampler(nw, 6, eng, seed=17, chunk=chunk)      # (the policy is per run: back to the rule)
+    dev5.run_mcmc(p0, 3)
+    assert dev5.overlapped is True
 
 
 def test_overlap_is_not_taken_where_it_could_deadlock_or_does_not_apply():

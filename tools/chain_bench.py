@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--device-steps', type=int, default=4000)
     ap.add_argument('--chunk', type=int, default=100)
     ap.add_argument('--no-host', action='store_true', help='skip the host-driven loop (profiling runs)')
+    ap.add_argument('--rng', default='host', help="host | device: who draws the move's randomness (DeviceEnsembleSampler)")
     args = ap.parse_args()
     from bench import build_workload
     from mcmc_spec_amd import synth
@@ -35,14 +36,14 @@ def main():
             t0 = time.perf_counter()
             host.run_mcmc(p0, steps)
             th = time.perf_counter() - t0
-        dev = DeviceEnsembleSampler(nw, 6, eng, seed=1, chunk=args.chunk)
+        dev = DeviceEnsembleSampler(nw, 6, eng, seed=1, chunk=args.chunk, rng=args.rng)
         dev.run_mcmc(p0, 5)
         dsteps = args.device_steps
         t0 = time.perf_counter()
         dev.run_mcmc(p0, dsteps, store=False)
         td = time.perf_counter() - t0
         print(json.dumps(dict(walkers=nw, steps=steps, host_loop_us_per_step=th / steps * 1e6,
-                              device_us_per_step=td / dsteps * 1e6, device_steps=dsteps, host_evals_per_s=nw * steps / th,
+                              device_us_per_step=td / dsteps * 1e6, device_steps=dsteps, randomness=args.rng, overlapped=bool(dev.overlapped), host_evals_per_s=nw * steps / th,
                               device_evals_per_s=nw * dsteps / td,
                               acceptance=float(dev.acceptance_fraction.mean()))), flush=True)
 

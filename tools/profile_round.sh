@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's profile set (run on the GPU box through gpurun); condensed summaries land in gpurun_out/profiles_<tag>/
 # and are copied into profiles/ (tracked) afterwards.
-#   gpurun --timeout 1100 -- 'tools/profile_round.sh r3'
+#   gpurun --timeout 1100 -- 'tools/profile_round.sh r4'
 # 1. kernel trace + stats of the default bench (config 2: 256 walkers x 4096 px), then two separate PMC passes
 #    (FETCH_SIZE, WRITE_SIZE -- never combined with trace domains) -> <tag>_logprob_kernel_stats.csv, _traffic.json
 # 2. SQ counter passes (counters only) at 256 / 3072 walkers (fused), 16,384 walkers (fused and pair) and config 4's
@@ -9,7 +9,7 @@
 # 3. per-kernel times of the forms: fused against pair (planner + pair kernel) at 4,096 / 16,384 walkers, fused against
 #    linked at 16,384 px
 # 4. sweeps (device time per batch), the dependent chain
-tag=${1:-r3}
+tag=${1:-r4}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/prof_$tag
 dst=$root/gpurun_out/profiles_$tag
@@ -60,7 +60,8 @@ python3 tools/sweep.py --blocks 0 --paths auto --walkers 26,128,256,512,1024,204
 python3 tools/sweep.py --blocks 0 --paths fused --walkers 4096,8192,16384 >> $dst/${tag}_sweep_4096px.jsonl 2>/dev/null
 python3 tools/sweep.py --blocks 0 --paths auto --npix 16384 --phot --walkers 32,128,512 > $dst/${tag}_sweep_16384px.jsonl 2>/dev/null
 python3 tools/sweep.py --blocks 0 --paths fused,linked --npix 16384 --phot --iters 200 --walkers 8,16,32,48,64,96,128 > $dst/${tag}_linked_sweep_16384px.jsonl 2>/dev/null
-tools/r3_pair_sweep.sh 2048,4096,8192,16384 > /dev/null 2>&1; cp $root/gpurun_out/r3_pair_sweep.txt $dst/${tag}_pair_sweep.txt
+tools/r3_pair_sweep.sh 2048,2304,3072,4096,8192,16384 > /dev/null 2>&1; cp $root/gpurun_out/r3_pair_sweep.txt $dst/${tag}_pair_sweep.txt
 python3 tools/chain_bench.py > $dst/${tag}_chain_bench.jsonl 2>/dev/null
+for r in 1 2 3 4 5; do python3 tools/chain_bench.py --walkers 256 --no-host --rng device >> $dst/${tag}_chain_bench.jsonl 2>/dev/null; python3 tools/chain_bench.py --walkers 256 --no-host >> $dst/${tag}_chain_bench.jsonl 2>/dev/null; done
 echo "[profile_round] 4 done" >&2
 ls -la $dst
