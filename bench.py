@@ -36,7 +36,7 @@ L2_PEAK_GBPS = 34500.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False, grid=None):
+def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False, grid=None, store='f64'):
     """Stage the synthetic 26x4x135,000 grid, broaden the data window on the device (A3), synthesise
     a data spectrum at theta* with the GPU's own make_composite and stage the problem."""
     from mcmc_spec_amd import bands, staging, synth
@@ -76,7 +76,7 @@ def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid
     d = f + rng.normal(0, 0.01 * f)  # mft6.py:3640
     med = np.median(d)
     data, err = [wl_um, d / med], 0.01 * f / med  # mft6.py:3506-3507
-    eng.stage_problem(data, err, fr, r, ctm, ptm, tmi, tma, matrix, **kw)
+    eng.stage_problem(data, err, fr, r, ctm, ptm, tmi, tma, matrix, store=store, **kw)
     nwin = int(np.sum((wl >= win[0] - 1) & (wl <= win[1] + 1)))
     out = dict(data=data, err=err, fr=fr, r=r, ctm=ctm, ptm=ptm, tmi=tmi, tma=tma, matrix=matrix, tabs=tabs,
                vega=(vw, vf), prior=prior, tmin=float(teffs[0]), tmax=float(teffs[-1]), nwin=nwin, win=win,
@@ -239,6 +239,8 @@ def main():
     ap.add_argument('--npix', type=int, default=0)
     ap.add_argument('--phot', action='store_true', help='add the 6-band photometry term')
     ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = auto)')
+    ap.add_argument('--store', default='f64', choices=['f64', 'f32'],
+                    help='storage precision of the staged grid table R (f32: a separately labelled precision, never the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the sweep / config-4 / P=15 extras of the N = 1 run')
     ap.add_argument('--no-overlap', action='store_true',
@@ -306,7 +308,7 @@ def main():
     else:
         eng = Engine(local)
         engines = [eng]
-        W = build_workload(eng, args.npix, args.phot, keep_host_grid=True)
+        W = build_workload(eng, args.npix, args.phot, keep_host_grid=True, store=args.store)
     # distinct coordinates per rank and a few distinct batches so no launch repeats the previous one
     nbatch = 4
     thetas = [torch.from_numpy(synth.draw_walkers(n, seed=3 + 1000 * rank + b, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
@@ -793,10 +795,11 @@ def main():
             'metric': 'walker log-likelihood evals/sec (whole node)',
             'value': n * world * args.steps / dt, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic',
+            'dtype': 'f64' if args.store == 'f64' else 'f64 arithmetic over a float32-STORED grid table (--store f32: a separately labelled precision, not the headline)',
             # (what the arithmetic type does not say: two of the staged tables only ever enter multiplied by eps ~ 4e-5 A_V and
             # are stored in float32 -- csrc/blend.h; every sum, the model vector and the grid's R table are float64)
-            'storage': {'R': 'f64', 'H': 'f32', 'dk': 'f32', 'note': 'R = lo + (hi - lo) t per grid node and pixel; H = hi t and dk = k_hi - k_lo enter the model only as eps * H, eps = 2^(redc dk) - 1: their 2^-24 rounding perturbs a pixel by < 2.4e-12 A_V relative (tests/test_gpu_parity.py, A_V = 3)'},
+            'storage': {'R': args.store, 'H': 'f32', 'dk': 'f32', 'note': 'R = lo + (hi - lo) t per grid node and pixel; H = hi t and dk = k_hi - k_lo enter the model only as eps * H, eps = 2^(redc dk) - 1: their 2^-24 rounding perturbs a pixel by < 2.4e-12 A_V relative (tests/test_gpu_parity.py, A_V = 3)'},
             'config': {'workload': workload, 'baseline_config': args.config if args.config != 2 or world == 1 else 3,
                        'walkers_total': n * world, 'npix': args.npix, 'nwin': W.get('nwin'),
                        'grid': '26x4x135000 f64 synthetic',
@@ -888,6 +891,26 @@ def main():
                                                   'evals_per_s': 128 / us * 1e6, 'form': _lib.FORM_NAMES[e4.ctx.last_form()],
                                                   'kernel': inf4['kernel'].split(' (')[0],
                                                   'requested_bytes_per_eval': inf4['requested_bytes_per_eval']}
+        if world == 1 and not replicas and not args.no_extras and args.npix == 4096 and not args.phot and args.store == 'f64':
+            # A separately labelled precision, beside the headline and never instead of it: the same problem with the
+            # grid table R STORED in float32 (include/msx.h, msx_set_grid_storage; the arithmetic stays float64)
+            e32 = Engine(local)
+            build_workload(e32, args.npix, False, grid=W.get('flux'), store='f32')
+            th32 = synth.draw_walkers(n, seed=3, tmin=W['tmin'], tmax=W['tmax'])
+            t32 = torch.from_numpy(th32).to(dev)
+            lp_, st_ = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+            us32 = device_time_us(e32, t32, lp_, st_, stream, n, 200)
+            us64 = device_time_us(eng, t32, logp[0], status[0], stream, n, 200)
+            g32, _ = e32.ctx.logprob_batch(th32, _lib.MODE_LOGPOST)
+            g64, _ = eng.ctx.logprob_batch(th32, _lib.MODE_LOGPOST)
+            fin = np.isfinite(g64)
+            inf32 = e32.ctx.launch_info(n)
+            extra['f32_stored_grid_table'] = {
+                'walkers': n, 'device_us': us32, 'evals_per_s': n / us32 * 1e6, 'device_us_f64_same_loop': us64,
+                'max_rel_dev_from_f64_tables': float(np.max(np.abs(g32[fin] - g64[fin]) / np.abs(g64[fin]))),
+                'kernel': inf32['kernel'].split(' (')[0], 'requested_bytes_per_eval': inf32['requested_bytes_per_eval'],
+                'note': 'labelled precision: R stored in float32 (2^-24 on the grid values), float64 arithmetic; plain launches back '
+                        'to back, HIP events; BASELINE tolerance 1e-6 relative'}
         if extra:
             out['extra'] = extra
         sys.stdout.flush()

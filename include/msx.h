@@ -300,6 +300,17 @@ int msx_bytes_per_eval(msx_ctx *ctx, int64_t n, int64_t *requested_bytes);
 int msx_probe_launch(msx_ctx *ctx, int32_t mode, const double *d_theta, int64_t n, int32_t ndim, double *d_logp,
                      int32_t *d_status, void *hip_stream, int32_t block_threads, double *out4);
 
+/* STORAGE precision of the staged grid tables (SURVEY 8b's `store_dtype`).  MSX_STORE_F64 (default): the per-node pixel
+ * table R = lo + (hi - lo) t in float64.  MSX_STORE_F32: R rounded to float32 (8 instead of 12 bytes per node-pixel through
+ * the CU's L2 port, which the blend runs at the limit of) and widened in the registers -- the arithmetic stays float64, the
+ * grid values carry 2^-24.  A SEPARATELY LABELLED precision: log-probabilities then agree with the reference to ~1e-7
+ * relative at S/N 100 (tests/test_gpu_parity.py), inside BASELINE's 1e-6 but not the 1e-9 the float64 tables are held to;
+ * bench.py reports it under its own label and never as the headline.  Takes effect at the next msx_stage_problem; fused
+ * binaries of at most 17,152 pixels only (the pair and linked forms, triples and longer spectra are refused, not mixed in). */
+#define MSX_STORE_F64 0
+#define MSX_STORE_F32 1
+int msx_set_grid_storage(msx_ctx *ctx, int32_t store_dtype);
+
 /* What an automatic launch of n walkers in `mode` (block_threads as for msx_logprob_batch_dev) WOULD take, asked of the
  * library's own launcher (nothing is queued): `name` receives the kernel's name and description, out8 = {form (MSX_FORM_*),
  * threads per workgroup, VGPRs, static LDS bytes, dynamic LDS bytes, bytes requested from the memory system per walker

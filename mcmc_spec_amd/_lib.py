@@ -21,6 +21,7 @@ MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
 PATH_AUTO, PATH_FUSED, PATH_PAIR, PATH_LINKED = 0, 1, 2, 4  # include/msx.h MSX_PATH_*
 FORM_FUSED, FORM_PAIR, FORM_LINKED = 0, 1, 2  # include/msx.h MSX_FORM_*
+STORE_F64, STORE_F32 = 0, 1  # include/msx.h MSX_STORE_*
 FORM_NAMES = {0: 'fused', 1: 'pair (planner + two walkers of one grid cell per workgroup)', 2: 'linked (one workgroup per walker and 8192-pixel segment)'}
 HOOK_LINKED_FAULT, HOOK_PAIR_LEASES = 1, 2  # include/msx.h MSX_HOOK_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
@@ -96,6 +97,7 @@ def load():
         'msx_logprob_batch_dev': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32]),
         'msx_probe_launch': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, _dp]),
         'msx_set_path': (C.c_int, [vp, C.c_int32]),
+        'msx_set_grid_storage': (C.c_int, [vp, C.c_int32]),
         'msx_opt_init': (C.c_int, [vp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_opt_step': (C.c_int, [vp, _dp, C.POINTER(C.c_int32), C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_sampler_run': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, C.POINTER(C.c_int32),
@@ -139,7 +141,7 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
+            'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_set_grid_storage', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_enqueue_drawn', 'msx_sampler_draw', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_launch_info', 'msx_last_form', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped', 'msx_sampler_policy']
@@ -263,6 +265,11 @@ class Context:
         self.check(self.lib.msx_logprob_batch_dev(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim),
                                                   C.c_void_p(d_logp_ptr), C.c_void_p(d_status_ptr),
                                                   C.c_void_p(stream_ptr), int(block_threads)))
+
+    def set_grid_storage(self, store):
+        """'f64' (default) or 'f32': the precision the NEXT stage_problem stores the per-node R table in (msx_set_grid_storage;
+        a separately labelled precision -- fused binaries only)."""
+        self.check(self.lib.msx_set_grid_storage(self.h, {'f64': STORE_F64, 'f32': STORE_F32}[store]))
 
     def probe_launch(self, d_theta_ptr, n, ndim, d_logp_ptr, d_status_ptr, stream_ptr, mode=MODE_LOGPOST, block_threads=0):
         """One launch with clock stamps (msx_probe_launch): {'shader_mhz', 'walker_us_median', 'walker_us_max', 'span_us'}."""

@@ -44,6 +44,8 @@ struct DevProblem {
     // (e & 255), e < npair (= the pixel count padded to a multiple of 512, halved; pad pixels repeat the last one):
     const double2 *r2;     // [nt*ng][npair]  R = flux[lo] + (flux[lo+1] - flux[lo]) t   (blend_pixel_rh, blend.h)
     const float2 *h2;      // [nt*ng][npair]  H = flux[lo+1] t
+    const float2 *r2f;     // [nt*ng][npair]  R rounded to float32: only with msx_set_grid_storage(MSX_STORE_F32), else null
+    const float4 *r4f, *r4fb;  // ... and by quad ({eA, eB = eA + 512} / {eA, eA + 256}), like h4 / h4b: one load per corner and trip
     const double2 *kl2;    // [npair]         CCM89 k[lo]
     const float2 *dk2;     // [npair]         k[lo+1] - k[lo]
     const double2 *f2, *u2, *iv2;  // [npair] data flux, mapped wavelength u, 1/err^2 (element copies of pix_flux, pix_u, pix_ivar)

@@ -273,7 +273,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 // element e = pixels {pa, pa + 256}, pa = (e >> 8) * 512 + (e & 255): a lane's 16-byte load (8-byte for the float32
 // table) brings both of its pixels, for workgroups of 256 and of 512 threads alike.  Per grid node and pixel the
 // tables hold R = lo + (hi - lo) t (float64) and H = hi t (float32): see blend_pixel_rh (blend.h).
-template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false>
+// R32 = the R table is stored in FLOAT32 (msx_set_grid_storage(MSX_STORE_F32): 8 instead of 12 bytes per node-pixel through
+//       the CU's L2 port, whose limit the blend runs at) and widened to float64 in the registers: the arithmetic is the
+//       same float64 chain, the grid values carry 2^-24 instead of 2^-53.  A SEPARATELY LABELLED precision (SURVEY 8b's
+//       store_dtype), never the default; fused binaries only.
+template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false>
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
@@ -568,6 +572,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // that runs two per CU instead of three -- SH there -- and so has 256 VGPRs)
     constexpr bool kQuad = (MAXT == 512 && !SH) || (MAXT == 256 && SH);
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
+    const float2 *rows_rf[NC];  // ... the float32 copy (R32)
+    const float4 *rows_r4f[NC]; // ... by quad
     const float2 *rows_h[NC];   // H = hi t
     const float4 *rows_h4[NC];  // ... by quad
     double w[NC];
@@ -576,6 +582,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     for (int c = 0; c < NC; ++c) {
         const int64_t off = (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * ne;
         rows_r[c] = P.r2 + off;
+        rows_rf[c] = R32 ? P.r2f + off : nullptr;
+        rows_r4f[c] = (R32 && kQuad) ? (MAXT == 512 ? P.r4f : P.r4fb) + (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * P.nquad : nullptr;
         rows_h[c] = P.h2 + off;
         rows_h4[c] = (MAXT == 512 ? P.h4 : P.h4b) + (!kQuad ? 0 : (int64_t)__builtin_amdgcn_readfirstlane(D.node[c]) * P.nquad);
         w[c] = uniform_f64(D.w[c]);
@@ -665,8 +673,14 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             float4 hq[G];
 #pragma unroll
             for (int c = 0; c < G; ++c) {
-                rA[c] = ld_off(rows_r[c0 + c], oA);
-                rB[c] = ld_off(rows_r[c0 + c], oB);
+                if constexpr (R32) {  // (one 16-byte load brings the quad's four float32 values: it is the load COUNT the blend pays for)
+                    const float4 qv4 = ld_off(rows_r4f[c0 + c], oq);
+                    rA[c] = make_double2((double)qv4.x, (double)qv4.y);
+                    rB[c] = make_double2((double)qv4.z, (double)qv4.w);
+                } else {
+                    rA[c] = ld_off(rows_r[c0 + c], oA);
+                    rB[c] = ld_off(rows_r[c0 + c], oB);
+                }
                 hq[c] = RED ? ld_off(rows_h4[c0 + c], oq) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (c0 == 0 && RED) { klA = ld_off(P.kl2, oA); klB = ld_off(P.kl2, oB); dk = ld_off(MAXT == 512 ? P.dk4 : P.dk4b, oq); }
@@ -722,7 +736,12 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                 float2 hh[G];
 #pragma unroll
                 for (int c = 0; c < G; ++c) {
-                    rr[c] = ld_off(rows_r[c0 + c], o16);
+                    if constexpr (R32) {
+                        const float2 a = ld_off(rows_rf[c0 + c], o8);
+                        rr[c] = make_double2((double)a.x, (double)a.y);
+                    } else {
+                        rr[c] = ld_off(rows_r[c0 + c], o16);
+                    }
                     hh[c] = RED ? ld_off(rows_h[c0 + c], o8) : make_float2(0.f, 0.f);
                 }
                 if (c0 == 0 && RED) { kl2 = ld_off(P.kl2, o16); dk2 = ld_off(P.dk2, o8); }

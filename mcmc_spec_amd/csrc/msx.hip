@@ -142,6 +142,8 @@ struct msx_ctx {
     bool probe_launch = false;         // ... is msx_probe_launch's: the kernel leaves clock stamps (bit 21)
     int32_t last_form = 0;             // MSX_FORM_* of the last launch queued (msx_last_form)
     int32_t smp_overlap_policy = -1;   // msx_sampler_policy: -1 = overlap half-steps when the rule allows, 0 = never
+    int32_t store_dtype = MSX_STORE_F64;  // msx_set_grid_storage: what the NEXT msx_stage_problem builds the R table in
+    bool store_f32 = false;               // ... and what the staged problem holds
 };
 static void sampler_free(msx_ctx *c);
 
@@ -346,11 +348,13 @@ bool takes_pf(const msx_ctx *c, int64_t n) {
 struct Variant {
     const void *fn;
     int ns, threads;
-    bool gm, sh, pf, lk;
+    bool gm, sh, pf, lk, r32;
     const char *what;
 };
 #define MSX_V(NS_, T_, GM_, SH_, PF_, LK_, WHAT_) \
-    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, WHAT_}
+    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, false, WHAT_}
+#define MSX_V32(T_, SH_, PF_, WHAT_) \
+    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, true>, 2, T_, false, SH_, PF_, false, true, WHAT_}
 const Variant kVariants[] = {
     MSX_V(2, 256, false, false, false, false, "three workgroups per CU"),
     MSX_V(2, 256, false, true, false, false, "two per CU, four pixels per lane and trip"),
@@ -365,11 +369,19 @@ const Variant kVariants[] = {
     MSX_V(3, 512, false, false, false, true, "one workgroup per walker and 8192-pixel segment; partial sums and histogram counters exchanged inside the launch; the segment's data flux staged in LDS; four pixels per lane and trip"),
     MSX_V(2, 512, true, false, false, false, "model vector in global memory (spectra beyond the LDS), sub-batched"),
     MSX_V(3, 512, true, false, false, false, "model vector in global memory (spectra beyond the LDS), sub-batched"),
+    // the fused binary variants once more over the FLOAT32 copy of the R table (msx_set_grid_storage(MSX_STORE_F32))
+    MSX_V32(256, false, false, "three workgroups per CU; R table stored in float32"),
+    MSX_V32(256, true, false, "two per CU, four pixels per lane and trip; R table stored in float32"),
+    MSX_V32(256, true, true, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; R table stored in float32"),
+    MSX_V32(512, false, false, "one workgroup per CU, four pixels per lane and trip; R table stored in float32"),
+    MSX_V32(512, true, false, "<= 128 VGPRs: two workgroups fit a CU; rows one star at a time; R table stored in float32"),
+    MSX_V32(512, false, true, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; R table stored in float32"),
 };
 #undef MSX_V
-const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk) {
+#undef MSX_V32
+const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk, bool r32 = false) {
     for (const Variant &v : kVariants)
-        if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk) return &v;
+        if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk && v.r32 == r32) return &v;
     return nullptr;
 }
 struct VariantChoice {
@@ -396,6 +408,16 @@ VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, i
     const bool sh2 = B == 512 && P.nspec == 2 && lds <= 70 * 1024 && c->force_sh2;
     const bool pf = B == 512 && !shared512 && !sh2 && takes_pf(c, n);
     const bool sh = B == 512 && !pf && (sh2 || shared512 || !own_cu);
+    const bool r32 = c->store_f32;  // (msx_stage_problem has checked that the problem has such variants: fused binaries)
+    if (ns == 2 && r32) {
+        const bool q256 = c->q256 > 0 || (c->q256 < 0 && n <= 2 * (int64_t)c->prop.multiProcessorCount);
+        if (B == 256 && q256 && c->pf256_ok && c->use_pf) return {find_variant(2, 256, false, true, true, false, true), lds_pf};
+        if (B == 256 && q256) return {find_variant(2, 256, false, true, false, false, true), lds};
+        if (B == 256) return {find_variant(2, 256, false, false, false, false, true), lds};
+        if (pf) return {find_variant(2, 512, false, false, true, false, true), lds_pf};
+        if (sh) return {find_variant(2, 512, false, true, false, false, true), lds};
+        return {find_variant(2, 512, false, false, false, false, true), lds};
+    }
     if (ns == 2) {
         // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
         // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
@@ -496,6 +518,10 @@ FormChoice decide_form(msx_ctx *c, int64_t n, int mode, bool peek) {
         f.pair = true;
     }
     if (c->probe_launch) f.pair = false;  // (the pair form carries no clock stamps)
+    if (c->store_f32) {  // float32-stored R table: the fused variants compiled for it, nothing else
+        if (c->path == MSX_PATH_PAIR || c->path == MSX_PATH_LINKED) { f.err = MSX_ERR_STATE; f.msg = "float32 grid storage (msx_set_grid_storage): the fused form only"; return f; }
+        f.pair = false; f.linked = false;
+    }
     if (f.pair) f.linked = false;
     return f;
 }
@@ -856,6 +882,22 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
                        P.pix_ivar, p->npix, npair, d_kl2, d_dk2, d_f2, d_u2, d_iv2);
     HIP_TRY(c, hipGetLastError());
     P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.iv2 = d_iv2; P.npair = npair;
+    c->store_f32 = false;
+    if (c->store_dtype == MSX_STORE_F32) {
+        // A separately labelled storage precision (store_dtype): the R table rounded to float32, read by the
+        // fused binary variants compiled for it.  Everything else keeps float64 -- and the forms that have no such variant
+        // (pair, linked, triples, spectra beyond the LDS) are refused rather than mixed in: one staged problem, one precision.
+        if (p->nspec != 2 || model_in_global)
+            return fail(c, MSX_ERR_STATE, "msx_set_grid_storage(MSX_STORE_F32): binaries of at most 17,152 pixels only");
+        float2 *d_r2f = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&d_r2f, sizeof(float2) * nn * npair)); tr.push_back(d_r2f);
+        const int64_t tot = nn * npair;
+        hipLaunchKernelGGL(narrow_r_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_r2, d_r2f, tot);
+        HIP_TRY(c, hipGetLastError());
+        P.r2f = d_r2f;
+        c->store_f32 = true;
+    }
+    float2 *const d_r2f_for_quads = const_cast<float2 *>(P.r2f);
     {   // the float32 tables in quads, for the 512-thread variants
         const int64_t nquad = (npair + 1023) / 1024 * 512;
         float4 *d_h4 = nullptr, *d_dk4 = nullptr, *d_h4b = nullptr, *d_dk4b = nullptr;
@@ -870,6 +912,15 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, 1), dim3(256), 0, c->stream, d_dk2, npair, nquad, (int64_t)256, d_dk4b);
         HIP_TRY(c, hipGetLastError());
         P.h4 = d_h4; P.dk4 = d_dk4; P.h4b = d_h4b; P.dk4b = d_dk4b; P.nquad = nquad;
+        if (d_r2f_for_quads) {  // float32 storage: the R table by quad too
+            float4 *d_r4f = nullptr, *d_r4fb = nullptr;
+            HIP_TRY(c, hipMalloc((void **)&d_r4f, sizeof(float4) * nn * nquad)); tr.push_back(d_r4f);
+            HIP_TRY(c, hipMalloc((void **)&d_r4fb, sizeof(float4) * nn * nquad)); tr.push_back(d_r4fb);
+            hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, (unsigned)nn), dim3(256), 0, c->stream, d_r2f_for_quads, npair, nquad, (int64_t)512, d_r4f);
+            hipLaunchKernelGGL(gather_quads_kernel, dim3(gq, (unsigned)nn), dim3(256), 0, c->stream, d_r2f_for_quads, npair, nquad, (int64_t)256, d_r4fb);
+            HIP_TRY(c, hipGetLastError());
+            P.r4f = d_r4f; P.r4fb = d_r4fb;
+        }
     }
     // band integrals
     double *d_tab = nullptr;
@@ -1042,6 +1093,13 @@ int msx_diag_read_stamps(msx_ctx *c, int64_t n, unsigned long long *out) {
     return MSX_OK;
 }
 #endif
+
+int msx_set_grid_storage(msx_ctx *c, int32_t store_dtype) {
+    if (!c || (store_dtype != MSX_STORE_F64 && store_dtype != MSX_STORE_F32))
+        return fail(c, MSX_ERR_INVALID, "msx_set_grid_storage: MSX_STORE_F64 or MSX_STORE_F32");
+    c->store_dtype = store_dtype;
+    return MSX_OK;
+}
 
 int msx_set_path(msx_ctx *c, int32_t path) {
     if (!c || (path != MSX_PATH_AUTO && path != MSX_PATH_FUSED && path != MSX_PATH_LINKED && path != MSX_PATH_PAIR))
@@ -1971,7 +2029,8 @@ static int64_t requested_bytes_of(msx_ctx *c, int64_t n, const FormChoice &f, co
     //   blend: 12-B {R f64, H f32} per corner + {k_lo f64, dk f32} + data flux, u (f64)        per pixel
     //   chi^2 pass: 1/err^2, and -- unless the variant kept them in LDS (PF) -- u and data flux again
     const bool pf = v && v->pf;
-    int64_t b = npix * (12 * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
+    const int64_t per_corner = (v && v->r32) ? 8 : 12;  // {R f64 | f32, H f32}
+    int64_t b = npix * (per_corner * (int64_t)c->P.nspec * 4 + 12 + 16 + (pf ? 8 : 24)) + 8 * (2 * c->P.nspec + 2) + 12;
     // the linked form: every segment's workgroup reads theta and writes its partials (counters, sums, range; chi^2 sum
     // and candidates: <= 64 of them as a rule), reads the other segments' partials, and one of them their candidates
     if (f.linked) {
@@ -2023,7 +2082,7 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
         threads = v->threads; dyn = (int64_t)ch.dyn_lds;
         grid = f.linked ? ((m + 7) & ~7ll) * c->nseg : m;
         nm = std::string("logprob_kernel<NS=") + std::to_string(v->ns) + ", " + std::to_string(v->threads) + " threads" +
-             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + "> (" + v->what + ")";
+             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + "> (" + v->what + ")";
     }
     hipFuncAttributes at;
     HIP_TRY(c, hipFuncGetAttributes(&at, fn));

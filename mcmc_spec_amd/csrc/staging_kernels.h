@@ -45,6 +45,12 @@ __device__ __forceinline__ void element_pixels(int64_t e, int64_t npix, int64_t 
     *pa = a < npix ? a : npix - 1;
     *pb = b < npix ? b : npix - 1;
 }
+// the R table once more in float32 (msx_set_grid_storage(MSX_STORE_F32): a separately labelled storage precision)
+__global__ void narrow_r_kernel(const double2 *__restrict__ r2, float2 *__restrict__ r2f, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r2f[i] = make_float2((float)r2[i].x, (float)r2[i].y);
+}
+
 // R = lo + (hi - lo) t, H = hi t of one grid node (blockIdx.y) at both pixels of element e
 __global__ void gather_rh_kernel(const double *__restrict__ grid, int64_t nwl, const int64_t *__restrict__ lo,
                                  const double *__restrict__ t, int64_t npix, int64_t npair, double2 *__restrict__ R,
