@@ -84,10 +84,19 @@ def build():
             continue
         j = jload(os.path.basename(name))
         cfg = j['config'].get('baseline_config')
-        o.append('| `%s`: config %s, %d steps | %s µs/step = **%s M evals/s**; kernel %s µs by HIP events; `roofline.frac` %s; un-ramped %s µs/step; '
-                 'clock probe %s MHz, walker %s µs, first start → last end %s µs |' %
+        lab = '' if (j.get('storage') or {}).get('R', 'f64') == 'f64' else ' — **float32-STORED grid table: a separately labelled precision, not the headline**'
+        o.append(('| `%s`: config %s, %d steps' + lab + ' | %s µs/step = **%s M evals/s**; kernel %s µs by HIP events; `roofline.frac` %s; un-ramped %s µs/step; '
+                  'clock probe %s MHz, walker %s µs, first start → last end %s µs |') %
                  (b['file'], cfg, b['steps'], f(b['us_step'], 2), f(b['mevals'], 2), f(b['kern'], 2), f(b['frac'], 3),
                   f(b['unr'] * 1e3 if b['unr'] else None, 2), f(b['mhz'], 0), f(b['walker'], 2), f(b['span'], 2)))
+    for name in sorted(glob.glob(os.path.join(PROF, TAG + '_rehearsal_*.json'))):
+        j = jload(os.path.basename(name))
+        bt = j['config'].get('block_tuned_next_to_the_collective') or {}
+        cands = '; '.join('%s: %s' % (k, f(v, 1)) for k, v in (bt.get('candidates_us_per_step') or {}).items())
+        o.append('| `%s`: ONE-GPU rehearsal of the N > 1 loop (self-launch through `torch.distributed.run`, one-rank RCCL communicator, all-gather '
+                 'every step), config %s, %d steps | %s µs/step; `%s`; `gather_verified` %s; set-up candidates, µs per step (%s): %s → *%s* |' %
+                 (os.path.basename(name), j['config'].get('baseline_config'), j['steps'], f(j['ms_per_step'] * 1e3, 2), j['config']['collective'],
+                  j.get('gather_verified'), bt.get('timed_as'), cands, bt.get('taken')))
     o.append('')
     # ---- batch sweep
     rows = jlines(TAG + '_sweep_4096px.jsonl')
