@@ -34,9 +34,14 @@ __device__ __forceinline__ void fit_coefs(const DevProblem &P, const double (&q)
 }
 // one pixel's chi^2 term before the median's scale^2: (model - data / P(u))^2 / err^2      mft6.py:196,120
 __device__ __forceinline__ double chi_term(double c0, double c1, double c2, double u, double f, double e, double xv, bool live) {
+#pragma clang fp contract(off)
+    // (no contraction: the term is a PRODUCT, added by the caller.  Where `live` is a compile-time true -- the pair kernel's
+    // FULL variants -- nothing stands between this multiply and the caller's add any more, and a fused multiply-add there
+    // would round differently from every variant that selects on `live`: a walker's bits must not depend on the variant.)
     const double poly = fma(fma(c2, u, c1), u, c0);
     const double r = xv - fast_div(f, poly);
-    return live ? (r * r) * e : 0.0;
+    const double t = (r * r) * e;
+    return live ? t : 0.0;
 }
 // the walker's value from its chi^2 sum (fused modes: before scale^2), the two medians and the recipe's scalars
 __device__ __forceinline__ double fused_total(const DevProblem &P, double chi_sum, double med_data, double med_model, int npix,

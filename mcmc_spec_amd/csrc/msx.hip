@@ -545,11 +545,17 @@ int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
     // (always the variant that loads the extinction terms: a problem staged without extinction -- every walker at
     // redc = 0 -- takes the unreddened values from it all the same and pays for the H rows; the variant without them
     // spilled registers at 4096 pixels and is not built)
-#define MSX_PAIR_GO(T_, NT_) MSX_PAIR_GO2(T_, NT_, true)
+#define MSX_PAIR_GO(T_, NT_) do { if (full) MSX_PAIR_GOF(T_, NT_); else MSX_PAIR_GO2(T_, NT_, true); } while (0)
+#define MSX_PAIR_GOF(T_, NT_)                                                                                                \
+    hipLaunchKernelGGL((logprob_pair_kernel<T_, NT_, true, true>), g, dim3(T_), 0, A.s, A.theta, (const unsigned char *)c->d_recipe_block, \
+                       A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status)
+    // (FULL: the spectrum fills the variant exactly -- no clamps, no validity selects; pair_kernel.h)
+    const bool full = P.npix == 2 * ne && (ne == 2 * 512 || ne == 4 * 512);
     // (512 threads, two workgroups per CU at <= 128 VGPRs: 16 waves per CU.  The 256-thread variants -- two per CU at
     // 256 VGPRs, 8 waves -- measured 411.8 us against 344.8 at 16,384 walkers and are not built.)
     if (ne <= 2 * 512) MSX_PAIR_GO(512, 2); else MSX_PAIR_GO(512, 4);
 #undef MSX_PAIR_GO
+#undef MSX_PAIR_GOF
 #undef MSX_PAIR_GO2
     HIP_TRY(c, hipGetLastError());
     return MSX_OK;
@@ -2069,9 +2075,11 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
     const Variant *v = nullptr;
     if (f.pair) {
         const bool nt2 = c->P.npair <= 2 * 512;
-        fn = nt2 ? (const void *)logprob_pair_kernel<512, 2, true> : (const void *)logprob_pair_kernel<512, 4, true>;
+        const bool full = c->P.npix == 2 * c->P.npair && (c->P.npair == 2 * 512 || c->P.npair == 4 * 512);
+        fn = full ? (nt2 ? (const void *)logprob_pair_kernel<512, 2, true, true> : (const void *)logprob_pair_kernel<512, 4, true, true>)
+                  : (nt2 ? (const void *)logprob_pair_kernel<512, 2, true> : (const void *)logprob_pair_kernel<512, 4, true>);
         nm = std::string("pair_plan_kernel + logprob_pair_kernel<512 threads, ") + (nt2 ? "2" : "4") +
-             " element trips per lane> (planner: one thread per walker; two walkers of one grid cell per workgroup, one set of row loads, model values in registers; two workgroups per CU)";
+             " element trips per lane" + (full ? ", FULL" : "") + "> (planner: one thread per walker; two walkers of one grid cell per workgroup, one set of row loads, model values in registers; two workgroups per CU)";
         threads = 512; grid = m;
     } else {
         const int B = f.linked ? 512 : block_threads > 0 ? block_threads : pick_block(c, m, c->P.npix);
