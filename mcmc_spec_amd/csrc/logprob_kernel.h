@@ -152,7 +152,8 @@ __device__ __forceinline__ void walker_done(const SmpView &P, const WalkerDesc &
 //         run-time flag inside the pass, whose merge points would bring register copies back.
 // Holds plain pointers, never a reference to the by-value kernel argument (see DevProblem).
 // FLDS = the data flux (alone) comes from LDS: the linked form, whose workgroup has room for one more vector of its segment.
-template <int MAXT, bool PF, bool ALWAYS, bool AHEAD, bool FLDS = false>
+// FULL = every element / pixel of every trip is valid (the spectrum is whole trips: logprob_kernel's FULL): no clamps, no selects
+template <int MAXT, bool PF, bool ALWAYS, bool AHEAD, bool FLDS = false, bool FULL = false>
 struct ChiElem {
     static constexpr int VK = kMaxWaves / (MAXT / kWave);
     static constexpr int NSET = AHEAD ? 2 : 1;
@@ -169,7 +170,7 @@ struct ChiElem {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
-            e = e < ne ? e : ne - 1;
+            e = (FULL || e < ne) ? e : ne - 1;
             const unsigned int o16 = (unsigned int)e << 4;
             nv[SET][j] = ld_off(iv2, o16);
             if (!PF) { nu[SET][j] = ld_off(u2, o16); if (!FLDS) nf[SET][j] = ld_off(f2, o16); }
@@ -195,7 +196,7 @@ struct ChiElem {
         for (int j = 0; j < 2; ++j) {
             if (PF) {
                 int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
-                e = e < ne ? e : ne - 1;
+                e = (FULL || e < ne) ? e : ne - 1;
                 cu[j] = u2[e]; cf[j] = f2[e];  // LDS
             } else {
                 cu[j] = nu[SET][j]; cf[j] = nf[SET][j];
@@ -211,7 +212,7 @@ struct ChiElem {
         const double e[4] = {nv[SET][0].x, nv[SET][0].y, nv[SET][1].x, nv[SET][1].y};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            acc[k & (VK - 1)] += chi_term(c0, c1, c2, u[k], f[k], e[k], xv[k], p[k] < npix);  // up to scale^2
+            acc[k & (VK - 1)] += chi_term(c0, c1, c2, u[k], f[k], e[k], xv[k], FULL || p[k] < npix);  // up to scale^2
         }
         // end of a segment of the canonical sum (8192 pixels), more pixels to come: fold it in.  (Uniform: every
         // thread of the workgroup walks the same trips.)
@@ -282,7 +283,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //       the CU's L2 port, whose limit the blend runs at) and widened to float64 in the registers: the arithmetic is the
 //       same float64 chain, the grid values carry 2^-24 instead of 2^-53.  A SEPARATELY LABELLED precision (SURVEY 8b's
 //       store_dtype), never the default; fused binaries only.
-template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false>
+// FULL = the spectrum is whole trips of the variant with no pad pixels (npix == 2 npair, npair a multiple of the trip:
+//        BASELINE's 4096 pixels): every lane of every trip holds live pixels, so the clamps of element and pixel indices,
+//        the per-pixel validity compares and their selects are compiled out of the blend, the chi^2 pass and the candidates'
+//        gather.  Same arithmetic on the same pixels: same bits (the launcher picks it; msx.hip, choose_variant).
+template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false, bool FULL = false>
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
@@ -625,8 +630,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                              auto sub_c) __attribute__((always_inline)) {
         constexpr int sub = decltype(sub_c)::value;
         const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
-        const bool ok[U] = {live && pa < npix, live && pb < npix};
-        const int pp[U] = {pa < npix ? pa : npix - 1, pb < npix ? pb : npix - 1};
+        const bool ok[U] = {FULL || (live && pa < npix), FULL || (live && pb < npix)};
+        const int pp[U] = {(FULL || pa < npix) ? pa : npix - 1, (FULL || pb < npix) ? pb : npix - 1};
         static_assert(!PF || kQuad, "PF: u and the data flux come from LDS (staged in phase 0; the quad trips read them there)");
         const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
         unsigned int fxs[U] = {0u, 0u};
@@ -655,7 +660,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
       if constexpr (kQuad) {
       for (int e0 = seg * kSegElems; e0 < e_end; e0 += 2 * B) {  // (segments are whole numbers of quad trips)
         const int eA = e0 + tid, eB = eA + B;
-        const bool liveA = eA < e_end, liveB = eB < e_end;
+        const bool liveA = FULL || eA < e_end, liveB = FULL || eB < e_end;
         const int ecA = liveA ? eA : e_end - 1, ecB = liveB ? eB : e_end - 1;
         const unsigned int oA = (unsigned int)ecA << 4, oB = (unsigned int)ecB << 4;
         const unsigned int oq = (unsigned int)((e0 >> 1) + tid) << 4;  // quad (e0 / 1024) * 512 + tid, 16 bytes each
@@ -717,7 +722,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         auto one = [&](auto sub_c) __attribute__((always_inline)) {
         constexpr int sub = decltype(sub_c)::value;
         const int e = e0 + sub * B + tid;
-        const bool live = e < e_end;
+        const bool live = FULL || e < e_end;
         const int ec = live ? e : e_end - 1;
         const unsigned int o16 = (unsigned int)ec << 4, o8 = (unsigned int)ec << 3;
         // data flux and u: requested with the rows by the 256-thread variant (one wait per trip instead of two:
@@ -1000,11 +1005,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     bool rank_split = false;  // (<= 64 candidates: ranked by several waves, picked by wave 0 behind the closing barrier)
     LogbinSel rank_Q;
     if (early && !LK) {  // (linked: only vectors the early histogram could not handle come this far)
-        ChiElem<MAXT, PF, true, kAhead> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
+        ChiElem<MAXT, PF, true, kAhead, false, FULL> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
                                          &red[0][0][0], {}, {}, {}, 0.0};
         // positive normal values spanning < 8 binades (anything else -- zeros, negatives, infinities, NaNs, huge ranges --
         // takes block_median below); > 256 equal-bin candidates come back unsolved too
-        if (frange_applicable(fmin_, fmax_)) solved = logbin_median<MAXT>(model, npix, fmin_, S, chi_fast, &med_model, &rank_split, &rank_Q);
+        if (frange_applicable(fmin_, fmax_)) solved = logbin_median<MAXT, FULL>(model, npix, fmin_, S, chi_fast, &med_model, &rank_split, &rank_Q);
         // the ranking of <= 64 candidates, a few trips of eight per wave (the waves that have nothing else left to do);
         // wave 0 reads the sums behind the closing barrier
         constexpr int kRankWaves = MAXT / kWave > 4 ? 4 : 2, kRank0 = MAXT / kWave > 4 ? 3 : 2;

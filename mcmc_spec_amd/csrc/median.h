@@ -141,7 +141,8 @@ struct NoElem {
 // of 8 BT): elem.process4, then per(p, xv).  A pixel p of a trip is valid iff p < p_hi.
 // (Validity travels as the pixel index, not as a flag: flags handed through arrays get packed into bytes and
 // unpacked again, a dozen instructions per trip; a compare against the end is one.)
-template <int BT, class Elem, class Per>
+// (FULL: every pixel of every trip is valid -- the caller has checked that the range is whole trips -- so no clamp)
+template <int BT, bool FULL = false, class Elem, class Per>
 __device__ __forceinline__ void pass_trips_range(const double *model, int p_lo, int p_hi, Elem &elem, Per per) {
     const int tid = threadIdx.x;
     auto one = [&](int base, auto par) __attribute__((always_inline)) {
@@ -151,7 +152,7 @@ __device__ __forceinline__ void pass_trips_range(const double *model, int p_lo, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // loads first, then use
             p[u] = pass_pixel<BT>(base, u, tid);
-            xv[u] = model[p[u] < p_hi ? p[u] : p_hi - 1];
+            xv[u] = model[(FULL || p[u] < p_hi) ? p[u] : p_hi - 1];
         }
         elem.template process4<decltype(par)::value>(base, p, xv);
         per(p, xv);
@@ -162,9 +163,9 @@ __device__ __forceinline__ void pass_trips_range(const double *model, int p_lo, 
     }
 }
 // ... over the whole vector
-template <int BT, class Elem, class Per>
+template <int BT, bool FULL = false, class Elem, class Per>
 __device__ __forceinline__ void pass_trips(const double *model, int npix, Elem &elem, Per per) {
-    pass_trips_range<BT>(model, 0, npix, elem, per);
+    pass_trips_range<BT, FULL>(model, 0, npix, elem, per);
 }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {  // l wave-uniform
@@ -611,7 +612,7 @@ __device__ __forceinline__ bool frange_applicable(unsigned int f0, unsigned int 
 // hmin = F of the vector's minimum; the caller has checked frange_applicable
 // split != nullptr: with <= 64 candidates the ranking is left to the caller (logbin_rank_part / _pick; *split = true, the
 // bins in *Qout, the pad slots written) -- it has idle waves to spread it over
-template <int BT, class Elem>
+template <int BT, bool FULL = false, class Elem>
 __device__ __forceinline__ bool logbin_median(const double *model, int npix, unsigned int hmin, BlockScratch &S, Elem &elem,
                                               double *med_out, bool *split = nullptr, LogbinSel *Qout = nullptr) {
     const bool need_two = (npix & 1) == 0;
@@ -623,11 +624,11 @@ __device__ __forceinline__ bool logbin_median(const double *model, int npix, uns
     const unsigned int sel_p = Q.sel_p, nxt_p = Q.nxt_p;
     MED_STAMP(2);
     // ---- one pass: chi^2 terms + the candidates (the values of the one or two bins above) ----------------------
-    pass_trips<BT>(model, npix, elem, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
+    pass_trips<BT, FULL>(model, npix, elem, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned int pb = logbin(xv[u]);
-            if (p[u] < npix && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
+            if ((FULL || p[u] < npix) && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
         }
     });
     if (split) {

@@ -93,6 +93,7 @@ struct msx_ctx {
     bool pf_ok = false;   // the LDS-staged-statics variants fit (msx_stage_problem)
     bool pf256_ok = false; // ... the 256-thread two-per-CU one (two workgroups of it in a CU's LDS)
     bool use_pf = true;   // MSX_NO_PF=1 in the environment turns them off (A/B measurements)
+    bool use_full = true; // MSX_NO_FULL=1: never the FULL (no-clamp) variants of the fused kernel
     int q256 = -1;           // 256-thread launches: the two-per-CU quad-trip variant always (1) / never (0) / up to two walkers per CU (-1); MSX_Q256
     bool force_sh2 = false;  // MSX_NO_SH2=0: binaries take the <= 128-VGPR variant even with a CU to themselves (A/B measurements)
     bool zero_copy = true;   // host-pointer entry point without copy commands; MSX_ZERO_COPY=0 restores them
@@ -348,13 +349,15 @@ bool takes_pf(const msx_ctx *c, int64_t n) {
 struct Variant {
     const void *fn;
     int ns, threads;
-    bool gm, sh, pf, lk, r32;
+    bool gm, sh, pf, lk, r32, full;
     const char *what;
 };
 #define MSX_V(NS_, T_, GM_, SH_, PF_, LK_, WHAT_) \
-    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, false, WHAT_}
+    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, false, false, WHAT_}
 #define MSX_V32(T_, SH_, PF_, WHAT_) \
-    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, true>, 2, T_, false, SH_, PF_, false, true, WHAT_}
+    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, true>, 2, T_, false, SH_, PF_, false, true, false, WHAT_}
+#define MSX_VF(T_, SH_, PF_, WHAT_) \
+    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, false, true>, 2, T_, false, SH_, PF_, false, false, true, WHAT_}
 const Variant kVariants[] = {
     MSX_V(2, 256, false, false, false, false, "three workgroups per CU"),
     MSX_V(2, 256, false, true, false, false, "two per CU, four pixels per lane and trip"),
@@ -376,12 +379,20 @@ const Variant kVariants[] = {
     MSX_V32(512, false, false, "one workgroup per CU, four pixels per lane and trip; R table stored in float32"),
     MSX_V32(512, true, false, "<= 128 VGPRs: two workgroups fit a CU; rows one star at a time; R table stored in float32"),
     MSX_V32(512, false, true, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; R table stored in float32"),
+    // the 256-thread binary variants once more for spectra that fill their trips exactly (FULL: no clamps, no validity
+    // selects).  Same box, general / FULL, us per batch of 4096 px: 512 walkers 24.2 / 23.1, 1,024: 39.5 / 37.8,
+    // 2,048: 63.3 / 60.4, 2,304: 68.9 / 66.7.  The 512-thread variants were built the same way and were SLOWER
+    // (256 walkers 14.35 -> 14.55 us by HIP events: the clamps' removal moved the scheduler's load order), so they are not here.
+    MSX_VF(256, false, false, "three workgroups per CU; whole trips, no clamps"),
+    MSX_VF(256, true, false, "two per CU, four pixels per lane and trip; whole trips, no clamps"),
+    MSX_VF(256, true, true, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps"),
 };
 #undef MSX_V
 #undef MSX_V32
-const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk, bool r32 = false) {
+#undef MSX_VF
+const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk, bool r32 = false, bool full = false) {
     for (const Variant &v : kVariants)
-        if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk && v.r32 == r32) return &v;
+        if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk && v.r32 == r32 && v.full == full) return &v;
     return nullptr;
 }
 struct VariantChoice {
@@ -417,6 +428,15 @@ VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, i
         if (pf) return {find_variant(2, 512, false, false, true, false, true), lds_pf};
         if (sh) return {find_variant(2, 512, false, true, false, false, true), lds};
         return {find_variant(2, 512, false, false, false, false, true), lds};
+    }
+    // FULL: no pad pixels and whole trips (a trip of the 256-thread variants is 512 elements = 1024 pixels): the variants
+    // without clamps (MSX_NO_FULL=1 in the environment keeps the general ones: A/B measurements)
+    const bool full = ns == 2 && B == 256 && c->use_full && P.npix == 2 * P.npair && P.npair % 512 == 0;
+    if (full) {
+        const bool q256 = c->q256 > 0 || (c->q256 < 0 && n <= 2 * (int64_t)c->prop.multiProcessorCount);
+        if (q256 && c->pf256_ok && c->use_pf) return {find_variant(2, 256, false, true, true, false, false, true), lds_pf};
+        if (q256) return {find_variant(2, 256, false, true, false, false, false, true), lds};
+        return {find_variant(2, 256, false, false, false, false, false, true), lds};
     }
     if (ns == 2) {
         // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
@@ -603,6 +623,7 @@ int msx_create(int device, msx_ctx **out) {
     c->device = device;
     memset(&c->P, 0, sizeof(c->P));
     if (const char *e = getenv("MSX_NO_PF")) c->use_pf = !(e[0] == '1');
+    if (const char *e = getenv("MSX_NO_FULL")) c->use_full = !(e[0] == '1');
     if (const char *e = getenv("MSX_NO_SH2")) c->force_sh2 = e[0] == '0';
     if (const char *e = getenv("MSX_Q256")) c->q256 = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("MSX_LINKED")) c->linked = e[0] == '1' ? 1 : 0;
@@ -2090,7 +2111,7 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
         threads = v->threads; dyn = (int64_t)ch.dyn_lds;
         grid = f.linked ? ((m + 7) & ~7ll) * c->nseg : m;
         nm = std::string("logprob_kernel<NS=") + std::to_string(v->ns) + ", " + std::to_string(v->threads) + " threads" +
-             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + "> (" + v->what + ")";
+             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + (v->full ? ", FULL" : "") + "> (" + v->what + ")";
     }
     hipFuncAttributes at;
     HIP_TRY(c, hipFuncGetAttributes(&at, fn));
