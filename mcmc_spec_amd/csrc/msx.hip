@@ -122,9 +122,8 @@ struct msx_ctx {
     int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _PAIR / _LINKED (msx_set_path)
     // pair form (pair_kernel.h): binaries of <= 4096 pixels with the register-resident recipe
     int64_t pair_rows = 0;          // walkers per sub-batch = capacity of the planner's item lists (0: no pair form here)
-    // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN; 0 = never).  Measured at 4096 px
-    // (profiles/r3_pair_sweep.txt): 2,048 walkers 74.0 us against 69.8 fused (the planner's launch costs more than the
-    // shared loads save), 4,096: 111.8 against 121.2, 8,192: 188.7 against 225.1, 16,384: 344.8 against 438.3.
+    // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN; 0 = never); set per problem by
+    // msx_stage_problem, with the measurements behind the rule
     int64_t pair_min_walkers = 4096;
     int32_t *d_pair_plan = nullptr; // the planner's output (pair_kernel.h: header, pairs, singles)
     PairItem *d_pair_items = nullptr;   // ... and its items: the pairs' recipes, [pair_rows / 2]
@@ -1078,13 +1077,14 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         c->h_pair_stats[0] = 1; c->h_pair_stats[1] = 0;  // (nothing known yet: try)
         c->pair_auto_launches = 0;
         c->pair_rows = rows;
-        // From where the pair form pays (the planner costs 13 us whatever the batch): measured on 256 CUs, fused against
-        // pair -- 4096 px: 2,048 walkers 62.9 / 71.5 us, 2,304: 73.9 / 70.3, 3,072: 87.9 / 83.0; 1194 and 2048 px: 2,304
-        // walkers 45.5 / 49.3 and 48.8 / 52.1, 4,096: 72.7 / 68.0 and 76.8 / 71.6.  In walkers per CU: 9 for the long
-        // spectra, 16 for the short ones.
+        // From where the pair form pays (the planner costs 11.5 us whatever the batch; 14.6 before its searches went 4-ary
+        // and side by side, round 4): measured on 256 CUs in one process, fused (FULL variants) against pair -- 4096 px:
+        // 1,536 walkers 52.6 / 52.3 us, 2,048: 64.1 / 59.4, 2,304: 66.9 / 62.4, 4,096: 109.8 / 90.5, 16,384: 402.9 / 287.9.
+        // 1194 and 2048 px (round 3, planner 3 us slower): 2,304 walkers 45.5 / 49.3 and 48.8 / 52.1, 4,096: 72.7 / 68.0
+        // and 76.8 / 71.6.  In walkers per CU: 8 for the long spectra, 16 for the short ones.
         {
             const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-            c->pair_min_walkers = (p->npix > 3072 ? 9 : 16) * cus;
+            c->pair_min_walkers = (p->npix > 3072 ? 8 : 16) * cus;
         }
         if (const char *e = getenv("MSX_PAIR_MIN")) c->pair_min_walkers = atoll(e) > 0 ? std::max<int64_t>(2, atoll(e)) : INT64_MAX;
     }

@@ -496,20 +496,23 @@ __device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane
     *partner_lane = -1;
     *leftover = false;
     unsigned long long rem = __ballot(tag != 0ull);
+    unsigned long long mygrp = 0ull;  // the lanes of this lane's tag, once its group's trip has come
     // (uniform: one trip per distinct cell in the wave -- up to kPlanCells of them: a wave with more is part of an
-    // ensemble spread over the grid, where there is little to pair and no point in 64 trips; the rest stay unplaced)
+    // ensemble spread over the grid, where there is little to pair and no point in 64 trips; the rest stay unplaced.
+    // A trip only finds the group; what a lane does with its group is worked out once, after the loop.)
     for (int trip = 0; rem != 0ull && trip < kPlanCells; ++trip) {
         const int leader = __ffsll((long long)rem) - 1;
         const unsigned long long ltag = readlane_u64(tag, leader);
-        const unsigned long long grp = __ballot(tag == ltag) & rem;
-        if ((grp >> lane) & 1ull) {
-            const int r = __popcll(grp & ((1ull << lane) - 1ull));
-            if ((r & 1) == 0) {
-                const unsigned long long nxt = lane < 63 ? (grp & ~((2ull << lane) - 1ull)) : 0ull;
-                if (nxt != 0ull) *partner_lane = __ffsll((long long)nxt) - 1; else *leftover = true;
-            }
-        }
+        const unsigned long long grp = __ballot(tag == ltag);  // (tags are never 0 here, and a lane of this tag is still in rem)
+        mygrp = (tag == ltag) ? grp : mygrp;
         rem &= ~grp;
+    }
+    if (mygrp != 0ull) {
+        const int r = __popcll(mygrp & ((1ull << lane) - 1ull));
+        if ((r & 1) == 0) {
+            const unsigned long long nxt = lane < 63 ? (mygrp & ~((2ull << lane) - 1ull)) : 0ull;
+            if (nxt != 0ull) *partner_lane = __ffsll((long long)nxt) - 1; else *leftover = true;
+        }
     }
     if ((rem >> lane) & 1ull) *leftover = true;
 }
@@ -519,43 +522,64 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
                  double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, PairItem *__restrict__ pair_items,
                  PairRec *__restrict__ single_items, double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats, DevProblem P) {
     constexpr int NS = 2, ndim = 6;
-    __shared__ double s_isot[4 * kWave], s_isog[4 * kWave], s_isol[4 * kWave], s_teff[kWave], s_logg[32];
-    __shared__ double s_ave[2 * kWave], s_avm[2 * kWave], s_avs[2 * kWave];
+    __shared__ double s_isot[kPlanIsoPad], s_isol[kPlanIsoPad], s_teff[kPlanNodePad + 1], s_logg[kPlanNodePad + 1];
+    __shared__ double4 s_isopack[kPlanIsoPad];
+    __shared__ double s_ave[kPlanIsoPad], s_avm[2 * kWave], s_avs[2 * kWave];
     __shared__ unsigned int s_pmask[kWave];
     __shared__ unsigned long long s_cards[kPlanSortMax];
     __shared__ int2 s_pairs[kPlanSortMax / 2];
     __shared__ unsigned long long s_left[kPlanSortMax];
     __shared__ int s_nc, s_np, s_nl, s_ns, s_basep, s_basel;
+    static_assert(kPlanThreads == kPlanIsoPad, "one table entry per thread");
     const int niso = niso_nt & 0xffff, nt = niso_nt >> 16;
     const int ng = ng_mode_fast & 0xff, mode = (ng_mode_fast >> 8) & 0xff;
     const GateArgs gates = {gate_tmin, gate_tmax, ((ng_mode_fast >> 18) & 1) != 0, ((ng_mode_fast >> 19) & 1) != 0};
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ int s_where[kPlanThreads];  // where this thread's walker goes: 2 (pair index) + slot, or -2 - (single index)
     s_where[tid] = -1;
-    {
-        const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT), *g_isog = reinterpret_cast<const double *>(rblk + kRbIsoG);
-        const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
-        if (tid < niso) { s_isot[tid] = g_isot[tid]; s_isog[tid] = g_isog[tid]; s_isol[tid] = P.iso_l[tid]; }
-        if (tid < P.nav + 1) s_ave[tid] = P.av_edges[tid];
-        if (tid < P.nav) { s_avm[tid] = P.av_mu[tid]; s_avs[tid] = P.av_sig[tid]; }
-        if (tid < nt) { s_teff[tid] = g_teff[tid]; s_pmask[tid] = reinterpret_cast<const unsigned int *>(rblk + kRbPresent)[tid]; }
-        if (tid < ng) s_logg[tid] = g_logg[tid];
-        if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
-    }
-    // (the walker's coordinates are requested before the barrier that publishes the tables: one memory round trip, not two)
+#ifdef MSX_STAMPS
+    if (tid == 0) msx_stamp_off = 0;
+#endif
+    MSX_STAMP(P, blockIdx.x, 0);
+    // (the walker's coordinates are requested first, with the tables: one memory round trip, not two)
     const int64_t i = (int64_t)blockIdx.x * kPlanThreads + tid;
     const bool mine = i < n;
     double t[ndim];
 #pragma unroll
     for (int k = 0; k < ndim; ++k) t[k] = mine ? theta[i * ndim + k] : 0.0;
+    {
+        // the tables, padded with +inf to the sizes the 4-ary searches walk (recipe.h, recipe_scalar2): every load first
+        // (clamped indices, no branches between them: one round trip), then the stores
+        const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT);
+        const double4 *g_pack = reinterpret_cast<const double4 *>(rblk + kRbIsoPack);
+        const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
+        const int nav = P.nav;
+        const int ii = tid < niso ? tid : niso - 1, it = tid < nt ? tid : nt - 1, ig = tid < ng ? tid : ng - 1;
+        const int ie = tid < nav + 1 ? tid : 0, ia = tid < nav ? tid : 0;
+        const double v_isot = g_isot[ii], v_isol = P.iso_l[ii];
+        const double4 v_pack = g_pack[tid];  // (the block holds all 256 entries)
+        const double v_teff = g_teff[it], v_logg = g_logg[ig];
+        const unsigned int v_mask = reinterpret_cast<const unsigned int *>(rblk + kRbPresent)[it];
+        const double v_ave = nav > 0 ? P.av_edges[ie] : 0.0, v_avm = nav > 0 ? P.av_mu[ia] : 0.0, v_avs = nav > 0 ? P.av_sig[ia] : 0.0;
+        s_isot[tid] = tid < niso ? v_isot : INFINITY;
+        s_isol[tid] = v_isol;
+        s_isopack[tid] = v_pack;
+        s_ave[tid] = (nav > 0 && tid < nav + 1) ? v_ave : INFINITY;
+        if (tid < 2 * kWave) { s_avm[tid] = v_avm; s_avs[tid] = v_avs; }
+        if (tid <= kPlanNodePad) { s_teff[tid] = tid < nt ? v_teff : INFINITY; s_logg[tid] = tid < ng ? v_logg : INFINITY; }
+        if (tid < kWave) s_pmask[tid] = tid < nt ? v_mask : 0u;
+        if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
+    }
     __syncthreads();
+    MSX_STAMP(P, blockIdx.x, 1);
     unsigned long long tag = 0ull;  // 0: nothing left to evaluate (rejected by the prior box, or an error status)
     PairRec mrec;
     if (mine) {
-        const ScalarTabs T = {s_isot, s_isog, s_teff, s_logg, s_pmask, niso, nt, ng};
-        int node[NS * 4];
+        const ScalarTabs T = {s_isot, s_teff, s_logg, s_isopack, s_pmask, s_ave, niso, nt, ng, P.nav};
+        int node[NS * 4], iso_lo[NS], av_bin;
         double w[NS * 4], redc;
-        const int st = recipe_scalar2(gates, T, mode, t, node, w, &redc);
+        const int st = recipe_scalar2(gates, T, mode, t, node, w, &redc, iso_lo, &av_bin);
+        MSX_STAMP(P, blockIdx.x, 2);
         if (st != MSX_W_OK) {  // final here, like the fused kernel's first lines
             logp[i] = (st > MSX_W_REJECT) ? nan_with_status(st) : -INFINITY;
             status[i] = st;
@@ -569,9 +593,11 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
             // what only the walker's last line reads: the Gaussian prior terms (f1) and the contrast / photometry
             // chi^2 (A5/A6) -- here and not by two waves of the pair kernel, whose workgroup would wait for their table
             // round trips after its median is long done
-            const ScalarPriorTabs TP = {s_isot, s_isol, s_ave, s_avm, s_avs};
-            R->lp = prior_terms_scalar2(P, TP, mode, t);
+            const ScalarPriorTabs TP = {s_isot, s_isol, s_avm, s_avs};
+            R->lp = prior_terms_scalar2(P, TP, mode, t, av_bin, iso_lo);
+            MSX_STAMP(P, blockIdx.x, 3);
             R->chi_extra = band_terms_scalar2(P, mode, t, node, w);
+            MSX_STAMP(P, blockIdx.x, 4);
             unsigned long long h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
             for (int c = 0; c < NS * 4; ++c) {
@@ -606,12 +632,14 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         (void)bases;
     }
     __syncthreads();
+    MSX_STAMP(P, blockIdx.x, 5);
     // ---- 2. the waves' leftovers meet inside the workgroup: the same ballots over the card list, 64 cards per wave, in
     //      rounds (128 cards -> at most one per cell and wave -> one wave -> at most one per cell) -------------------------
     int nc = s_nc;
     const int nsingle = s_ns;
     unsigned long long *src = s_cards, *dst = s_cards + kPlanSortMax / 2;
     for (int round = 0; round < 3 && nc > 1; ++round) {  // (uniform)
+        const bool one_wave = nc <= kWave;  // every card meets every other in this round: nothing left to find after it
         if (tid == 0) s_nl = 0;
         __syncthreads();
         const int k = tid;  // (nc <= kPlanThreads)
@@ -635,17 +663,20 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         if (left == nc) break;  // nothing met (every card its own cell, or one card per wave): the rest are singles
         nc = left;
         unsigned long long *t_ = src; src = dst; dst = t_;
+        if (one_wave) break;
     }
     __syncthreads();
     for (int k = tid; k < nc; k += kPlanThreads) s_left[nsingle + k] = src[k];
     if (tid == 0) s_nl = nc;
     __syncthreads();
+    MSX_STAMP(P, blockIdx.x, 6);
     // ---- the workgroup's lists to global memory: one atomic add per list.  What the workgroup could not place -- at
     //      most one walker per cell -- is a single. --------------------------------------------------------------------
     const int np = s_np, nl = s_nl;
     if (tid == 0) s_basep = np ? atomicAdd(&plan[2], np) : 0;
     if (tid == 1) s_basel = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;
     __syncthreads();
+    MSX_STAMP(P, blockIdx.x, 7);
     // every walker's recipe goes where its workgroup will look for it
     const int base = blockIdx.x * kPlanThreads;
     for (int k = tid; k < np; k += kPlanThreads) {
@@ -659,6 +690,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         PairRec *dst = wh >= 0 ? &pair_items[wh >> 1].r[wh & 1] : single_items + (-2 - wh);
         *dst = mrec;
     }
+    MSX_STAMP(P, blockIdx.x, 8);
     // ---- the last workgroup to finish publishes the counts and leaves the working counters at zero for the next launch
     // (the ticket is taken after this workgroup's own adds have RETURNED -- their results placed the stores above)
     __syncthreads();
@@ -677,6 +709,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
             atomicExch(&plan[4], 0);
         }
     }
+    MSX_STAMP(P, blockIdx.x, 9);
 }
 
 }  // namespace

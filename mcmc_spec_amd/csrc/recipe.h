@@ -370,9 +370,10 @@ __device__ __forceinline__ double interp_segment(double x0, double y0, double x1
     const double slope = (y1 - y0) / (x1 - x0);
     return fma(slope, x - x0, y0);
 }
+__device__ __forceinline__ double gauss_term_z(double lp, double z) { return lp + -0.5 * (z * z); }
 __device__ __forceinline__ double gauss_term(double lp, double x, double mean, double sig) {  // lp - 0.5 ((x - mean) / sig)^2
     const double z = (x - mean) / sig;
-    return lp + -0.5 * (z * z);
+    return gauss_term_z(lp, z);
 }
 __device__ __forceinline__ double model_radius(double lum, double teff) {  // get_radius, mft6.py:66-85 (Stefan-Boltzmann)
     const double sigma_sb = 5.670374e-5, lsun = 3.839e33;
@@ -398,7 +399,9 @@ __device__ __forceinline__ double band_job_value(const DevProblem &P, const int 
     for (int c = 0; c < NS * 4; ++c) flux += w[c] * P.band_tab[(int64_t)node[c] * nb + P.nc + f];
     return -2.5 * log10(flux / P.pzero[f]);  // mft6.py:780-782
 }
-// icontrast + iphot from the jobs' magnitudes (val(k) = magnitude of job k)
+// icontrast + iphot from the jobs' magnitudes (val(k) = magnitude of job k).  The sum's fused multiply-adds are WRITTEN
+// (the contraction the compiler chose here anyway): the one-thread form below has the same sum spread over branches, where
+// a contraction left to the compiler came out as multiply + add -- one ulp of the total apart.
 template <int NS, class V>
 __device__ __forceinline__ double band_chi(const DevProblem &P, bool redden, double a_v, V val) {
     double chi = 0.0;
@@ -407,13 +410,13 @@ __device__ __forceinline__ double band_chi(const DevProblem &P, bool redden, dou
         if (NS == 3 && f >= P.nc / 2) sec = 2;  // mft6.py:747-749
         const double con = val(f * NS + sec) - val(f * NS);  // mft6.py:741
         const double z = con - P.cmag[f];
-        chi += (z * z) * P.civar[f];  // mft6.py:120,1182
+        chi = fma(z * z, P.civar[f], chi);  // mft6.py:120,1182
     }
     for (int f = 0; f < P.np; ++f) {
         const double mag = val(P.nc * NS + f);
-        const double mred = redden ? mag + a_v * P.pk[f] : mag;  // mft6.py:1163
+        const double mred = redden ? fma(a_v, P.pk[f], mag) : mag;  // mft6.py:1163
         const double z = mred - P.pmag[f];
-        chi += (z * z) * P.pivar[f];  // mft6.py:1188
+        chi = fma(z * z, P.pivar[f], chi);  // mft6.py:1188
     }
     return chi;
 }
@@ -660,74 +663,131 @@ __device__ __forceinline__ void recipe_part1_regs(const DevProblem &P, const Gat
 // walker's weights do not depend on which form computed them (tests/test_gpu_pair.py compares whole batches).
 // ------------------------------------------------------------------------------------------------
 struct ScalarTabs {
-    const double *isot, *isog, *teff, *logg;  // LDS copies of the recipe block
+    // LDS copies of the recipe block, every table padded with +inf to the size its search walks (kPlanIsoPad / kPlanNodePad)
+    const double *isot, *teff, *logg;
+    const double4 *isopack;  // kRbIsoPack: {x_i, x_i+1, y_i, slope_i}
     const unsigned int *pmask;
-    int niso, nt, ng;
+    const double *av_edges;  // (the prior's A_V(distance) table rides along: its search runs beside the recipe's)
+    int niso, nt, ng, nav;
 };
-// lane_bracket for the interval [nodes[l], nodes[l + 1]) that holds v (nodes[n] = +inf), l by binary search; below the
-// first node the wrap of recipe_part1_regs.  (v is finite: non-finite coordinates are rejected before, and a logg is
-// only used when its Teff lies inside the isochrone.)
-__device__ __forceinline__ int scalar_bracket(const double *nodes, int n, double v, int *i1, int *i2, double *e1, double *e2) {
-    if (!(v >= nodes[0])) {
-        *i1 = 0; *i2 = n - 1; *e1 = nodes[0]; *e2 = nodes[n - 1];
-        return MSX_W_OK;
-    }
-    int lo = 0, hi = n;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (nodes[mid] <= v) lo = mid; else hi = mid;
-    }
-    const double nl = nodes[lo], nn = lo + 1 < n ? nodes[lo + 1] : INFINITY;
+constexpr int kPlanIsoPad = 256, kPlanNodePad = 64;
+// One level of a 4-ary search for c = #{i : xs[i] <= v} in a sorted table padded with +inf: three probes, read together.
+// After the levels with step = N / 4, N / 16, ..., 1 the base is c for every c < N - 1 (xs[N - 1] is never probed: callers
+// whose table may be full, or whose v may reach the last entry, settle that case themselves).
+__device__ __forceinline__ void probe3(const double *xs, int base, int step, double (&p)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = xs[base + (k + 1) * step - 1];
+}
+__device__ __forceinline__ int advance3(int base, int step, const double (&p)[3], double v) {
+    return base + step * ((p[0] <= v ? 1 : 0) + (p[1] <= v ? 1 : 0) + (p[2] <= v ? 1 : 0));
+}
+// lane_bracket for the interval [nodes[l], nodes[l + 1]) that holds v, given c = #{nodes <= v} (nodes padded with +inf:
+// nodes[n] = +inf); below the first node the wrap of recipe_part1_regs.  (v is finite: non-finite coordinates are rejected
+// before, and a logg is only used when its Teff lies inside the isochrone.)
+__device__ __forceinline__ int bracket_from_count(const double *nodes, int n, int c, double first, double last, double v, int *i1, int *i2,
+                                                  double *e1, double *e2) {
+    const int lo = c > 0 ? c - 1 : 0;
+    const double nl = nodes[lo], nn = nodes[lo + 1];  // (lo + 1 <= n <= kPlanNodePad - 1 ... or the pad: +inf)
     const bool up = fabs(nn - v) < fabs(nl - v);
     const bool eq = nl == v;
-    *i1 = up ? lo + 1 : lo;
-    *i2 = (up || eq) ? lo : lo + 1;
-    *e1 = up ? nn : nl;
-    *e2 = (up || eq) ? nl : nn;
-    return (!up && !eq && lo + 1 >= n) ? MSX_W_INDEXERROR : MSX_W_OK;
+    const bool below = c == 0;  // !(v >= nodes[0])
+    *i1 = below ? 0 : (up ? lo + 1 : lo);
+    *i2 = below ? n - 1 : ((up || eq) ? lo : lo + 1);
+    *e1 = below ? first : (up ? nn : nl);
+    *e2 = below ? last : ((up || eq) ? nl : nn);
+    return (!below && !up && !eq && lo + 1 >= n) ? MSX_W_INDEXERROR : MSX_W_OK;
 }
 // One binary's recipe: node[8] (canonical order per star), w[8], redc; returns the walker's status (MSX_W_*), combined
-// over the two stars like logprob_kernel does.
+// over the two stars like logprob_kernel does.  A thread alone with its walker waits out every LDS round trip, so the
+// searches are arranged for few of them: 4-ary instead of binary, and the five that depend on theta alone -- two stars x
+// {Teff bracket, isochrone interval}, and the prior's A_V bin -- walk their levels TOGETHER (fifteen probes in flight per
+// level, four levels); the isochrone's interval comes back as one packed entry (the slope was divided at staging, like the
+// wave form's), and the two logg brackets walk together again.  Ten dependent round trips where the binary searches one
+// after the other took forty-six: planner 14.6 -> see DESIGN 5.1.  Indices, hence bits, are those of the searches they
+// replace (a sorted table has one last entry <= v).
+// iso_lo[s] (out): the isochrone interval of star s (the radius prior's luminosity lookup is the same search);
+// av_bin (out): #{av_edges <= 1 / plx} - 1, unclamped.
 __device__ __forceinline__ int recipe_scalar2(const GateArgs &G, const ScalarTabs &T, int mode, const double (&t)[6],
-                                              int (&node)[8], double (&w)[8], double *redc) {
+                                              int (&node)[8], double (&w)[8], double *redc, int (&iso_lo)[2], int *av_bin) {
     constexpr int NS = 2;
     bool alive = true;
 #pragma unroll
     for (int k = 0; k < 6; ++k) alive = alive && isfinite(t[k]);
     if (alive && (mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) alive = prior_gates<NS>(G, t);
+    const double plx = t[2 * NS + 1];
+    const double dist = 1.0 / plx;  // pc, mft6.py:1233 (the prior's; the recipe's own is fast_div below, as before)
+    const double t_first = T.teff[0], t_last = T.teff[T.nt - 1], g_first = T.logg[0], g_last = T.logg[T.ng - 1];
+    const double iso_first = T.isot[0], iso_last = T.isot[T.niso - 1];
+    // ---- the searches that need theta alone, level by level ----
+    int ct[NS] = {0, 0}, ci[NS] = {0, 0}, ca = 0;
+#pragma unroll
+    for (int lev = 0; lev < 4; ++lev) {
+        const int step = 64 >> (2 * lev);  // 64, 16, 4, 1 (tables of 256); the Teff table (64) joins at the second level
+        double pi[NS][3], pt[NS][3], pa[3];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            probe3(T.isot, ci[s], step, pi[s]);
+            if (lev > 0) probe3(T.teff, ct[s], step, pt[s]);
+        }
+        probe3(T.av_edges, ca, step, pa);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ci[s] = advance3(ci[s], step, pi[s], t[s]);
+            if (lev > 0) ct[s] = advance3(ct[s], step, pt[s], t[s]);
+        }
+        ca = advance3(ca, step, pa, dist);
+    }
+    *av_bin = ca - 1;  // (nav + 1 <= 128 edges in a table of 256: never near the unprobed last entry)
+    // ---- what the intervals hold: one round trip ----
+    int lo[NS];
+    double4 ent[NS];
+    bool in_iso[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        in_iso[s] = (t[s] >= iso_first) && (t[s] <= iso_last);
+        lo[s] = (t[s] >= iso_last) ? T.niso - 1 : (ci[s] > 0 ? ci[s] - 1 : 0);  // the last i with isot[i] <= ts
+        ent[s] = T.isopack[lo[s]];
+        iso_lo[s] = lo[s];
+        if (t[s] >= t_last) ct[s] = T.nt;  // (a full table's last entry is never probed)
+    }
+    int i1[NS], i2[NS], st_t[NS];
+    double te1[NS], te2[NS], lg[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        st_t[s] = bracket_from_count(T.teff, T.nt, ct[s], t_first, t_last, t[s], &i1[s], &i2[s], &te1[s], &te2[s]);
+        lg[s] = in_iso[s] ? fma(ent[s].w, t[s] - ent[s].x, ent[s].z) : T.isopack[0].z;  // mft6.py:1149
+    }
+    // ---- the two logg brackets, together ----
+    int cg[NS] = {0, 0};
+#pragma unroll
+    for (int lev = 0; lev < 3; ++lev) {
+        const int step = 16 >> (2 * lev);  // 16, 4, 1 (table of 64)
+        double pg[NS][3];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) probe3(T.logg, cg[s], step, pg[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) cg[s] = advance3(cg[s], step, pg[s], lg[s]);
+    }
     int stat[NS];
 #pragma unroll
     for (int star = 0; star < NS; ++star) {
         const double ts = t[star];
         const double rs = star == 0 ? t[NS + 1] : t[NS + 1] * t[NS + 1 + star];
-        const double plx = t[2 * NS + 1];
         const double q = fast_div(rs * kRsunCm, fast_div(1.0, plx) * kPcCm);  // mft6.py:690-691,700
         const double sc = q * q;
-        int i1, i2, g1, g2;
-        double te1, te2, ge1, ge2;
-        const int st_t = scalar_bracket(T.teff, T.nt, ts, &i1, &i2, &te1, &te2);
-        const double bw = (i1 == i2) ? 0.0 : fast_div(ts - te1, te2 - te1);
-        int st = MSX_W_OK;
-        const bool in_iso = (ts >= T.isot[0]) && (ts <= T.isot[T.niso - 1]);
-        if (!in_iso) st = MSX_W_VALUEERROR;
-        double lg = T.isog[0];
-        if (in_iso) {
-            int lo = 0, hi = T.niso;  // the last i with isot[i] <= ts
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (T.isot[mid] <= ts) lo = mid; else hi = mid;
-            }
-            const double slope = lo + 1 < T.niso ? (T.isog[lo + 1] - T.isog[lo]) / (T.isot[lo + 1] - T.isot[lo]) : 0.0;
-            lg = fma(slope, ts - T.isot[lo], T.isog[lo]);  // mft6.py:1149
-        }
-        const int st_g = scalar_bracket(T.logg, T.ng, lg, &g1, &g2, &ge1, &ge2);
-        const double a = (g1 == g2) ? 0.0 : fast_div(lg - ge1, ge2 - ge1);
-        if (st == MSX_W_OK) st = st_t;
+        const double bw = (i1[star] == i2[star]) ? 0.0 : fast_div(ts - te1[star], te2[star] - te1[star]);
+        int st = in_iso[star] ? MSX_W_OK : MSX_W_VALUEERROR;
+        int g1, g2;
+        double ge1, ge2;
+        if (lg[star] >= g_last) cg[star] = T.ng;
+        const int st_g = bracket_from_count(T.logg, T.ng, cg[star], g_first, g_last, lg[star], &g1, &g2, &ge1, &ge2);
+        const double a = (g1 == g2) ? 0.0 : fast_div(lg[star] - ge1, ge2 - ge1);
+        if (st == MSX_W_OK) st = st_t[star];
         if (st == MSX_W_OK) st = st_g;
-        const unsigned int mA = T.pmask[i1], mB = T.pmask[i2];
+        const unsigned int mA = T.pmask[i1[star]], mB = T.pmask[i2[star]];
         const bool have = (((mA >> g1) & (mA >> g2) & (mB >> g1) & (mB >> g2)) & 1u) != 0u;
         if (st == MSX_W_OK && !have) st = MSX_W_KEYERROR;
-        int nd[4] = {i1 * T.ng + g1, i1 * T.ng + g2, i2 * T.ng + g1, i2 * T.ng + g2};
+        int nd[4] = {i1[star] * T.ng + g1, i1[star] * T.ng + g2, i2[star] * T.ng + g1, i2[star] * T.ng + g2};
         double ww[4] = {(1.0 - bw) * (1.0 - a) * sc, (1.0 - bw) * a * sc, bw * (1.0 - a) * sc, bw * a * sc};
         sort4_by_node(nd, ww);
 #pragma unroll
@@ -835,56 +895,145 @@ __device__ __forceinline__ void recipe_band_finish(const DevProblem &P, int mode
 
 // ---- the one-thread forms (pair_kernel.h's planner) ---------------------------------------------------------------------
 struct ScalarPriorTabs {
-    const double *isot, *isol;               // isochrone Teff, luminosity (LDS)
-    const double *av_edges, *av_mu, *av_sig;  // the A_V(distance) table (LDS)
+    const double *isot, *isol;     // isochrone Teff, luminosity (LDS)
+    const double *av_mu, *av_sig;  // the A_V(distance) table (LDS)
 };
-// the Gaussian prior terms (f1) of a binary in LOGPOST mode: recipe_prior_terms by one thread
-__device__ __forceinline__ double prior_terms_scalar2(const DevProblem &P, const ScalarPriorTabs &T, int mode, const double (&t)[6]) {
+// the Gaussian prior terms (f1) of a binary in LOGPOST mode: recipe_prior_terms by one thread.  The two table searches
+// are recipe_scalar2's (av_bin = #{edges <= 1 / plx} - 1; iso_lo[s] = the isochrone interval of star s).
+__device__ __forceinline__ double prior_terms_scalar2(const DevProblem &P, const ScalarPriorTabs &T, int mode, const double (&t)[6],
+                                                      int av_bin, const int (&iso_lo)[2]) {
     constexpr int NS = 2;
-    const double a_v = t[NS], plx = t[2 * NS + 1];
+    const double a_v = t[NS];
     const double *rad = &t[NS + 1];
     double lp = 0.0;
     if (!(mode == MSX_MODE_LOGPOST || mode == MSX_MODE_LOGPRIOR)) return lp;
     if (P.use_av && P.nav > 0) {
-        const double d = 1.0 / plx;  // pc, mft6.py:1233
-        int lo = -1, hi = P.nav + 1;  // b = #{edges <= d} - 1
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.av_edges[mid] <= d) lo = mid; else hi = mid; }
-        int b = lo;
+        int b = av_bin;  // b = #{edges <= d} - 1, d = 1 / plx pc (mft6.py:1233)
         b = b < 0 ? 0 : (b > P.nav - 1 ? P.nav - 1 : b);
         double sig = T.av_sig[b];
         if (sig == 0.0) sig = 0.05;  // mft6.py:1237-1238
         lp = gauss_term(lp, a_v, T.av_mu[b], sig);
     }
     if (P.has_prior) {
-#pragma clang loop unroll(full)
-        for (int k = 0; k < 2 * NS + 2; ++k) {
-            if (P.pmean[k] != 0.0) lp = gauss_term(lp, t[k], P.pmean[k], P.psig[k]);  // mft6.py:1258
-        }
+        // (the six quotients first, side by side -- a thread alone with its walker has nothing else to fill a division's
+        // latency with -- then the sum in the reference's order; an unused term's quotient is computed and dropped)
+        double pm[2 * NS + 2], z[2 * NS + 2];
+#pragma unroll
+        for (int k = 0; k < 2 * NS + 2; ++k) { pm[k] = P.pmean[k]; z[k] = (t[k] - pm[k]) / P.psig[k]; }
+#pragma unroll
+        for (int k = 0; k < 2 * NS + 2; ++k) lp = (pm[k] != 0.0) ? gauss_term_z(lp, z[k]) : lp;  // mft6.py:1258
     }
     if (P.rad_prior) {  // mft6.py:1262-1269 (a Teff outside the isochrone has failed the walker already)
         double mr[NS];
+        const double iso_first = T.isot[0], iso_last = T.isot[P.niso - 1], lum_last = T.isol[P.niso - 1];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (!(t[s] >= T.isot[0]) || !(t[s] <= T.isot[P.niso - 1])) { mr[s] = 1.0; continue; }
-            int lo = -1, hi = P.niso;  // j = #{isot <= x} - 1
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.isot[mid] <= t[s]) lo = mid; else hi = mid; }
-            const int j = lo;
-            const double lum = j >= P.niso - 1 ? T.isol[P.niso - 1] : interp_segment(T.isot[j], T.isol[j], T.isot[j + 1], T.isol[j + 1], t[s]);
-            mr[s] = model_radius(lum, t[s]);
+            const bool inside = (t[s] >= iso_first) && (t[s] <= iso_last);
+            const int j = iso_lo[s];  // #{isot <= x} - 1
+            const int j1 = j + 1 < P.niso ? j + 1 : P.niso - 1;
+            const double seg = interp_segment(T.isot[j], T.isol[j], T.isot[j1], T.isol[j1], t[s]);
+            const double lum = j >= P.niso - 1 ? lum_last : seg;
+            mr[s] = inside ? model_radius(lum, t[s]) : 1.0;
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) lp = radius_term(lp, rad[s], (s == 0) ? mr[0] : mr[s] / mr[0]);
     }
     return lp;
 }
-// icontrast + iphot of a binary: recipe_band_terms by one thread
+// a value the optimiser must take as given: a magnitude is ROUNDED before anything is added to it, as in the wave form,
+// where it crosses lanes (without this the product inside it may be contracted into the caller's sum)
+__device__ __forceinline__ double rounded_here(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// icontrast + iphot of a binary: recipe_band_terms by one thread -- band_job_value's sums and band_chi's terms in their
+// order, but the band table's rows are requested up to FOUR BANDS x EIGHT NODES at a time, two bands to a 16-byte load
+// when the rows are even (one round trip of eight loads for the two contrast filters of BASELINE's configs, where job
+// after job took a round trip each)
 __device__ __forceinline__ double band_terms_scalar2(const DevProblem &P, int mode, const double (&t)[6], const int (&node)[8],
                                                      const double (&w)[8]) {
     constexpr int NS = 2;
     const double a_v = t[NS];
     const bool redden = redden_rule(mode, P.use_av, a_v);
-    // (band_chi asks for every job's magnitude exactly once: computed on demand, no array)
-    return band_chi<NS>(P, redden, a_v, [&](int k) __attribute__((always_inline)) { return band_job_value<NS>(P, node, w, k); });
+    const int nc = P.nc, nb = P.nc + P.np;
+    double chi = 0.0;
+    const double *row[NS * 4];
+#pragma unroll
+    for (int c = 0; c < NS * 4; ++c) row[c] = P.band_tab + (int64_t)node[c] * nb;
+    auto one_band = [&](int b, const double (&v)[NS * 4]) __attribute__((always_inline)) {
+        if (b < nc) {  // contrast filter b: the stars' instrumental magnitudes (A5)
+            double mag[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                double m = 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m += w[4 * s + c] * v[4 * s + c];
+                mag[s] = rounded_here(-2.5 * log10(m));  // mft6.py:733
+            }
+            const double con = mag[1] - mag[0];  // mft6.py:741
+            const double z = con - P.cmag[b];
+            chi = fma(z * z, P.civar[b], chi);  // mft6.py:120,1182
+        } else {  // photometric band b - nc (A6)
+            const int f = b - nc;
+            double flux = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) flux += w[c] * v[c];
+            const double mag = rounded_here(-2.5 * log10(flux / P.pzero[f]));  // mft6.py:780-782
+            const double mred = redden ? fma(a_v, P.pk[f], mag) : mag;  // mft6.py:1163
+            const double z = mred - P.pmag[f];
+            chi = fma(z * z, P.pivar[f], chi);  // mft6.py:1188
+        }
+    };
+    auto bands = [&](auto even_c) __attribute__((always_inline)) {
+        constexpr bool EVEN = decltype(even_c)::value;
+        for (int b0 = 0; b0 < nb; b0 += 4) {  // (uniform)
+            const bool more = b0 + 2 < nb;  // (uniform)
+            double2 va[NS * 4], vb[NS * 4];
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) {
+                if constexpr (EVEN) {
+                    va[c] = *reinterpret_cast<const double2 *>(row[c] + b0);
+                } else {
+                    va[c] = make_double2(row[c][b0], row[c][b0 + 1 < nb ? b0 + 1 : nb - 1]);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < NS * 4; ++c) {
+                    if constexpr (EVEN) {
+                        vb[c] = *reinterpret_cast<const double2 *>(row[c] + b0 + 2);
+                    } else {
+                        vb[c] = make_double2(row[c][b0 + 2], row[c][b0 + 3 < nb ? b0 + 3 : nb - 1]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NS * 4; ++c) vb[c] = make_double2(1.0, 1.0);
+            }
+            double v[NS * 4];
+#pragma unroll
+            for (int c = 0; c < NS * 4; ++c) v[c] = va[c].x;
+            one_band(b0, v);
+            if (b0 + 1 < nb) {
+#pragma unroll
+                for (int c = 0; c < NS * 4; ++c) v[c] = va[c].y;
+                one_band(b0 + 1, v);
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < NS * 4; ++c) v[c] = vb[c].x;
+                one_band(b0 + 2, v);
+                if (b0 + 3 < nb) {
+#pragma unroll
+                    for (int c = 0; c < NS * 4; ++c) v[c] = vb[c].y;
+                    one_band(b0 + 3, v);
+                }
+            }
+        }
+    };
+    // (rows of an even number of bands are 16-byte aligned: the table is, and a row is nb doubles)
+    if ((nb & 1) == 0) bands(std::true_type{}); else bands(std::false_type{});
+    return chi;
 }
 
 }  // namespace

@@ -225,7 +225,7 @@ def test_pair_median_exits(shape):
 
 
 def test_auto_choice_never_changes_values():
-    """MSX_PATH_AUTO takes the pair form from 9 walkers per CU on (spectra of <= 3,072 px: 16) while the planner's last count says pairing pays, the
+    """MSX_PATH_AUTO takes the pair form from 8 walkers per CU on (spectra of <= 3,072 px: 16) while the planner's last count says pairing pays, the
     fused kernel while it says the ensemble is spread over the grid, and looks again every 32nd launch: whatever it takes,
     in whatever order the two kinds of batches arrive, the values are the fused kernel's."""
     import bench
