@@ -574,10 +574,12 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     MSX_STAMP(P, blockIdx.x, 1);
     unsigned long long tag = 0ull;  // 0: nothing left to evaluate (rejected by the prior box, or an error status)
     PairRec mrec;
+    int node[NS * 4], iso_lo[NS] = {0, 0}, av_bin = 0;
+    double w[NS * 4];
+    BandRows band_pre;
     if (mine) {
         const ScalarTabs T = {s_isot, s_teff, s_logg, s_isopack, s_pmask, s_ave, niso, nt, ng, P.nav};
-        int node[NS * 4], iso_lo[NS], av_bin;
-        double w[NS * 4], redc;
+        double redc;
         const int st = recipe_scalar2(gates, T, mode, t, node, w, &redc, iso_lo, &av_bin);
         MSX_STAMP(P, blockIdx.x, 2);
         if (st != MSX_W_OK) {  // final here, like the fused kernel's first lines
@@ -590,14 +592,9 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
             R->redc = redc;
             R->walker = (int32_t)i;
             R->pad = 0;
-            // what only the walker's last line reads: the Gaussian prior terms (f1) and the contrast / photometry
-            // chi^2 (A5/A6) -- here and not by two waves of the pair kernel, whose workgroup would wait for their table
-            // round trips after its median is long done
-            const ScalarPriorTabs TP = {s_isot, s_isol, s_avm, s_avs};
-            R->lp = prior_terms_scalar2(P, TP, mode, t, av_bin, iso_lo);
-            MSX_STAMP(P, blockIdx.x, 3);
-            R->chi_extra = band_terms_scalar2(P, mode, t, node, w);
-            MSX_STAMP(P, blockIdx.x, 4);
+            // (what only the walker's last line reads -- the prior terms, the contrast / photometry chi^2 -- is worked out
+            // further down, while the workgroup's global adds are in flight; the band table's rows are requested here)
+            band_rows_first(P, node, band_pre);
             unsigned long long h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
             for (int c = 0; c < NS * 4; ++c) {
@@ -632,7 +629,7 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         (void)bases;
     }
     __syncthreads();
-    MSX_STAMP(P, blockIdx.x, 5);
+    MSX_STAMP(P, blockIdx.x, 3);
     // ---- 2. the waves' leftovers meet inside the workgroup: the same ballots over the card list, 64 cards per wave, in
     //      rounds (128 cards -> at most one per cell and wave -> one wave -> at most one per cell) -------------------------
     int nc = s_nc;
@@ -669,14 +666,27 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     for (int k = tid; k < nc; k += kPlanThreads) s_left[nsingle + k] = src[k];
     if (tid == 0) s_nl = nc;
     __syncthreads();
-    MSX_STAMP(P, blockIdx.x, 6);
+    MSX_STAMP(P, blockIdx.x, 4);
     // ---- the workgroup's lists to global memory: one atomic add per list.  What the workgroup could not place -- at
     //      most one walker per cell -- is a single. --------------------------------------------------------------------
     const int np = s_np, nl = s_nl;
-    if (tid == 0) s_basep = np ? atomicAdd(&plan[2], np) : 0;
-    if (tid == 1) s_basel = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;
+    int gbase = 0;  // (the add's result is not looked at before the terms below are done: its round trip is theirs)
+    if (tid == 0) gbase = np ? atomicAdd(&plan[2], np) : 0;
+    if (tid == 1) gbase = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;
+    MSX_STAMP(P, blockIdx.x, 5);
+    // what only the walker's last line reads: the Gaussian prior terms (f1) and the contrast / photometry chi^2 (A5/A6) --
+    // here and not by two waves of the pair kernel, whose workgroup would wait for their table round trips after its
+    // median is long done
+    if (tag != 0ull) {
+        const ScalarPriorTabs TP = {s_isot, s_isol, s_avm, s_avs};
+        mrec.lp = prior_terms_scalar2(P, TP, mode, t, av_bin, iso_lo);
+        MSX_STAMP(P, blockIdx.x, 6);
+        mrec.chi_extra = band_terms_scalar2(P, mode, t, node, w, band_pre);
+        MSX_STAMP(P, blockIdx.x, 7);
+    }
+    if (tid == 0) s_basep = gbase;
+    if (tid == 1) s_basel = gbase;
     __syncthreads();
-    MSX_STAMP(P, blockIdx.x, 7);
     // every walker's recipe goes where its workgroup will look for it
     const int base = blockIdx.x * kPlanThreads;
     for (int k = tid; k < np; k += kPlanThreads) {

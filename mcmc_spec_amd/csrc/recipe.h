@@ -950,8 +950,22 @@ __device__ __forceinline__ double rounded_here(double x) {
 // order, but the band table's rows are requested up to FOUR BANDS x EIGHT NODES at a time, two bands to a 16-byte load
 // when the rows are even (one round trip of eight loads for the two contrast filters of BASELINE's configs, where job
 // after job took a round trip each)
+// (pre: the rows' first four bands, requested by band_rows_first long before -- the planner walks its pairing in between)
+struct BandRows { double2 a[8], b[8]; };
+__device__ __forceinline__ void band_rows_first(const DevProblem &P, const int (&node)[8], BandRows &pre) {
+    const int nb = P.nc + P.np;
+    const bool even = (nb & 1) == 0, more = 2 < nb;  // (uniform)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double *row = P.band_tab + (int64_t)node[c] * nb;
+        if (nb <= 0) { pre.a[c] = pre.b[c] = make_double2(1.0, 1.0); continue; }
+        pre.a[c] = even ? *reinterpret_cast<const double2 *>(row) : make_double2(row[0], row[1 < nb ? 1 : nb - 1]);
+        pre.b[c] = !more ? make_double2(1.0, 1.0)
+                         : (even ? *reinterpret_cast<const double2 *>(row + 2) : make_double2(row[2], row[3 < nb ? 3 : nb - 1]));
+    }
+}
 __device__ __forceinline__ double band_terms_scalar2(const DevProblem &P, int mode, const double (&t)[6], const int (&node)[8],
-                                                     const double (&w)[8]) {
+                                                     const double (&w)[8], const BandRows &pre) {
     constexpr int NS = 2;
     const double a_v = t[NS];
     const bool redden = redden_rule(mode, P.use_av, a_v);
@@ -989,26 +1003,31 @@ __device__ __forceinline__ double band_terms_scalar2(const DevProblem &P, int mo
         for (int b0 = 0; b0 < nb; b0 += 4) {  // (uniform)
             const bool more = b0 + 2 < nb;  // (uniform)
             double2 va[NS * 4], vb[NS * 4];
+            if (b0 == 0) {  // (uniform) the first group is in registers already
 #pragma unroll
-            for (int c = 0; c < NS * 4; ++c) {
-                if constexpr (EVEN) {
-                    va[c] = *reinterpret_cast<const double2 *>(row[c] + b0);
-                } else {
-                    va[c] = make_double2(row[c][b0], row[c][b0 + 1 < nb ? b0 + 1 : nb - 1]);
-                }
-            }
-            if (more) {
+                for (int c = 0; c < NS * 4; ++c) { va[c] = pre.a[c]; vb[c] = pre.b[c]; }
+            } else {
 #pragma unroll
                 for (int c = 0; c < NS * 4; ++c) {
                     if constexpr (EVEN) {
-                        vb[c] = *reinterpret_cast<const double2 *>(row[c] + b0 + 2);
+                        va[c] = *reinterpret_cast<const double2 *>(row[c] + b0);
                     } else {
-                        vb[c] = make_double2(row[c][b0 + 2], row[c][b0 + 3 < nb ? b0 + 3 : nb - 1]);
+                        va[c] = make_double2(row[c][b0], row[c][b0 + 1 < nb ? b0 + 1 : nb - 1]);
                     }
                 }
-            } else {
+                if (more) {
 #pragma unroll
-                for (int c = 0; c < NS * 4; ++c) vb[c] = make_double2(1.0, 1.0);
+                    for (int c = 0; c < NS * 4; ++c) {
+                        if constexpr (EVEN) {
+                            vb[c] = *reinterpret_cast<const double2 *>(row[c] + b0 + 2);
+                        } else {
+                            vb[c] = make_double2(row[c][b0 + 2], row[c][b0 + 3 < nb ? b0 + 3 : nb - 1]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NS * 4; ++c) vb[c] = make_double2(1.0, 1.0);
+                }
             }
             double v[NS * 4];
 #pragma unroll

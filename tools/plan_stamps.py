@@ -41,8 +41,8 @@ def main():
     fn.restype = C.c_int
     assert fn(eng.ctx.h, nb, out.ctypes.data) == 0
     o = out.astype(np.int64)
-    names = ['tables + theta (barrier)', 'recipe_scalar2', 'prior terms', 'band terms', 'pairs in the wave + barrier', 'card rounds',
-             'global adds + barrier', 'where + records stored', 'ticket']
+    names = ['tables + theta (barrier)', 'recipe_scalar2 (+ band rows requested)', 'pairs in the wave + barrier', 'card rounds',
+             'global adds issued', 'prior terms', 'band terms', 'adds back + barrier + where + records stored', 'ticket']
     print('planner, {} walkers, {} workgroups; stamps are shader cycles (2.3-2.4 GHz)'.format(n, nb))
     print('  entry -> end: median {} max {}'.format(int(np.median(o[:, 9] - o[:, 0])), int((o[:, 9] - o[:, 0]).max())))
     pass
