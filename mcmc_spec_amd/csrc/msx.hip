@@ -1080,11 +1080,12 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         // From where the pair form pays (the planner costs 11.5 us whatever the batch; 14.6 before its searches went 4-ary
         // and side by side, round 4): measured on 256 CUs in one process, fused (FULL variants) against pair -- 4096 px:
         // 1,536 walkers 52.6 / 52.3 us, 2,048: 64.1 / 59.4, 2,304: 66.9 / 62.4, 4,096: 109.8 / 90.5, 16,384: 402.9 / 287.9.
-        // 1194 and 2048 px (round 3, planner 3 us slower): 2,304 walkers 45.5 / 49.3 and 48.8 / 52.1, 4,096: 72.7 / 68.0
-        // and 76.8 / 71.6.  In walkers per CU: 8 for the long spectra, 16 for the short ones.
+        // (profiles/r4_crossover_4096px.jsonl with the 10.5 us planner: 1,536 walkers 49.8 / 49.6, 2,048: 60.5 / 57.1, 3,072:
+        // 85.4 / 73.8.)  1194 px (r4_crossover_1194px.jsonl): 2,304 walkers 45.9 / 46.3, 3,072: 55.9 / 53.4, 4,096: 72.2 / 64.2,
+        // 6,144: 104.6 / 85.8.  In walkers per CU: 8 for the long spectra, 12 for the short ones.
         {
             const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-            c->pair_min_walkers = (p->npix > 3072 ? 8 : 16) * cus;
+            c->pair_min_walkers = (p->npix > 3072 ? 8 : 12) * cus;
         }
         if (const char *e = getenv("MSX_PAIR_MIN")) c->pair_min_walkers = atoll(e) > 0 ? std::max<int64_t>(2, atoll(e)) : INT64_MAX;
     }

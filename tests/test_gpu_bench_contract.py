@@ -81,7 +81,7 @@ def test_the_rooflines_kernel_name_comes_from_the_library():
     import torch
     from mcmc_spec_amd import synth
     dev = torch.device('cuda', 0)
-    for m in (128, 2048, 4096):
+    for m in (128, 1024, 2048, 4096):
         th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=3000.0, tmax=5500.0)).to(dev)
         lp, st = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
         would = eng.ctx.launch_info(m)
@@ -89,4 +89,4 @@ def test_the_rooflines_kernel_name_comes_from_the_library():
             eng.ctx.logprob_batch_dev(th.data_ptr(), m, 6, lp.data_ptr(), st.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         torch.cuda.synchronize()
         assert eng.ctx.last_form() == would['form_id'], (m, would)
-    assert eng.ctx.launch_info(4096)['form'].startswith('pair') and eng.ctx.launch_info(2048)['form'] == 'fused'
+    assert eng.ctx.launch_info(2048)['form'].startswith('pair') and eng.ctx.launch_info(1024)['form'] == 'fused'   # (8 walkers per CU)

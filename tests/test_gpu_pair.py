@@ -42,6 +42,33 @@ def test_pair_matches_reference_golden_and_fused_bits():
     assert same_bits(outs) and np.isinf(outs[0]).sum() == 8
 
 
+@pytest.mark.parametrize('nphot', [1, 3, 5])
+def test_pair_band_terms_with_odd_band_counts(nphot):
+    """The planner reads the band table two bands to a 16-byte load when a row holds an even number of bands and band by
+    band when it does not, four bands to a trip (recipe.h, band_terms_scalar2): 2 contrast filters + 1 / 3 / 5 photometric
+    bands = rows of 3 / 5 / 7 -- the odd path, one trip and two -- against the fused kernel (bits) and the oracle."""
+    import copy
+    from mcmc_spec_amd.engine import Engine
+    from mcmc_spec_amd import bands
+    c = copy.copy(golden_case('B'))
+    c.ptm = [x[:nphot] for x in c.ptm]
+    c.fr = [c.fr[0], c.fr[1], c.fr[2], c.fr[3][:nphot], c.fr[4][:nphot], c.fr[5][:nphot]]
+    c.tmi, c.tma = common.tm_extrema(c.ctm, c.ptm)
+    eng = Engine(0)
+    eng.stage_specs(c.specs)
+    eng.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=2,
+                      bands=bands.make_bands(c.tables, *c.vega), av_table=common.av_table_exact(), tmin=c.tmin, tmax=c.tmax,
+                      prior=c.prior)
+    th = np.repeat(c.theta, 2, axis=0)
+    for fn in (eng.loglikelihood, eng.logposterior):
+        outs = forms(eng, fn, th)
+        assert same_bits(outs) and np.isfinite(outs[0]).sum() >= len(c.theta)
+    want = np.array([common.orc.loglikelihood(list(t), c.fr, 2, c.data, c.err, c.r, c.specs, c.ctm, c.ptm, c.tmi, c.tma,
+                                              c.matrix, bandlib=c.bandlib) for t in c.theta[:4]])
+    eng.ctx.set_path(__import__('mcmc_spec_amd._lib', fromlist=['x']).PATH_PAIR)
+    assert rel_err(eng.loglikelihood(th)[:8:2], want).max() < TIGHT
+
+
 def test_pair_problem_staged_without_extinction():
     """`a=False` (mft6.py:1161): no walker is reddened; the pair kernel's only variant loads the extinction terms and
     must still return the unreddened values, bit for bit."""
@@ -225,7 +252,7 @@ def test_pair_median_exits(shape):
 
 
 def test_auto_choice_never_changes_values():
-    """MSX_PATH_AUTO takes the pair form from 8 walkers per CU on (spectra of <= 3,072 px: 16) while the planner's last count says pairing pays, the
+    """MSX_PATH_AUTO takes the pair form from 8 walkers per CU on (spectra of <= 3,072 px: 12) while the planner's last count says pairing pays, the
     fused kernel while it says the ensemble is spread over the grid, and looks again every 32nd launch: whatever it takes,
     in whatever order the two kinds of batches arrive, the values are the fused kernel's."""
     import bench

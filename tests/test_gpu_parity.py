@@ -922,7 +922,7 @@ def test_resampled_tables_stay_at_rounding_level_under_heavy_extinction():
     if not any(k in os.environ for k in ('MSX_NO_PF', 'MSX_PAIR_MIN', 'MSX_LINKED')):   # (the variants AUTO takes by default)
         assert eng.ctx.bytes_per_eval(1000) == 700 * (12 * 8 + 12 + 16 + 24) + 8 * 6 + 12
         assert eng.ctx.bytes_per_eval(64) == 700 * (12 * 8 + 12 + 16 + 8) + 8 * 6 + 12
-        # ... and from 4,096 walkers on two walkers of one grid cell share every load (+ the planner's 128-byte record)
+        # ... and from 3,072 walkers on (12 per CU) two walkers of one grid cell share every load (+ the planner's 128-byte record)
         assert eng.ctx.bytes_per_eval(100000) == 700 * (12 * 8 + 12 + 16 + 24) // 2 + 128 + 8 * 6 + 12
 
 
