@@ -175,22 +175,26 @@ def cpu_baseline(W, theta, gpu_logp, budget_s=20.0, procs=(0,)):
     return out
 
 
-def device_time_us(eng, theta_dev, lp, st, stream, n, iters):
-    """Mean device time of one launch over `n` walkers (HIP events on the launch stream around `iters` launches)."""
+def device_time_us(eng, theta_dev, lp, st, stream, n, iters, warm=3, reps=1):
+    """Mean device time of one launch over `n` walkers (HIP events on the launch stream around `iters` launches; the
+    median of `reps` such blocks behind `warm` untimed launches)."""
     import torch
     from mcmc_spec_amd import _lib
     def go():
         eng.ctx.logprob_batch_dev(theta_dev.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), stream.cuda_stream,
                                   _lib.MODE_LOGPOST, 0)
-    for _ in range(3):
+    for _ in range(warm):
         go()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        go()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    got = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            go()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        got.append(e0.elapsed_time(e1) / iters * 1e3)
+    return sorted(got)[len(got) // 2]
 
 
 def load_profile(name):
@@ -858,10 +862,15 @@ def main():
         if world == 1 and not replicas and not args.no_extras:
             # batch-size sweep on the staged problem (device time per launch, automatic variant choice)
             sweep = []
+            # (the CPU baseline above left the GPU idle for tens of seconds: the clocks are brought back up first -- ~50 ms
+            # of launches, untimed -- and every row is the median of three timed blocks behind ten untimed launches)
+            th_w = torch.from_numpy(synth.draw_walkers(1024, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
+            device_time_us(eng, th_w, torch.empty(1024, dtype=torch.float64, device=dev), torch.empty(1024, dtype=torch.int32, device=dev),
+                           stream, 1024, 1500)
             for m in (128, 256, 512, 1024, 2048, 4096, 16384):
                 th = torch.from_numpy(synth.draw_walkers(m, seed=3, tmin=W['tmin'], tmax=W['tmax'])).to(dev)
                 lp_, st_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.int32, device=dev)
-                us = device_time_us(eng, th, lp_, st_, stream, m, max(30, min(60, 400000 // m)))
+                us = device_time_us(eng, th, lp_, st_, stream, m, max(30, min(60, 400000 // m)), warm=10, reps=3)
                 # the form the launches TOOK (msx_last_form: MSX_PATH_AUTO looks at the planner's counts) and what that form
                 # requests per walker -- from the library, like the headline's
                 ran = eng.ctx.last_form()

@@ -670,9 +670,13 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     // ---- the workgroup's lists to global memory: one atomic add per list.  What the workgroup could not place -- at
     //      most one walker per cell -- is a single. --------------------------------------------------------------------
     const int np = s_np, nl = s_nl;
-    int gbase = 0;  // (the add's result is not looked at before the terms below are done: its round trip is theirs)
-    if (tid == 0) gbase = np ? atomicAdd(&plan[2], np) : 0;
-    if (tid == 1) gbase = (nsingle + nl) ? atomicAdd(&plan[3], nsingle + nl) : 0;
+    // (the adds' results are not looked at before the terms below are done: their round trip is the terms'.  ONE
+    // instruction for the two of them, its address a function of the lane: a uniform address would have the compiler's
+    // atomic optimizer rewrite the add with a readfirstlane -- and a wait -- right behind it)
+    int gbase = 0;
+    int tid_v = tid;  // (the thread index as a value the optimiser cannot see through: keeps the addresses per-lane)
+    asm volatile("" : "+v"(tid_v));
+    if (tid < 2) gbase = atomicAdd(&plan[2 + tid_v], tid == 0 ? np : nsingle + nl);
     MSX_STAMP(P, blockIdx.x, 5);
     // what only the walker's last line reads: the Gaussian prior terms (f1) and the contrast / photometry chi^2 (A5/A6) --
     // here and not by two waves of the pair kernel, whose workgroup would wait for their table round trips after its
@@ -686,6 +690,12 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     }
     if (tid == 0) s_basep = gbase;
     if (tid == 1) s_basel = gbase;
+    // The ticket of "the last workgroup publishes the counts" is taken HERE -- this workgroup's two adds have returned (both
+    // are lanes of this wave: their results are in hand) and that is all the ticket stands for; the records' stores below are
+    // the kernel boundary's to publish -- and looked at in the kernel's last lines, a round trip later.  (Address by lane, as
+    // above.)
+    int ticket = -1;
+    if (tid < 1) ticket = atomicAdd(&plan[4 + tid_v], 1);
     __syncthreads();
     // every walker's recipe goes where its workgroup will look for it
     const int base = blockIdx.x * kPlanThreads;
@@ -701,23 +711,19 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
         *dst = mrec;
     }
     MSX_STAMP(P, blockIdx.x, 8);
-    // ---- the last workgroup to finish publishes the counts and leaves the working counters at zero for the next launch
-    // (the ticket is taken after this workgroup's own adds have RETURNED -- their results placed the stores above)
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = atomicAdd(&plan[4], 1);
-        if (ticket == (int)gridDim.x - 1) {
-            const int np_all = atomicExch(&plan[2], 0), ns_all = atomicExch(&plan[3], 0);
-            plan[0] = np_all;
-            plan[1] = ns_all;
-            // ... and tells the host, which decides from it what the NEXT launches take (msx.hip, pair_worth_it): a word
-            // of host memory, written and forgotten
-            if (host_stats) {
-                __hip_atomic_store(host_stats, np_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(host_stats + 1, ns_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            atomicExch(&plan[4], 0);
+    // ---- the last workgroup to take its ticket publishes the counts and leaves the working counters at zero for the next
+    // launch (every other workgroup's adds had returned before its ticket was taken)
+    if (tid == 0 && ticket == (int)gridDim.x - 1) {
+        const int np_all = atomicExch(&plan[2], 0), ns_all = atomicExch(&plan[3], 0);
+        plan[0] = np_all;
+        plan[1] = ns_all;
+        // ... and tells the host, which decides from it what the NEXT launches take (msx.hip, pair_worth_it): a word
+        // of host memory, written and forgotten
+        if (host_stats) {
+            __hip_atomic_store(host_stats, np_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_stats + 1, ns_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        atomicExch(&plan[4], 0);
     }
     MSX_STAMP(P, blockIdx.x, 9);
 }
