@@ -569,7 +569,7 @@ int launch_pair(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
     hipLaunchKernelGGL((logprob_pair_kernel<T_, NT_, true, true>), g, dim3(T_), 0, A.s, A.theta, (const unsigned char *)c->d_recipe_block, \
                        A.niso_nt, A.ng_mode_fast, (int64_t)A.n, P.tmin, P.tmax, plan, P, A.logp, A.status)
     // (FULL: the spectrum fills the variant exactly -- no clamps, no validity selects; pair_kernel.h)
-    const bool full = P.npix == 2 * ne && (ne == 2 * 512 || ne == 4 * 512);
+    const bool full = c->use_full && P.npix == 2 * ne && (ne == 2 * 512 || ne == 4 * 512);
     // (512 threads, two workgroups per CU at <= 128 VGPRs: 16 waves per CU.  The 256-thread variants -- two per CU at
     // 256 VGPRs, 8 waves -- measured 411.8 us against 344.8 at 16,384 walkers and are not built.)
     if (ne <= 2 * 512) MSX_PAIR_GO(512, 2); else MSX_PAIR_GO(512, 4);
@@ -2097,7 +2097,7 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
     const Variant *v = nullptr;
     if (f.pair) {
         const bool nt2 = c->P.npair <= 2 * 512;
-        const bool full = c->P.npix == 2 * c->P.npair && (c->P.npair == 2 * 512 || c->P.npair == 4 * 512);
+        const bool full = c->use_full && c->P.npix == 2 * c->P.npair && (c->P.npair == 2 * 512 || c->P.npair == 4 * 512);
         fn = full ? (nt2 ? (const void *)logprob_pair_kernel<512, 2, true, true> : (const void *)logprob_pair_kernel<512, 4, true, true>)
                   : (nt2 ? (const void *)logprob_pair_kernel<512, 2, true> : (const void *)logprob_pair_kernel<512, 4, true>);
         nm = std::string("pair_plan_kernel + logprob_pair_kernel<512 threads, ") + (nt2 ? "2" : "4") +
