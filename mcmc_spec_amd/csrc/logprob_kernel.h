@@ -285,9 +285,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //       store_dtype), never the default; fused binaries only.
 // FULL = the spectrum is whole trips of the variant with no pad pixels (npix == 2 npair, npair a multiple of the trip:
 //        BASELINE's 4096 pixels): every lane of every trip holds live pixels, so the clamps of element and pixel indices,
-//        the per-pixel validity compares and their selects are compiled out of the blend, the chi^2 pass and the candidates'
-//        gather.  Same arithmetic on the same pixels: same bits (the launcher picks it; msx.hip, choose_variant).
-template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false, bool FULL = false>
+//        the per-pixel validity compares and their selects can be compiled out -- bit 0: of the blend, bit 1: of the chi^2
+//        pass and the candidates' gather.  Same arithmetic on the same pixels: same bits (the launcher picks it; msx.hip,
+//        choose_variant).  Which bits pay was measured per workgroup size (same box, alternating runs): the 256-thread
+//        variants gain from both (2,048 walkers 63.3 -> 60.4 us), the 512-thread headline variant gains from the chi^2
+//        pass's (14.63 -> 14.36 us per step) and LOSES with the blend's (14.67 -> 14.96: the loads' order changed).
+template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false, int FULL = 0>
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
@@ -581,6 +584,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     // (512 threads: not the <= 128-VGPR variant, which has no room for a quad's rows; 256 threads: only the variant
     // that runs two per CU instead of three -- SH there -- and so has 256 VGPRs)
     constexpr bool kQuad = (MAXT == 512 && !SH) || (MAXT == 256 && SH);
+    constexpr bool FULLB = (FULL & 1) != 0, FULLC = (FULL & 2) != 0;  // whole trips: no clamps in the blend / in the chi^2 pass
     const double2 *rows_r[NC];  // R = lo + (hi - lo) t of each corner's grid node, two pixels per element
     const float2 *rows_rf[NC];  // ... the float32 copy (R32)
     const float4 *rows_r4f[NC]; // ... by quad
@@ -630,8 +634,8 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
                              auto sub_c) __attribute__((always_inline)) {
         constexpr int sub = decltype(sub_c)::value;
         const int pa = ((ec >> 8) << 9) | (ec & 255), pb = pa + 256;
-        const bool ok[U] = {FULL || (live && pa < npix), FULL || (live && pb < npix)};
-        const int pp[U] = {(FULL || pa < npix) ? pa : npix - 1, (FULL || pb < npix) ? pb : npix - 1};
+        const bool ok[U] = {FULLB || (live && pa < npix), FULLB || (live && pb < npix)};
+        const int pp[U] = {(FULLB || pa < npix) ? pa : npix - 1, (FULLB || pb < npix) ? pb : npix - 1};
         static_assert(!PF || kQuad, "PF: u and the data flux come from LDS (staged in phase 0; the quad trips read them there)");
         const double mm[U] = {m2.x, m2.y}, ff[U] = {f2.x, f2.y}, uu[U] = {u2.x, u2.y};
         unsigned int fxs[U] = {0u, 0u};
@@ -660,7 +664,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
       if constexpr (kQuad) {
       for (int e0 = seg * kSegElems; e0 < e_end; e0 += 2 * B) {  // (segments are whole numbers of quad trips)
         const int eA = e0 + tid, eB = eA + B;
-        const bool liveA = FULL || eA < e_end, liveB = FULL || eB < e_end;
+        const bool liveA = FULLB || eA < e_end, liveB = FULLB || eB < e_end;
         const int ecA = liveA ? eA : e_end - 1, ecB = liveB ? eB : e_end - 1;
         const unsigned int oA = (unsigned int)ecA << 4, oB = (unsigned int)ecB << 4;
         const unsigned int oq = (unsigned int)((e0 >> 1) + tid) << 4;  // quad (e0 / 1024) * 512 + tid, 16 bytes each
@@ -722,7 +726,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         auto one = [&](auto sub_c) __attribute__((always_inline)) {
         constexpr int sub = decltype(sub_c)::value;
         const int e = e0 + sub * B + tid;
-        const bool live = FULL || e < e_end;
+        const bool live = FULLB || e < e_end;
         const int ec = live ? e : e_end - 1;
         const unsigned int o16 = (unsigned int)ec << 4, o8 = (unsigned int)ec << 3;
         // data flux and u: requested with the rows by the 256-thread variant (one wait per trip instead of two:
@@ -1005,11 +1009,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
     bool rank_split = false;  // (<= 64 candidates: ranked by several waves, picked by wave 0 behind the closing barrier)
     LogbinSel rank_Q;
     if (early && !LK) {  // (linked: only vectors the early histogram could not handle come this far)
-        ChiElem<MAXT, PF, true, kAhead, false, FULL> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
+        ChiElem<MAXT, PF, true, kAhead, false, FULLC> chi_fast{PF ? lds_u2 : P.u2, PF ? lds_f2 : P.f2, P.iv2, ne, npix, pc0, pc1, pc2, {}, true,
                                          &red[0][0][0], {}, {}, {}, 0.0};
         // positive normal values spanning < 8 binades (anything else -- zeros, negatives, infinities, NaNs, huge ranges --
         // takes block_median below); > 256 equal-bin candidates come back unsolved too
-        if (frange_applicable(fmin_, fmax_)) solved = logbin_median<MAXT, FULL>(model, npix, fmin_, S, chi_fast, &med_model, &rank_split, &rank_Q);
+        if (frange_applicable(fmin_, fmax_)) solved = logbin_median<MAXT, FULLC>(model, npix, fmin_, S, chi_fast, &med_model, &rank_split, &rank_Q);
         // the ranking of <= 64 candidates, a few trips of eight per wave (the waves that have nothing else left to do);
         // wave 0 reads the sums behind the closing barrier
         constexpr int kRankWaves = MAXT / kWave > 4 ? 4 : 2, kRank0 = MAXT / kWave > 4 ? 3 : 2;

@@ -348,15 +348,17 @@ bool takes_pf(const msx_ctx *c, int64_t n) {
 struct Variant {
     const void *fn;
     int ns, threads;
-    bool gm, sh, pf, lk, r32, full;
+    bool gm, sh, pf, lk, r32;
+    int full;  // FULL bits of the variant (logprob_kernel.h): 1 blend, 2 chi^2 pass
     const char *what;
 };
 #define MSX_V(NS_, T_, GM_, SH_, PF_, LK_, WHAT_) \
-    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, false, false, WHAT_}
+    {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, false, 0, WHAT_}
 #define MSX_V32(T_, SH_, PF_, WHAT_) \
-    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, true>, 2, T_, false, SH_, PF_, false, true, false, WHAT_}
-#define MSX_VF(T_, SH_, PF_, WHAT_) \
-    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, false, true>, 2, T_, false, SH_, PF_, false, false, true, WHAT_}
+    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, true>, 2, T_, false, SH_, PF_, false, true, 0, WHAT_}
+#define MSX_VF(T_, SH_, PF_, F_, WHAT_) \
+    {(const void *)logprob_kernel<2, 2, T_, false, SH_, PF_, false, false, F_>, 2, T_, false, SH_, PF_, false, false, F_, WHAT_}
+constexpr int kFull256 = 3;  // (measured against 1 and 2 as well: profiles/r4_ab_full.txt)
 const Variant kVariants[] = {
     MSX_V(2, 256, false, false, false, false, "three workgroups per CU"),
     MSX_V(2, 256, false, true, false, false, "two per CU, four pixels per lane and trip"),
@@ -378,18 +380,20 @@ const Variant kVariants[] = {
     MSX_V32(512, false, false, "one workgroup per CU, four pixels per lane and trip; R table stored in float32"),
     MSX_V32(512, true, false, "<= 128 VGPRs: two workgroups fit a CU; rows one star at a time; R table stored in float32"),
     MSX_V32(512, false, true, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; R table stored in float32"),
-    // the 256-thread binary variants once more for spectra that fill their trips exactly (FULL: no clamps, no validity
-    // selects).  Same box, general / FULL, us per batch of 4096 px: 512 walkers 24.2 / 23.1, 1,024: 39.5 / 37.8,
-    // 2,048: 63.3 / 60.4, 2,304: 68.9 / 66.7.  The 512-thread variants were built the same way and were SLOWER
-    // (256 walkers 14.35 -> 14.55 us by HIP events: the clamps' removal moved the scheduler's load order), so they are not here.
-    MSX_VF(256, false, false, "three workgroups per CU; whole trips, no clamps"),
-    MSX_VF(256, true, false, "two per CU, four pixels per lane and trip; whole trips, no clamps"),
-    MSX_VF(256, true, true, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps"),
+    // the binary variants once more for spectra that fill their trips exactly (FULL: no clamps, no validity selects; bit 0
+    // in the blend, bit 1 in the chi^2 pass).  Same box, general / FULL, us per batch of 4096 px -- 256 threads, both bits:
+    // 512 walkers 24.2 / 23.1, 1,024: 39.5 / 37.8, 2,048: 63.3 / 60.4, 2,304: 68.9 / 66.7.  512 threads, one workgroup per
+    // CU (the 256-walker headline), per step: both bits 14.35 -> 14.55 (slower), the blend's alone 14.67 -> 14.96 (slower:
+    // without the clamps the scheduler orders the trip's loads differently), the chi^2 pass's alone 14.63 -> 14.36.
+    MSX_VF(256, false, false, kFull256, "three workgroups per CU; whole trips, no clamps"),
+    MSX_VF(256, true, false, kFull256, "two per CU, four pixels per lane and trip; whole trips, no clamps"),
+    MSX_VF(256, true, true, kFull256, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps"),
+    MSX_VF(512, false, true, 2, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps in the chi^2 pass"),
 };
 #undef MSX_V
 #undef MSX_V32
 #undef MSX_VF
-const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk, bool r32 = false, bool full = false) {
+const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk, bool r32 = false, int full = 0) {
     for (const Variant &v : kVariants)
         if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk && v.r32 == r32 && v.full == full) return &v;
     return nullptr;
@@ -433,10 +437,12 @@ VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, i
     const bool full = ns == 2 && B == 256 && c->use_full && P.npix == 2 * P.npair && P.npair % 512 == 0;
     if (full) {
         const bool q256 = c->q256 > 0 || (c->q256 < 0 && n <= 2 * (int64_t)c->prop.multiProcessorCount);
-        if (q256 && c->pf256_ok && c->use_pf) return {find_variant(2, 256, false, true, true, false, false, true), lds_pf};
-        if (q256) return {find_variant(2, 256, false, true, false, false, false, true), lds};
-        return {find_variant(2, 256, false, false, false, false, false, true), lds};
+        if (q256 && c->pf256_ok && c->use_pf) return {find_variant(2, 256, false, true, true, false, false, kFull256), lds_pf};
+        if (q256) return {find_variant(2, 256, false, true, false, false, false, kFull256), lds};
+        return {find_variant(2, 256, false, false, false, false, false, kFull256), lds};
     }
+    if (ns == 2 && B == 512 && pf && c->use_full && P.npix == 2 * P.npair && P.npair % 1024 == 0)
+        return {find_variant(2, 512, false, false, true, false, false, 2), lds_pf};
     if (ns == 2) {
         // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
         // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
@@ -2112,7 +2118,7 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
         threads = v->threads; dyn = (int64_t)ch.dyn_lds;
         grid = f.linked ? ((m + 7) & ~7ll) * c->nseg : m;
         nm = std::string("logprob_kernel<NS=") + std::to_string(v->ns) + ", " + std::to_string(v->threads) + " threads" +
-             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + (v->full ? ", FULL" : "") + "> (" + v->what + ")";
+             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + (v->full == 3 ? ", FULL" : v->full == 2 ? ", FULL(chi2 pass)" : "") + "> (" + v->what + ")";
     }
     hipFuncAttributes at;
     HIP_TRY(c, hipFuncGetAttributes(&at, fn));

@@ -72,7 +72,7 @@ def test_the_rooflines_kernel_name_comes_from_the_library():
     bench.build_workload(eng, 4096, False)
     info = eng.ctx.launch_info(256, _lib.MODE_LOGPOST, 0)
     r = j['roofline']
-    assert r['kernel'] == info['kernel'] and r['kernel'].startswith('logprob_kernel<NS=2, 512 threads, PF>')
+    assert r['kernel'] == info['kernel'] and r['kernel'].startswith("logprob_kernel<NS=2, 512 threads, PF")
     assert r['requested_bytes_per_eval'] == info['requested_bytes_per_eval'] == eng.ctx.bytes_per_eval(256)
     assert r['kernel_resources']['vgprs'] == info['vgprs'] and r['kernel_resources']['form'] == 'fused'
     assert j['storage'] == {k: j['storage'][k] for k in j['storage']} and j['storage']['R'] == 'f64' and j['storage']['H'] == 'f32' and j['storage']['dk'] == 'f32'
