@@ -207,7 +207,9 @@ struct ChiElem {
                 }
             }
         }
-        if (AHEAD) load_trip<AHEAD ? 1 - PAR : 0>(base + 4 * MAXT);
+        // (FULL has no clamp inside load_trip: the trip requested behind the LAST one would lie past the tables' end --
+        // it asks for the current trip again instead; uniform, two scalar instructions)
+        if (AHEAD) load_trip<AHEAD ? 1 - PAR : 0>((FULL && base + 4 * MAXT >= npix) ? base : base + 4 * MAXT);
         const double u[4] = {cu[0].x, cu[0].y, cu[1].x, cu[1].y}, f[4] = {cf[0].x, cf[0].y, cf[1].x, cf[1].y};
         const double e[4] = {nv[SET][0].x, nv[SET][0].y, nv[SET][1].x, nv[SET][1].y};
 #pragma unroll
