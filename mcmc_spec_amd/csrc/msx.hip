@@ -1083,12 +1083,12 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         c->h_pair_stats[0] = 1; c->h_pair_stats[1] = 0;  // (nothing known yet: try)
         c->pair_auto_launches = 0;
         c->pair_rows = rows;
-        // From where the pair form pays (the planner costs 11.5 us whatever the batch; 14.6 before its searches went 4-ary
-        // and side by side, round 4): measured on 256 CUs in one process, fused (FULL variants) against pair -- 4096 px:
-        // 1,536 walkers 52.6 / 52.3 us, 2,048: 64.1 / 59.4, 2,304: 66.9 / 62.4, 4,096: 109.8 / 90.5, 16,384: 402.9 / 287.9.
-        // (profiles/r4_crossover_4096px.jsonl with the 10.5 us planner: 1,536 walkers 49.8 / 49.6, 2,048: 60.5 / 57.1, 3,072:
-        // 85.4 / 73.8.)  1194 px (r4_crossover_1194px.jsonl): 2,304 walkers 45.9 / 46.3, 3,072: 55.9 / 53.4, 4,096: 72.2 / 64.2,
-        // 6,144: 104.6 / 85.8.  In walkers per CU: 8 for the long spectra, 12 for the short ones.
+        // From where the pair form pays (the planner costs 10.6 us whatever the batch; 14.6 before its searches went 4-ary
+        // and side by side, round 4): measured on 256 CUs in one process, fused (FULL variants) against pair, us per batch
+        // -- 4096 px (profiles/r4_crossover_4096px.jsonl): 1,024 walkers 40.0 / 42.3, 1,536: 50.1 / 49.3, 2,048: 61.1 / 56.8,
+        // 2,304: 66.4 / 61.4, 3,072: 86.0 / 73.4, 4,096: 111.0 / 89.4.  1194 px (r4_crossover_1194px.jsonl): 2,304 walkers
+        // 46.6 / 46.3, 3,072: 56.2 / 53.1, 4,096: 72.2 / 63.9, 6,144: 104.3 / 85.2.  In walkers per CU: 8 for the long
+        // spectra, 12 for the short ones.
         {
             const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
             c->pair_min_walkers = (p->npix > 3072 ? 8 : 12) * cus;

@@ -17,3 +17,12 @@ python tools/region_probe.py --tag default > $dst/${tag}_region_probe.jsonl 2>> 
 MSX_LIB=$root/build/libmsx_stamps.so python tools/stamps.py --walkers 256 > $dst/${tag}_fused_stamps.txt 2>&1
 MSX_LIB=$root/build/libmsx_stamps.so python tools/stamps.py --walkers 128 >> $dst/${tag}_fused_stamps.txt 2>&1
 ls -la $dst
+# the planner's phases (stamps build), the forms' crossovers in one process, the pair form's soak
+MSX_LIB=$root/build/libmsx_stamps.so python tools/plan_stamps.py --walkers 2048 > $dst/${tag}_plan_stamps.txt 2>&1
+MSX_LIB=$root/build/libmsx_stamps.so python tools/plan_stamps.py --walkers 16384 >> $dst/${tag}_plan_stamps.txt 2>&1
+python tools/sweep.py --blocks 0 --paths fused,pair --walkers 1024,1536,2048,2304,3072,4096 > $dst/${tag}_crossover_4096px.jsonl 2>> $dst/err.log
+python tools/sweep.py --npix 1194 --blocks 0 --paths fused,pair --walkers 2304,3072,4096,6144 > $dst/${tag}_crossover_1194px.jsonl 2>> $dst/err.log
+python tools/soak_pair.py --batches 300 > $dst/${tag}_soak_pair.txt 2>&1
+python tools/soak_pair.py --batches 150 --npix 1194 --seed 2 2>&1 | tail -1 >> $dst/${tag}_soak_pair.txt
+python tools/soak_pair.py --batches 100 --phot --seed 3 2>&1 | tail -1 >> $dst/${tag}_soak_pair.txt
+ls -la $dst
