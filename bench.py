@@ -36,7 +36,7 @@ L2_PEAK_GBPS = 34500.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False, grid=None, store='f64'):
+def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid=False, grid=None, store='f64', broaden='staging'):
     """Stage the synthetic 26x4x135,000 grid, broaden the data window on the device (A3), synthesise
     a data spectrum at theta* with the GPU's own make_composite and stage the problem."""
     from mcmc_spec_amd import bands, staging, synth
@@ -48,7 +48,7 @@ def build_workload(eng, npix, with_phot, resolution=1700, seed=2, keep_host_grid
     wl_um = synth.data_wavelengths_um(npix)
     r = [float(wl_um.min()), float(wl_um.max())]
     win = [np.floor(r[0] * 1e4), np.ceil(r[1] * 1e4)]  # "spmin/spmax" of the run, Angstrom
-    eng.broaden_grid_window(win, resolution)
+    eng.broaden_grid_window(win, resolution, broaden)   # ('in_path': the raw window stays on the device beside the broadened grid)
     matrix = synth.make_isochrone_matrix()
     ctm = synth.synthetic_contrast_filters()
     if with_phot:

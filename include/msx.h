@@ -122,6 +122,13 @@ int msx_broaden(msx_ctx *ctx, const double *wl, const double *flux, int64_t n, d
                 double maxsig, double *out);
 /* every staged node, in place, over grid samples [i0, i0+n): the staging step mft6.py:366-378     */
 int msx_broaden_grid(msx_ctx *ctx, int64_t i0, int64_t n, double resolution, double maxsig);
+/* Where the broadening is PLACED: MSX_BROADEN_STAGING (default) -- once per grid node, by msx_broaden_grid: the
+ * reference's live path; MSX_BROADEN_IN_PATH -- msx_broaden_grid additionally keeps the window's rows as they were, and
+ * the problems staged afterwards get the per-walker form MSX_PATH_INPATH (below) beside all the others.  Takes effect at the
+ * next msx_broaden_grid. */
+#define MSX_BROADEN_STAGING 0
+#define MSX_BROADEN_IN_PATH 1
+int msx_set_broadening(msx_ctx *ctx, int32_t placement);
 /* copy one staged node back to the host (tests / the drop-in `specs` view)                        */
 int msx_read_node(msx_ctx *ctx, int32_t it, int32_t ig, double *out_nwl);
 
@@ -148,7 +155,7 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
  * PAIR: for large batches of a binary with <= 4096 pixels: a planner kernel (one thread per walker: the recipe, the
  * prior and band terms, who shares a grid cell with whom) and a kernel that evaluates TWO walkers of one grid cell
  * per workgroup from one set of loads, model values in registers (16,384 walkers 316 us against 419 fused).
- * MSX_PATH_AUTO takes it from 9 walkers per CU on (2,304; spectra of <= 3,072 pixels: 16 per CU; MSX_PAIR_MIN in the
+ * MSX_PATH_AUTO takes it from 8 walkers per CU on (2,048; spectra of <= 3,072 pixels: 12 per CU; MSX_PAIR_MIN in the
  * environment) while the planner's last count says the ensemble pairs (msx_pair_stats); DESIGN.md section 5.1.
  * LINKED: for few walkers x long spectra (2..8 segments of 8192 pixels), one workgroup per (walker, segment) in ONE
  * launch, so that e.g. 128 walkers x 16,384 pixels use 256 CUs instead of 128 and each workgroup's chain of latencies
@@ -168,6 +175,16 @@ int msx_logprob_batch_dev(msx_ctx *ctx, int32_t mode, const double *d_theta, int
 #define MSX_PATH_FUSED 1
 #define MSX_PATH_PAIR 2
 #define MSX_PATH_LINKED 4
+/* In-path broadening (SURVEY A3 placement (ii); mft6.py:124-152 applied per evaluation, the call the reference keeps
+ * commented out at :550): the instrumental broadening is applied PER WALKER to the unreddened composite inside the data
+ * window -- composite of the raw window rows with the recipe's weights, Gaussian FIR, the two edge patches, then reddening
+ * and the resample to the data pixels -- instead of once per grid node at staging.  Broadening is linear: the values agree
+ * with every other form to the order of the sums (~1e-13 relative), not bit for bit.  Never taken by MSX_PATH_AUTO (the
+ * per-node placement is the reference's live path); needs msx_set_broadening(MSX_BROADEN_IN_PATH) BEFORE
+ * msx_broaden_grid, a binary whose data pixels all lie inside that window, float64 tables, a likelihood / posterior /
+ * chi^2 mode.  Costs a walker eight raw rows of the window and a convolution where the table form reads resampled pixels:
+ * several times the headline path's time. */
+#define MSX_PATH_INPATH 8
 int msx_set_path(msx_ctx *ctx, int32_t path);
 
 /* ---- f4: the pre-optimiser's chi^2 (fit_spec, mft6.py:856-1137) on the same kernel --------------- */
@@ -318,6 +335,7 @@ int msx_set_grid_storage(msx_ctx *ctx, int32_t store_dtype);
 #define MSX_FORM_FUSED 0
 #define MSX_FORM_PAIR 1
 #define MSX_FORM_LINKED 2
+#define MSX_FORM_INPATH 3
 int msx_launch_info(msx_ctx *ctx, int32_t mode, int64_t n, int32_t block_threads, char *name, int32_t name_len, int64_t *out8);
 /* the form (MSX_FORM_*) the last launch queued on this context took (MSX_PATH_AUTO looks at the planner's lagging counts) */
 int msx_last_form(msx_ctx *ctx, int32_t *form);

@@ -19,10 +19,12 @@ MSX_ERR_INVALID, MSX_ERR_HIP, MSX_ERR_STATE, MSX_ERR_RANGE = -1, -2, -3, -4
 W_OK, W_REJECT, W_KEYERROR, W_INDEXERROR, W_VALUEERROR, W_HANDOVER = 0, 1, 2, 3, 4, 5
 MODE_LOGLIKE, MODE_LOGPOST, MODE_CHISQ, MODE_LOGPRIOR = 0, 1, 2, 3
 BLOCK_512_SHARED = 1512  # include/msx.h MSX_BLOCK_512_SHARED: 512 threads, two workgroups per CU
-PATH_AUTO, PATH_FUSED, PATH_PAIR, PATH_LINKED = 0, 1, 2, 4  # include/msx.h MSX_PATH_*
-FORM_FUSED, FORM_PAIR, FORM_LINKED = 0, 1, 2  # include/msx.h MSX_FORM_*
+PATH_AUTO, PATH_FUSED, PATH_PAIR, PATH_LINKED, PATH_INPATH = 0, 1, 2, 4, 8  # include/msx.h MSX_PATH_*
+BROADEN_STAGING, BROADEN_IN_PATH = 0, 1  # include/msx.h MSX_BROADEN_*
+FORM_FUSED, FORM_PAIR, FORM_LINKED, FORM_INPATH = 0, 1, 2, 3  # include/msx.h MSX_FORM_*
 STORE_F64, STORE_F32 = 0, 1  # include/msx.h MSX_STORE_*
-FORM_NAMES = {0: 'fused', 1: 'pair (planner + two walkers of one grid cell per workgroup)', 2: 'linked (one workgroup per walker and 8192-pixel segment)'}
+FORM_NAMES = {0: 'fused', 1: 'pair (planner + two walkers of one grid cell per workgroup)', 2: 'linked (one workgroup per walker and 8192-pixel segment)',
+              3: 'in-path broadening (recipe, composite + convolution, resample, then the fused kernel on the given model values)'}
 HOOK_LINKED_FAULT, HOOK_PAIR_LEASES = 1, 2  # include/msx.h MSX_HOOK_*
 MAX_SPEC, MAX_BANDS, MAX_DIM = 3, 8, 8
 
@@ -98,6 +100,7 @@ def load():
         'msx_probe_launch': (C.c_int, [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, _dp]),
         'msx_set_path': (C.c_int, [vp, C.c_int32]),
         'msx_set_grid_storage': (C.c_int, [vp, C.c_int32]),
+        'msx_set_broadening': (C.c_int, [vp, C.c_int32]),
         'msx_opt_init': (C.c_int, [vp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_opt_step': (C.c_int, [vp, _dp, C.POINTER(C.c_int32), C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
         'msx_sampler_run': (C.c_int, [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, _dp, _dp, C.POINTER(C.c_int32),
@@ -141,7 +144,7 @@ def load():
 EXPORTED = ['msx_create', 'msx_destroy', 'msx_last_error', 'msx_device_info', 'msx_stage_grid', 'msx_ccm89_k',
             'msx_resample_linear',
             'msx_broaden', 'msx_broaden_grid', 'msx_read_node', 'msx_stage_problem', 'msx_logprob_batch',
-            'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_set_grid_storage', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
+            'msx_logprob_batch_dev', 'msx_probe_launch', 'msx_set_path', 'msx_set_grid_storage', 'msx_set_broadening', 'msx_opt_init', 'msx_opt_step', 'msx_sampler_run', 'msx_sampler_begin',
             'msx_sampler_shard', 'msx_sampler_enqueue', 'msx_sampler_enqueue_drawn', 'msx_sampler_draw', 'msx_sampler_collect', 'msx_sampler_end', 'msx_make_composite', 'msx_comm_unique_id', 'msx_comm_init', 'msx_comm_allgather_dev', 'msx_comm_wait_slot',
             'msx_comm_init_loopback', 'msx_sampler_enqueue_group',
             'msx_stream_copy_gbps', 'msx_bytes_per_eval', 'msx_launch_info', 'msx_last_form', 'msx_test_hook', 'msx_pair_stats', 'msx_sampler_overlapped', 'msx_sampler_policy']
@@ -277,6 +280,11 @@ class Context:
         self.check(self.lib.msx_probe_launch(self.h, int(mode), C.c_void_p(d_theta_ptr), int(n), int(ndim), C.c_void_p(d_logp_ptr),
                                              C.c_void_p(d_status_ptr), C.c_void_p(stream_ptr), int(block_threads), dptr(out)))
         return {'shader_mhz': float(out[0]), 'walker_us_median': float(out[1]), 'walker_us_max': float(out[2]), 'span_us': float(out[3])}
+
+    def set_broadening(self, placement):
+        """'staging' (default: once per grid node, the reference's live path) or 'in_path' (msx_set_broadening): the next
+        broaden_grid also keeps the raw window, and problems staged afterwards have the per-walker form PATH_INPATH."""
+        self.check(self.lib.msx_set_broadening(self.h, {'staging': BROADEN_STAGING, 'in_path': BROADEN_IN_PATH}[placement]))
 
     def set_path(self, path):
         """PATH_AUTO / PATH_FUSED / PATH_PAIR / PATH_LINKED: which form of the hot path launches take (same bits either

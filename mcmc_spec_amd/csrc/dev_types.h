@@ -125,11 +125,22 @@ struct DevProblem {
     // wall clock and the shader-cycle counter at its first and last line -- [walker][4] for the first kProbeWalkers
     // walkers: the clock the CUs ran at under THIS kernel's load, and the walker's own time inside the launch
     unsigned long long *clk_probe;
+    // in-path broadening (inpath_kernels.h; MSX_PATH_INPATH): the walkers' model vectors, computed before the launch by the
+    // in-path kernels -- [walker][given_stride] in PIXEL order -- and read by logprob_kernel's GIVEN variant in place of the blend
+    const double *given;
+    int64_t given_stride;
 #ifdef MSX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [walker][16] shader-clock stamps
 #endif
 };
 constexpr int kProbeWalkers = 4096;
+// what the in-path kernels need of a walker's recipe (inpath_recipe_kernel -> inpath_conv_kernel, inpath_resample_kernel)
+struct InpathRec {
+    double w[8];
+    int32_t node[8];
+    double redc;
+    int32_t ok, pad;
+};
 // granules of one walker (smp_gran): coordinate d = words 2 d (high half) and 2 d + 1 (low half); then the log-probability's
 // two halves and the low 32 bits of the acceptance count
 constexpr int kGranPerWalker = 2 * MSX_MAX_DIM + 4, kGranLogp = 2 * MSX_MAX_DIM, kGranNacc = 2 * MSX_MAX_DIM + 2;

@@ -292,7 +292,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //        choose_variant).  Which bits pay was measured per workgroup size (same box, alternating runs): the 256-thread
 //        variants gain from both (2,048 walkers 63.3 -> 60.4 us), the 512-thread headline variant gains from the chi^2
 //        pass's (14.63 -> 14.36 us per step) and LOSES with the blend's (14.67 -> 14.96: the loads' order changed).
-template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false, int FULL = 0>
+// GIVEN = the model values are not blended here: the in-path broadening kernels (inpath_kernels.h) have left them in
+//        P.given[walker][pixel]; everything else -- recipe (for the walker's status, its prior and band terms), fit sums,
+//        median, chi^2 pass -- is this kernel's.  One variant: 512 threads, quad trips.
+template <int NS, int U, int MAXT, bool GM = false, bool SH = false, bool PF = false, bool LK = false, bool R32 = false, int FULL = 0,
+          bool GIVEN = false>
 // (second launch bound = waves per SIMD the register allocation must leave room for: k workgroups of T threads per
 // CU <=> k T / 256.  256 threads: three per CU = 168 VGPRs; 512 threads sharing a CU: two per CU = four waves per
 // SIMD = 128 VGPRs.)
@@ -683,6 +687,15 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         double2 klA = make_double2(0.0, 0.0), klB = klA;
         float4 dk = make_float4(0.f, 0.f, 0.f, 0.f);
+        double2 mA, mB;
+        if constexpr (GIVEN) {
+            // (pixel order; pad pixels of the last element repeat the last real one -- finish_elem does not look at them)
+            const double *gv = P.given + wk * P.given_stride;
+            const int paA = ((ecA >> 8) << 9) | (ecA & 255), paB = ((ecB >> 8) << 9) | (ecB & 255);
+            const int last = npix - 1;
+            mA = make_double2(gv[paA < last ? paA : last], gv[paA + 256 < last ? paA + 256 : last]);
+            mB = make_double2(gv[paB < last ? paB : last], gv[paB + 256 < last ? paB + 256 : last]);
+        } else {
 #pragma unroll
         for (int c0 = 0; c0 < NC; c0 += G) {
             double2 rA[G], rB[G];
@@ -712,11 +725,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
             blend_accumulate<G>(r2, h2, w + c0, wf + c0, RED, sr[2], sh[2]);
             blend_accumulate<G>(r3, h3, w + c0, wf + c0, RED, sr[3], sh[3]);
         }
-        double2 mA, mB;
         mA.x = blend_finish(sr[0], sh[0], klA.x, (double)dk.x, redc, RED, e2tab);
         mA.y = blend_finish(sr[1], sh[1], klA.y, (double)dk.y, redc, RED, e2tab);
         mB.x = blend_finish(sr[2], sh[2], klB.x, (double)dk.z, redc, RED, e2tab);
         mB.y = blend_finish(sr[3], sh[3], klB.y, (double)dk.w, redc, RED, e2tab);
+        }
         if (!kEarlyFUq) { fA = ld_off(P.f2, oA); uA = ld_off(P.u2, oA); fB = ld_off(P.f2, oB); uB = ld_off(P.u2, oB); }
         if (PF) { fA = lds_f2[ecA]; uA = lds_u2[ecA]; fB = lds_f2[ecB]; uB = lds_u2[ecB]; }  // (staged in phase 0)
         if (LK) { fA = lds_lf2[ecA]; fB = lds_lf2[ecB]; }

@@ -58,6 +58,7 @@
 #include "logprob_kernel.h"
 #include "pair_kernel.h"
 #include "staging_kernels.h"
+#include "inpath_kernels.h"
 
 // ================================================================================================
 // host side: context + C ABI
@@ -120,6 +121,17 @@ struct msx_ctx {
     int nseg = 1;                   // segments of the staged spectrum (8192 pixels each)
     int64_t scratch_rows = 0;       // 0 = neither form applies: launches are never cut into sub-batches
     int32_t path = 0;               // MSX_PATH_AUTO / _FUSED / _PAIR / _LINKED (msx_set_path)
+    // in-path broadening (inpath_kernels.h; msx_set_broadening, MSX_PATH_INPATH): the raw window rows kept by
+    // msx_broaden_grid, the taps' parameters, and the form's scratch (sized at msx_stage_problem)
+    int32_t broaden_placement = 0;  // MSX_BROADEN_STAGING / MSX_BROADEN_IN_PATH (takes effect at the next msx_broaden_grid)
+    double *d_raw_win = nullptr;    // [nt * ng][raw_n]: the window before the broadening
+    int64_t raw_i0 = 0, raw_n = 0;
+    int raw_lx = 0;
+    double raw_dx = 0.0, raw_sigma = 0.0;
+    InpathRec *d_inp_rec = nullptr;
+    double *d_inp_tmp = nullptr, *d_inp_given = nullptr;
+    const int64_t *d_pix_lo = nullptr;
+    int64_t inp_rows = 0, inp_gstride = 0;  // walkers per sub-batch (0: the staged problem has no in-path form)
     // pair form (pair_kernel.h): binaries of <= 4096 pixels with the register-resident recipe
     int64_t pair_rows = 0;          // walkers per sub-batch = capacity of the planner's item lists (0: no pair form here)
     // MSX_PATH_AUTO takes the pair form from this many walkers on (MSX_PAIR_MIN; 0 = never); set per problem by
@@ -221,12 +233,14 @@ void free_problem(msx_ctx *c) {
     c->opt_chains = 0;
     if (c->h_pair_stats) (void)hipHostFree(c->h_pair_stats);
     c->h_pair_stats = nullptr;
-    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_items, c->d_pair_singles};
+    void *sp[] = {c->d_model_scratch, c->d_segparts, c->d_seg_flag, c->d_pair_plan, c->d_pair_items, c->d_pair_singles,
+                  c->d_inp_rec, c->d_inp_tmp, c->d_inp_given};
     for (void *p : sp)
         if (p) (void)hipFree(p);
     c->d_segparts = nullptr; c->d_seg_flag = nullptr; c->d_model_scratch = nullptr; c->scratch_rows = 0;
     c->d_pair_plan = nullptr; c->d_pair_items = nullptr; c->d_pair_singles = nullptr; c->pair_rows = 0;
     c->linked_poisoned = false;
+    c->d_inp_rec = nullptr; c->d_inp_tmp = c->d_inp_given = nullptr; c->d_pix_lo = nullptr; c->inp_rows = 0;
 }
 
 void free_grid(msx_ctx *c) {
@@ -235,6 +249,8 @@ void free_grid(msx_ctx *c) {
         if (p) (void)hipFree(p);
     c->d_grid = c->d_wl = c->d_kgrid = c->d_teff = c->d_logg = nullptr;
     c->d_present = nullptr;
+    if (c->d_raw_win) (void)hipFree(c->d_raw_win);
+    c->d_raw_win = nullptr; c->raw_n = 0;
     c->grid_staged = false;
 }
 
@@ -351,6 +367,7 @@ struct Variant {
     bool gm, sh, pf, lk, r32;
     int full;  // FULL bits of the variant (logprob_kernel.h): 1 blend, 2 chi^2 pass
     const char *what;
+    bool given = false;  // model values given (in-path broadening): the one such entry at the table's end
 };
 #define MSX_V(NS_, T_, GM_, SH_, PF_, LK_, WHAT_) \
     {(const void *)logprob_kernel<NS_, 2, T_, GM_, SH_, PF_, LK_>, NS_, T_, GM_, SH_, PF_, LK_, false, 0, WHAT_}
@@ -389,13 +406,21 @@ const Variant kVariants[] = {
     MSX_VF(256, true, false, kFull256, "two per CU, four pixels per lane and trip; whole trips, no clamps"),
     MSX_VF(256, true, true, kFull256, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps"),
     MSX_VF(512, false, true, 2, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps in the chi^2 pass"),
+    // in-path broadening (inpath_kernels.h): the model values are given, the blend is compiled out
+    {(const void *)logprob_kernel<2, 2, 512, false, false, false, false, false, 0, true>, 2, 512, false, false, false, false, false, 0,
+     "model values given by the in-path broadening kernels; four pixels per lane and trip", true},
 };
 #undef MSX_V
 #undef MSX_V32
 #undef MSX_VF
 const Variant *find_variant(int ns, int threads, bool gm, bool sh, bool pf, bool lk, bool r32 = false, int full = 0) {
     for (const Variant &v : kVariants)
-        if (v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk && v.r32 == r32 && v.full == full) return &v;
+        if (!v.given && v.ns == ns && v.threads == threads && v.gm == gm && v.sh == sh && v.pf == pf && v.lk == lk && v.r32 == r32 && v.full == full) return &v;
+    return nullptr;
+}
+const Variant *given_variant() {
+    for (const Variant &v : kVariants)
+        if (v.given) return &v;
     return nullptr;
 }
 struct VariantChoice {
@@ -405,6 +430,7 @@ struct VariantChoice {
 // Which variant a launch of n walkers with workgroups of B threads takes (LK: the linked form, one workgroup per walker
 // and segment; else the fused kernel in the variant the table in pick_block() names), and its dynamic LDS.
 VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, int B, bool shared512, bool LK) {
+    if (P.given) return {given_variant(), sizeof(double) * (size_t)P.npix + (size_t)c->pad_lds};  // (in-path form: launch_inpath)
     // dynamic LDS: the model vector (linked: one segment of it, and the segment's data flux behind it)
     const size_t lds = LK ? sizeof(double) * (size_t)(2 * kSegElems) + sizeof(double2) * (size_t)kSegElems
                           : sizeof(double) * (size_t)P.npix + (size_t)c->pad_lds;
@@ -483,6 +509,32 @@ int launch_logprob(msx_ctx *c, const DevProblem &P, const LaunchArgs &A, int B, 
     return MSX_OK;
 }
 
+// The in-path broadening form over A.n <= inp_rows walkers (inpath_kernels.h): recipe -> composite of the raw window rows,
+// convolved -> edge patches, reddening, resample -> logprob_kernel<GIVEN>.
+int launch_inpath(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
+    const int64_t m = A.n, nwin = c->raw_n;
+    hipLaunchKernelGGL(inpath_recipe_kernel, dim3((unsigned)((m + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, A.s, A.theta,
+                       (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, m, P.tmin, P.tmax, c->d_inp_rec, P);
+    HIP_TRY(c, hipGetLastError());
+    const size_t lds = sizeof(double) * ((size_t)c->raw_lx + ((size_t)(kConvTile + c->raw_lx - 1) * 5) / 4 + 2);
+    if (lds > 150 * 1024) return fail(c, MSX_ERR_RANGE, "in-path broadening: kernel too long for the LDS tile");
+    static bool raised = false;  // (once per process; the limit is per function)
+    if (lds > 64 * 1024 && !raised) {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)inpath_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL(inpath_conv_kernel, dim3((unsigned)((nwin + kConvTile - 1) / kConvTile), (unsigned)m), dim3(256), lds, A.s,
+                       c->d_raw_win, nwin, c->d_inp_rec, c->d_inp_tmp, nwin, nwin, c->raw_lx, c->raw_dx, c->raw_sigma);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(inpath_resample_kernel, dim3((unsigned)((c->inp_gstride + 255) / 256), (unsigned)m), dim3(256), 0, A.s, c->d_inp_tmp,
+                       nwin, nwin, c->raw_i0, c->d_inp_rec, c->d_pix_lo, P.pix_t, c->d_kgrid, (int64_t)P.npix, c->d_inp_given, c->inp_gstride);
+    HIP_TRY(c, hipGetLastError());
+    DevProblem Pg = P;
+    Pg.given = c->d_inp_given;
+    Pg.given_stride = c->inp_gstride;
+    return launch_logprob<false>(c, Pg, A, 512, false);
+}
+
 // Does MSX_PATH_AUTO take the linked form for n walkers (of a problem and mode that have one)?  While every workgroup
 // gets a CU of its own: the walker's workgroups wait for each other.
 bool auto_takes_linked(const msx_ctx *c, int64_t n) {
@@ -509,7 +561,7 @@ bool pair_worth_it(msx_ctx *c, bool peek = false) {
 // Which FORM of the path a launch of n walkers in `mode` takes (msx_logprob_batch_dev decides with this; msx_launch_info
 // and msx_bytes_per_eval ask with peek = true).  err != MSX_OK: an explicit msx_set_path that the staged problem cannot take.
 struct FormChoice {
-    bool linked = false, pair = false;
+    bool linked = false, pair = false, inpath = false;
     int err = MSX_OK;
     const char *msg = "";
 };
@@ -548,6 +600,15 @@ FormChoice decide_form(msx_ctx *c, int64_t n, int mode, bool peek) {
         f.pair = false; f.linked = false;
     }
     if (f.pair) f.linked = false;
+    // in-path broadening (inpath_kernels.h): never taken by MSX_PATH_AUTO -- the per-node placement is the reference's
+    if (c->path == MSX_PATH_INPATH) {
+        if (c->inp_rows <= 0 || !fast || Pc.smp_on || !lp_mode || c->store_f32 || c->probe_launch) {
+            f.err = MSX_ERR_STATE;
+            f.msg = "msx_set_path(INPATH): needs msx_set_broadening(MSX_BROADEN_IN_PATH) before msx_broaden_grid, a binary whose data pixels lie inside that window, float64 tables, the register-resident recipe and a likelihood / posterior / chi^2 mode";
+            return f;
+        }
+        f.inpath = true; f.pair = false; f.linked = false;
+    }
     return f;
 }
 
@@ -806,6 +867,15 @@ int msx_broaden_grid(msx_ctx *c, int64_t i0, int64_t n, double resolution, doubl
     int lx;
     conv_taps(mean, wl[1] - wl[0], resolution, maxsig, &sigma, &lx);
     const int64_t rows = (int64_t)c->nt * c->ng;
+    // in-path placement (msx_set_broadening): the window's rows as they are NOW are kept for the per-walker form; the grid
+    // is broadened in place all the same, so that every other form -- and the band tables -- see the reference's live path
+    if (c->d_raw_win) { (void)hipFree(c->d_raw_win); c->d_raw_win = nullptr; c->raw_n = 0; }
+    if (c->broaden_placement == MSX_BROADEN_IN_PATH) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_raw_win, sizeof(double) * rows * n));
+        HIP_TRY(c, hipMemcpy2D(c->d_raw_win, sizeof(double) * n, c->d_grid + i0, sizeof(double) * c->nwl, sizeof(double) * n, (size_t)rows,
+                               hipMemcpyDeviceToDevice));
+        c->raw_i0 = i0; c->raw_n = n; c->raw_lx = lx; c->raw_dx = wl[1] - wl[0]; c->raw_sigma = sigma;
+    }
     double *d_tmp = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_tmp, sizeof(double) * rows * n));
     rc = launch_conv(c, c->d_grid + i0, c->nwl, d_tmp, rows, n, lx, wl[1] - wl[0], sigma);
@@ -914,6 +984,25 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
                        P.pix_ivar, p->npix, npair, d_kl2, d_dk2, d_f2, d_u2, d_iv2);
     HIP_TRY(c, hipGetLastError());
     P.r2 = d_r2; P.h2 = d_h2; P.kl2 = d_kl2; P.dk2 = d_dk2; P.f2 = d_f2; P.u2 = d_u2; P.iv2 = d_iv2; P.npair = npair;
+    c->d_pix_lo = d_lo;
+    c->inp_rows = 0;
+    P.given = nullptr; P.given_stride = 0;
+    if (c->d_raw_win && p->nspec == 2 && !model_in_global && !p->no_spectrum) {
+        // the in-path form needs both model samples of every data pixel inside the window that msx_broaden_grid kept raw
+        bool inside = true;
+        for (int64_t i = 0; i < p->npix && inside; ++i) inside = p->pix_lo[i] >= c->raw_i0 && p->pix_lo[i] + 1 < c->raw_i0 + c->raw_n;
+        if (inside) {
+            const int64_t gstride = 2 * npair;
+            int64_t budget = 256ll << 20;
+            if (const char *e = getenv("MSX_INPATH_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
+            int64_t rows_i = budget / (int64_t)(sizeof(double) * (c->raw_n + gstride) + sizeof(InpathRec));
+            rows_i = std::max<int64_t>(16, std::min<int64_t>(rows_i, 16384));
+            HIP_TRY(c, hipMalloc((void **)&c->d_inp_rec, sizeof(InpathRec) * rows_i));
+            HIP_TRY(c, hipMalloc((void **)&c->d_inp_tmp, sizeof(double) * rows_i * c->raw_n));
+            HIP_TRY(c, hipMalloc((void **)&c->d_inp_given, sizeof(double) * rows_i * gstride));
+            c->inp_rows = rows_i; c->inp_gstride = gstride;
+        }
+    }
     c->store_f32 = false;
     if (c->store_dtype == MSX_STORE_F32) {
         // A separately labelled storage precision (store_dtype): the R table rounded to float32, read by the
@@ -1136,9 +1225,16 @@ int msx_set_grid_storage(msx_ctx *c, int32_t store_dtype) {
 }
 
 int msx_set_path(msx_ctx *c, int32_t path) {
-    if (!c || (path != MSX_PATH_AUTO && path != MSX_PATH_FUSED && path != MSX_PATH_LINKED && path != MSX_PATH_PAIR))
-        return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path (MSX_PATH_AUTO, _FUSED, _PAIR or _LINKED)");
+    if (!c || (path != MSX_PATH_AUTO && path != MSX_PATH_FUSED && path != MSX_PATH_LINKED && path != MSX_PATH_PAIR && path != MSX_PATH_INPATH))
+        return fail(c, MSX_ERR_INVALID, "msx_set_path: bad path (MSX_PATH_AUTO, _FUSED, _PAIR, _LINKED or _INPATH)");
     c->path = path;
+    return MSX_OK;
+}
+
+int msx_set_broadening(msx_ctx *c, int32_t placement) {
+    if (!c || (placement != MSX_BROADEN_STAGING && placement != MSX_BROADEN_IN_PATH))
+        return fail(c, MSX_ERR_INVALID, "msx_set_broadening: MSX_BROADEN_STAGING or MSX_BROADEN_IN_PATH");
+    c->broaden_placement = placement;
     return MSX_OK;
 }
 
@@ -1171,19 +1267,23 @@ int msx_logprob_batch_dev(msx_ctx *c, int32_t mode, const double *d_theta, int64
     // ---- which form of the path (decide_form) ---------------------------------------------------------------
     const FormChoice form = decide_form(c, n, mode, false);
     if (form.err != MSX_OK) return fail(c, form.err, form.msg);
-    const bool linked = form.linked, pair = form.pair;
+    const bool linked = form.linked, pair = form.pair, inpath = form.inpath;
     if (c->smp_overlap_launch) A.ng_mode_fast |= 1 << 20;
     if (c->probe_launch) A.ng_mode_fast |= 1 << 21;
-    c->last_form = pair ? MSX_FORM_PAIR : linked ? MSX_FORM_LINKED : MSX_FORM_FUSED;
+    c->last_form = inpath ? MSX_FORM_INPATH : pair ? MSX_FORM_PAIR : linked ? MSX_FORM_LINKED : MSX_FORM_FUSED;
     // sub-batches: the linked form's scratch, and the fused kernel's global model vectors for spectra beyond the LDS,
     // hold scratch_rows walkers; the pair form's spill rows pair_rows
-    const int64_t step = pair ? c->pair_rows : (linked || c->model_in_global) ? c->scratch_rows : n;
+    const int64_t step = inpath ? c->inp_rows : pair ? c->pair_rows : (linked || c->model_in_global) ? c->scratch_rows : n;
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min<int64_t>(step, n - off);
         A.theta = d_theta + off * ndim; A.logp = d_logp + off; A.status = d_status + off; A.n = m;
         const DevProblem P = problem_at(Pc, off, mode, ndim);
         const int B = block_threads > 0 ? block_threads : pick_block(c, m, Pc.npix);
         int rc;
+        if (inpath) {
+            if ((rc = launch_inpath(c, P, A))) return rc;
+            continue;
+        }
         if (pair) {
             if ((rc = launch_pair(c, P, A))) return rc;
             continue;
@@ -2096,7 +2196,7 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
     const FormChoice f = decide_form(c, n, mode, true);
     if (f.err != MSX_OK) return fail(c, f.err, f.msg);
     // (the first sub-batch stands for the launch: sub-batches only differ in their walker count)
-    const int64_t m = f.pair ? std::min<int64_t>(n, c->pair_rows) : (f.linked || c->model_in_global) && c->scratch_rows ? std::min<int64_t>(n, c->scratch_rows) : n;
+    const int64_t m = f.inpath ? std::min<int64_t>(n, c->inp_rows) : f.pair ? std::min<int64_t>(n, c->pair_rows) : (f.linked || c->model_in_global) && c->scratch_rows ? std::min<int64_t>(n, c->scratch_rows) : n;
     std::string nm;
     const void *fn = nullptr;
     int64_t threads = 0, dyn = 0, grid = 0;
@@ -2110,19 +2210,22 @@ int msx_launch_info(msx_ctx *c, int32_t mode, int64_t n, int32_t block_threads, 
              " element trips per lane" + (full ? ", FULL" : "") + "> (planner: one thread per walker; two walkers of one grid cell per workgroup, one set of row loads, model values in registers; two workgroups per CU)";
         threads = 512; grid = m;
     } else {
-        const int B = f.linked ? 512 : block_threads > 0 ? block_threads : pick_block(c, m, c->P.npix);
-        const VariantChoice ch = choose_variant(c, c->P, m, B, shared512, f.linked);
+        const int B = (f.linked || f.inpath) ? 512 : block_threads > 0 ? block_threads : pick_block(c, m, c->P.npix);
+        DevProblem Pq = c->P;
+        if (f.inpath) { Pq.given = c->d_inp_given; Pq.given_stride = c->inp_gstride; }
+        const VariantChoice ch = choose_variant(c, Pq, m, B, shared512, f.linked);
         if (!ch.v) return fail(c, MSX_ERR_STATE, "no kernel variant for this launch");
         v = ch.v;
         fn = v->fn;
         threads = v->threads; dyn = (int64_t)ch.dyn_lds;
         grid = f.linked ? ((m + 7) & ~7ll) * c->nseg : m;
         nm = std::string("logprob_kernel<NS=") + std::to_string(v->ns) + ", " + std::to_string(v->threads) + " threads" +
-             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + (v->full == 3 ? ", FULL" : v->full == 2 ? ", FULL(chi2 pass)" : "") + "> (" + v->what + ")";
+             (v->lk ? ", linked" : v->gm ? ", GM" : v->pf && v->sh ? ", SH, PF" : v->pf ? ", PF" : v->sh ? ", SH" : "") + (v->r32 ? ", R32" : "") + (v->full == 3 ? ", FULL" : v->full == 2 ? ", FULL(chi2 pass)" : "") + (v->given ? ", GIVEN" : "") + "> (" + v->what + ")";
+        if (f.inpath) nm = "inpath_recipe_kernel + inpath_conv_kernel + inpath_resample_kernel + " + nm;
     }
     hipFuncAttributes at;
     HIP_TRY(c, hipFuncGetAttributes(&at, fn));
-    out8[0] = f.pair ? MSX_FORM_PAIR : f.linked ? MSX_FORM_LINKED : MSX_FORM_FUSED;
+    out8[0] = f.inpath ? MSX_FORM_INPATH : f.pair ? MSX_FORM_PAIR : f.linked ? MSX_FORM_LINKED : MSX_FORM_FUSED;
     out8[1] = threads;
     out8[2] = at.numRegs;
     out8[3] = (int64_t)at.sharedSizeBytes;

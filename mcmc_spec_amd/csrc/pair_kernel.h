@@ -490,6 +490,39 @@ constexpr int kPlanThreads = 256;
 constexpr int kPlanCells = 12;
 constexpr int kPlanSortMax = 2048;  // capacity of the workgroup's card list (1024 walkers: at most 1024 cards)
 
+// The recipe's tables for the one-thread form (recipe.h, recipe_scalar2), copied into LDS by a workgroup of kPlanThreads
+// threads and padded with +inf to the sizes the 4-ary searches walk: every load first (clamped indices, no branches between
+// them: one round trip), then the stores.  The caller's barrier publishes them.
+__device__ __forceinline__ void stage_scalar_tables(const unsigned char *__restrict__ rblk, const DevProblem &P, int niso, int nt, int ng,
+                                                    ScalarTabs &T, ScalarPriorTabs &TP) {
+    __shared__ double s_isot[kPlanIsoPad], s_isol[kPlanIsoPad], s_teff[kPlanNodePad + 1], s_logg[kPlanNodePad + 1];
+    __shared__ double4 s_isopack[kPlanIsoPad];
+    __shared__ double s_ave[kPlanIsoPad], s_avm[2 * kWave], s_avs[2 * kWave];
+    __shared__ unsigned int s_pmask[kWave];
+    static_assert(kPlanThreads == kPlanIsoPad, "one table entry per thread");
+    const int tid = threadIdx.x;
+    const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT);
+    const double4 *g_pack = reinterpret_cast<const double4 *>(rblk + kRbIsoPack);
+    const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
+    const int nav = P.nav;
+    const int ii = tid < niso ? tid : niso - 1, it = tid < nt ? tid : nt - 1, ig = tid < ng ? tid : ng - 1;
+    const int ie = tid < nav + 1 ? tid : 0, ia = tid < nav ? tid : 0;
+    const double v_isot = g_isot[ii], v_isol = P.iso_l[ii];
+    const double4 v_pack = g_pack[tid];  // (the block holds all 256 entries)
+    const double v_teff = g_teff[it], v_logg = g_logg[ig];
+    const unsigned int v_mask = reinterpret_cast<const unsigned int *>(rblk + kRbPresent)[it];
+    const double v_ave = nav > 0 ? P.av_edges[ie] : 0.0, v_avm = nav > 0 ? P.av_mu[ia] : 0.0, v_avs = nav > 0 ? P.av_sig[ia] : 0.0;
+    s_isot[tid] = tid < niso ? v_isot : INFINITY;
+    s_isol[tid] = v_isol;
+    s_isopack[tid] = v_pack;
+    s_ave[tid] = (nav > 0 && tid < nav + 1) ? v_ave : INFINITY;
+    if (tid < 2 * kWave) { s_avm[tid] = v_avm; s_avs[tid] = v_avs; }
+    if (tid <= kPlanNodePad) { s_teff[tid] = tid < nt ? v_teff : INFINITY; s_logg[tid] = tid < ng ? v_logg : INFINITY; }
+    if (tid < kWave) s_pmask[tid] = tid < nt ? v_mask : 0u;
+    T = ScalarTabs{s_isot, s_teff, s_logg, s_isopack, s_pmask, s_ave, niso, nt, ng, nav};
+    TP = ScalarPriorTabs{s_isot, s_isol, s_avm, s_avs};
+}
+
 // The lanes of one tag, in lane order: ranks 0 and 1 are a pair, 2 and 3, ...; the odd one out of a tag is `leftover`.
 // Ballots only.  partner_lane = the lane this (even-rank) lane pairs with, or -1.
 __device__ __forceinline__ void plan_wave_pairs(unsigned long long tag, int lane, int *partner_lane, bool *leftover) {
@@ -522,10 +555,6 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
                  double gate_tmin, double gate_tmax, int32_t *__restrict__ plan, PairItem *__restrict__ pair_items,
                  PairRec *__restrict__ single_items, double *__restrict__ logp, int32_t *__restrict__ status, int32_t *__restrict__ host_stats, DevProblem P) {
     constexpr int NS = 2, ndim = 6;
-    __shared__ double s_isot[kPlanIsoPad], s_isol[kPlanIsoPad], s_teff[kPlanNodePad + 1], s_logg[kPlanNodePad + 1];
-    __shared__ double4 s_isopack[kPlanIsoPad];
-    __shared__ double s_ave[kPlanIsoPad], s_avm[2 * kWave], s_avs[2 * kWave];
-    __shared__ unsigned int s_pmask[kWave];
     __shared__ unsigned long long s_cards[kPlanSortMax];
     __shared__ int2 s_pairs[kPlanSortMax / 2];
     __shared__ unsigned long long s_left[kPlanSortMax];
@@ -547,29 +576,10 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     double t[ndim];
 #pragma unroll
     for (int k = 0; k < ndim; ++k) t[k] = mine ? theta[i * ndim + k] : 0.0;
-    {
-        // the tables, padded with +inf to the sizes the 4-ary searches walk (recipe.h, recipe_scalar2): every load first
-        // (clamped indices, no branches between them: one round trip), then the stores
-        const double *g_isot = reinterpret_cast<const double *>(rblk + kRbIsoT);
-        const double4 *g_pack = reinterpret_cast<const double4 *>(rblk + kRbIsoPack);
-        const double *g_teff = reinterpret_cast<const double *>(rblk + kRbTeff), *g_logg = reinterpret_cast<const double *>(rblk + kRbLogg);
-        const int nav = P.nav;
-        const int ii = tid < niso ? tid : niso - 1, it = tid < nt ? tid : nt - 1, ig = tid < ng ? tid : ng - 1;
-        const int ie = tid < nav + 1 ? tid : 0, ia = tid < nav ? tid : 0;
-        const double v_isot = g_isot[ii], v_isol = P.iso_l[ii];
-        const double4 v_pack = g_pack[tid];  // (the block holds all 256 entries)
-        const double v_teff = g_teff[it], v_logg = g_logg[ig];
-        const unsigned int v_mask = reinterpret_cast<const unsigned int *>(rblk + kRbPresent)[it];
-        const double v_ave = nav > 0 ? P.av_edges[ie] : 0.0, v_avm = nav > 0 ? P.av_mu[ia] : 0.0, v_avs = nav > 0 ? P.av_sig[ia] : 0.0;
-        s_isot[tid] = tid < niso ? v_isot : INFINITY;
-        s_isol[tid] = v_isol;
-        s_isopack[tid] = v_pack;
-        s_ave[tid] = (nav > 0 && tid < nav + 1) ? v_ave : INFINITY;
-        if (tid < 2 * kWave) { s_avm[tid] = v_avm; s_avs[tid] = v_avs; }
-        if (tid <= kPlanNodePad) { s_teff[tid] = tid < nt ? v_teff : INFINITY; s_logg[tid] = tid < ng ? v_logg : INFINITY; }
-        if (tid < kWave) s_pmask[tid] = tid < nt ? v_mask : 0u;
-        if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
-    }
+    ScalarTabs T;
+    ScalarPriorTabs TP;
+    stage_scalar_tables(rblk, P, niso, nt, ng, T, TP);
+    if (tid == 0) { s_nc = 0; s_np = 0; s_nl = 0; s_ns = 0; }
     __syncthreads();
     MSX_STAMP(P, blockIdx.x, 1);
     unsigned long long tag = 0ull;  // 0: nothing left to evaluate (rejected by the prior box, or an error status)
@@ -578,7 +588,6 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     double w[NS * 4];
     BandRows band_pre;
     if (mine) {
-        const ScalarTabs T = {s_isot, s_teff, s_logg, s_isopack, s_pmask, s_ave, niso, nt, ng, P.nav};
         double redc;
         const int st = recipe_scalar2(gates, T, mode, t, node, w, &redc, iso_lo, &av_bin);
         MSX_STAMP(P, blockIdx.x, 2);
@@ -682,7 +691,6 @@ pair_plan_kernel(const double *__restrict__ theta, const unsigned char *__restri
     // here and not by two waves of the pair kernel, whose workgroup would wait for their table round trips after its
     // median is long done
     if (tag != 0ull) {
-        const ScalarPriorTabs TP = {s_isot, s_isol, s_avm, s_avs};
         mrec.lp = prior_terms_scalar2(P, TP, mode, t, av_bin, iso_lo);
         MSX_STAMP(P, blockIdx.x, 6);
         mrec.chi_extra = band_terms_scalar2(P, mode, t, node, w, band_pre);

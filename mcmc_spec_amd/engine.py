@@ -50,9 +50,12 @@ class Engine:
         teff, logg, wl, flux, present = staging.parse_specs(specs)
         self.stage_grid(wl, teff, logg, flux, present)
 
-    def broaden_grid_window(self, w_aa, resolution):
+    def broaden_grid_window(self, w_aa, resolution, placement='staging'):
         """Broaden every node over the data window ``[min(w), max(w)]`` [A] in place: the staging step
-        of ``spec_interpolator`` (mft6.py:366-378)."""
+        of ``spec_interpolator`` (mft6.py:366-378).  ``placement='in_path'`` additionally keeps the raw window on the
+        device: problems staged afterwards can be evaluated with the broadening applied per walker
+        (``ctx.set_path(_lib.PATH_INPATH)``) beside the default forms."""
+        self.ctx.set_broadening(placement)
         wl = self.grid['wl']
         idx = np.where((wl >= min(w_aa)) & (wl <= max(w_aa)))[0]
         self.ctx.broaden_grid(int(idx[0]), int(idx.size), resolution, 5.0)

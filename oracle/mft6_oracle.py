@@ -318,8 +318,13 @@ def norm_spec(wl, model, data):
 
 
 def loglikelihood(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, matrix, av=True, optimize=False,
-                  bandlib=None, temps=None, lgs=None, parts=None, spectrum=True):
-    """mft6.py:1139-1205 for len(p0) in (6, 8).  ``parts`` (a dict) receives intermediates for tests."""
+                  bandlib=None, temps=None, lgs=None, parts=None, spectrum=True, inpath=None):
+    """mft6.py:1139-1205 for len(p0) in (6, 8).  ``parts`` (a dict) receives intermediates for tests.
+
+    ``inpath=dict(specs_raw=..., w=[wmin, wmax] (Angstrom), resolution=R)``: SURVEY A3 placement (ii) -- the composite of the
+    spectrum term is built from the UNbroadened node spectra and ``broaden`` (mft6.py:124-152, the call the reference keeps
+    commented out at :550, restricted here to the data window like the staging step :373) is applied to it per evaluation,
+    before the reddening; ``specs`` (broadened per node at staging) still feeds the contrast and photometry terms."""
     wl, spec = np.array(data)
     t_guess = p0[:nspec]
     a_v = p0[nspec]
@@ -329,6 +334,14 @@ def loglikelihood(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, matrix
     wave1, cspec, contrast, phot_cwl, phot, _ = make_composite(
         t_guess, lg, rad, plx, fr[2], fr[5], r, specs, ctm, ptm, tmi, tma, nspec=nspec, bandlib=bandlib,
         temps=temps, lgs=lgs)
+    if inpath is not None:
+        wave_r, cspec_r = make_composite(t_guess, lg, rad, plx, fr[2], fr[5], r, inpath['specs_raw'], ctm, ptm, tmi, tma,
+                                         nspec=nspec, bandlib=bandlib, temps=temps, lgs=lgs)[:2]
+        inside = np.where((wave_r >= min(inpath['w'])) & (wave_r <= max(inpath['w'])))
+        _, brd = broaden(wave_r[inside], cspec_r[inside], inpath['resolution'])
+        cspec = np.array(cspec_r, dtype=float)
+        cspec[inside] = brd
+        wave1 = wave_r
     if av == True and a_v > 0:  # mft6.py:1161-1163
         cspec = extinct(wave1, cspec, a_v)
         init_phot = -2.5 * np.log10(extinct(phot_cwl, 10 ** (-0.4 * phot), a_v))
@@ -438,14 +451,14 @@ def _logprior_no_dist(p0, nspec, tmin, tmax, matrix, av_prior, prior, ext, rad_p
 
 
 def logposterior(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, tmin, tmax, matrix, av_prior,
-                 prior=0, a=True, dist_fit=True, rad_prior=False, bandlib=None, temps=None, lgs=None):
-    """mft6.py:1459-1470."""
+                 prior=0, a=True, dist_fit=True, rad_prior=False, bandlib=None, temps=None, lgs=None, inpath=None):
+    """mft6.py:1459-1470.  (``inpath``: see loglikelihood.)"""
     lp = logprior(p0, nspec, tmin, tmax, matrix, av_prior, prior=prior, ext=a, dist_fit=dist_fit,
                   rad_prior=rad_prior)
     if not np.isfinite(lp):
         return -np.inf
     lh = loglikelihood(p0, fr, nspec, data, err, r, specs, ctm, ptm, tmi, tma, matrix, av=a,
-                       bandlib=bandlib, temps=temps, lgs=lgs)
+                       bandlib=bandlib, temps=temps, lgs=lgs, inpath=inpath)
     return lp + lh
 
 

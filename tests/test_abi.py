@@ -100,7 +100,9 @@ def test_python_constants_mirror_the_header():
              'MSX_MODE_LOGLIKE': _lib.MODE_LOGLIKE, 'MSX_MODE_LOGPOST': _lib.MODE_LOGPOST, 'MSX_MODE_CHISQ': _lib.MODE_CHISQ,
              'MSX_MODE_LOGPRIOR': _lib.MODE_LOGPRIOR, 'MSX_BLOCK_512_SHARED': _lib.BLOCK_512_SHARED,
              'MSX_PATH_AUTO': _lib.PATH_AUTO, 'MSX_PATH_FUSED': _lib.PATH_FUSED, 'MSX_PATH_PAIR': _lib.PATH_PAIR,
-             'MSX_PATH_LINKED': _lib.PATH_LINKED,
+             'MSX_PATH_LINKED': _lib.PATH_LINKED, 'MSX_PATH_INPATH': _lib.PATH_INPATH,
+             'MSX_BROADEN_STAGING': _lib.BROADEN_STAGING, 'MSX_BROADEN_IN_PATH': _lib.BROADEN_IN_PATH,
+             'MSX_FORM_FUSED': _lib.FORM_FUSED, 'MSX_FORM_PAIR': _lib.FORM_PAIR, 'MSX_FORM_LINKED': _lib.FORM_LINKED, 'MSX_FORM_INPATH': _lib.FORM_INPATH,
              'MSX_HOOK_LINKED_FAULT': _lib.HOOK_LINKED_FAULT,
              'MSX_MAX_SPEC': _lib.MAX_SPEC, 'MSX_MAX_BANDS': _lib.MAX_BANDS, 'MSX_MAX_DIM': _lib.MAX_DIM}
     for name, val in pairs.items():

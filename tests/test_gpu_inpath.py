@@ -1,0 +1,80 @@
+"""In-path broadening (include/msx.h, MSX_PATH_INPATH; SURVEY A3 placement (ii)): the instrumental broadening applied per
+walker to the unreddened composite inside the data window, instead of once per grid node at staging.  Broadening is
+linear, so the form must agree with the default one to the order of the sums -- and with the oracle's restatement of the
+same placement (oracle/mft6_oracle.py, loglikelihood(inpath=...)) to the usual 1e-9."""
+import sys
+
+import numpy as np
+import pytest
+
+import common
+from common import rel_err
+
+sys.path.insert(0, common.ROOT)
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope='module')
+def work():
+    from bench import build_workload
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    W = build_workload(eng, 4096, False, keep_host_grid=True, broaden='in_path')
+    return eng, W
+
+
+def test_inpath_matches_the_staging_placement_and_the_oracle(work):
+    from mcmc_spec_amd import _lib, synth
+    from oracle import mft6_oracle as orc
+    eng, W = work
+    th = synth.draw_walkers(300, seed=11, tmin=W['tmin'], tmax=W['tmax'])
+    th[1, 2] = 0.0          # unreddened
+    th[2, 0] = 3800.0       # on a Teff node
+    th[3, 3] = 0.04         # rejected by the prior box
+    th[4, 1] = 2000.0       # outside the isochrone: ValueError status (never reaches the in-path kernels' output)
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    ref, st_ref = eng.ctx.logprob_batch(th, _lib.MODE_LOGPOST)
+    ll_ref, _ = eng.ctx.logprob_batch(th, _lib.MODE_LOGLIKE)
+    eng.ctx.set_path(_lib.PATH_INPATH)
+    got, st = eng.ctx.logprob_batch(th, _lib.MODE_LOGPOST)
+    ll, _ = eng.ctx.logprob_batch(th, _lib.MODE_LOGLIKE)
+    assert eng.ctx.last_form() == _lib.FORM_INPATH and 'GIVEN' in eng.ctx.launch_info(300)['kernel']
+    assert np.array_equal(st, st_ref) and np.isneginf(got[3]) and st[4] != 0
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin) and fin.sum() == 298
+    e = rel_err(got[fin], ref[fin]).max()
+    e_ll = rel_err(ll[fin], ll_ref[fin]).max()
+    print('in-path against the staging placement: max relative difference', e, '(log-likelihood alone', e_ll, ')')
+    assert e < 1e-11 and e_ll < 1e-11
+    # the oracle's restatement of the same placement: composite of the RAW nodes, broadened per evaluation
+    raw = synth.grid_to_specs(W['teffs'], W['loggs'], W['wl'], W['flux'])
+    specs = orc.broaden_specs_window(raw, W['win'], W['resolution'])
+    bl = orc.make_band_library(W['tabs'], *W['vega'])
+    pick = [0, 1, 2, 5, 6, 7]
+    want = np.array([orc.loglikelihood(list(th[k]), W['fr'], 2, W['data'], W['err'], W['r'], specs, W['ctm'], W['ptm'], W['tmi'],
+                                       W['tma'], W['matrix'], bandlib=bl,
+                                       inpath=dict(specs_raw=raw, w=W['win'], resolution=W['resolution'])) for k in pick])
+    assert rel_err(ll[pick], want).max() < TIGHT
+    # sub-batches (the form's scratch holds ~1,300 walkers of this problem), permutations: a walker's value is its own
+    big = synth.draw_walkers(3000, seed=5, tmin=W['tmin'], tmax=W['tmax'])
+    a = eng.logposterior(big)
+    perm = np.random.default_rng(0).permutation(len(big))
+    assert np.array_equal(eng.logposterior(big[perm]), a[perm]) and np.array_equal(eng.logposterior(big[:7]), a[:7])
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    assert rel_err(a, eng.logposterior(big)).max() < 1e-11
+    assert eng.ctx.last_form() != _lib.FORM_INPATH            # AUTO never takes it
+
+
+def test_inpath_is_refused_without_the_raw_window():
+    from bench import build_workload
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    W = build_workload(eng, 1194, False)                      # staging placement: nothing kept
+    th = synth.draw_walkers(8, seed=1, tmin=W['tmin'], tmax=W['tmax'])
+    eng.ctx.set_path(_lib.PATH_INPATH)
+    with pytest.raises(_lib.MsxError):
+        eng.logposterior(th)
+    eng.ctx.set_path(_lib.PATH_AUTO)
+    assert np.all(np.isfinite(eng.logposterior(th)))

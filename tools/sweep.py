@@ -29,7 +29,7 @@ def main():
     from mcmc_spec_amd.engine import Engine
     dev = torch.device('cuda', 0)
     eng = Engine(0)
-    W = build_workload(eng, args.npix, args.phot)
+    W = build_workload(eng, args.npix, args.phot, broaden='in_path' if 'inpath' in args.paths.split(',') else 'staging')
     b_alg = 2 * 4 * W['nwin'] * 8 + 56
     stream = torch.cuda.current_stream(dev)
     rows = []
@@ -43,7 +43,8 @@ def main():
         lp = torch.empty(n, dtype=torch.float64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
         for path in args.paths.split(','):
-          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'linked': _lib.PATH_LINKED, 'pair': _lib.PATH_PAIR}[path])
+          eng.ctx.set_path({'auto': _lib.PATH_AUTO, 'fused': _lib.PATH_FUSED, 'linked': _lib.PATH_LINKED, 'pair': _lib.PATH_PAIR,
+                             'inpath': _lib.PATH_INPATH}[path])   # (inpath: the broadening applied per walker, include/msx.h)
           for B in [int(x) for x in args.blocks.split(',')]:
             def go(sp):
                 eng.ctx.logprob_batch_dev(th.data_ptr(), n, 6, lp.data_ptr(), st.data_ptr(), sp, _lib.MODE_LOGPOST, B)
