@@ -66,6 +66,26 @@ def test_inpath_matches_the_staging_placement_and_the_oracle(work):
     assert eng.ctx.last_form() != _lib.FORM_INPATH            # AUTO never takes it
 
 
+def test_inpath_on_config_4s_share():
+    """16,384 px + 6 photometric bands: a window of 69,015 samples and 155 taps (sub-batches of ~390 walkers), the band terms
+    through the fused kernel's own recipe."""
+    from bench import build_workload
+    from mcmc_spec_amd import _lib, synth
+    from mcmc_spec_amd.engine import Engine
+    eng = Engine(0)
+    W = build_workload(eng, 16384, True, broaden='in_path')
+    th = synth.draw_walkers(500, seed=4, tmin=W['tmin'], tmax=W['tmax'])
+    th[7, 2] = 0.0
+    eng.ctx.set_path(_lib.PATH_FUSED)
+    ref = eng.logposterior(th)
+    eng.ctx.set_path(_lib.PATH_INPATH)
+    got = eng.logposterior(th)
+    assert eng.ctx.last_form() == _lib.FORM_INPATH
+    e = rel_err(got, ref).max()
+    print('config 4 share, in-path against the staging placement:', e)
+    assert np.all(np.isfinite(ref)) and e < 1e-11
+
+
 def test_inpath_is_refused_without_the_raw_window():
     from bench import build_workload
     from mcmc_spec_amd import _lib, synth

@@ -26,3 +26,6 @@ python tools/soak_pair.py --batches 300 > $dst/${tag}_soak_pair.txt 2>&1
 python tools/soak_pair.py --batches 150 --npix 1194 --seed 2 2>&1 | tail -1 >> $dst/${tag}_soak_pair.txt
 python tools/soak_pair.py --batches 100 --phot --seed 3 2>&1 | tail -1 >> $dst/${tag}_soak_pair.txt
 ls -la $dst
+# the in-path broadening form beside the fused kernel
+tools/prof_inpath.sh $tag > /dev/null 2>&1; cp $root/gpurun_out/${tag}_inpath.txt $dst/${tag}_inpath.txt
+ls -la $dst
