@@ -517,12 +517,8 @@ int launch_inpath(msx_ctx *c, const DevProblem &P, const LaunchArgs &A) {
                        (const unsigned char *)c->d_recipe_block, A.niso_nt, A.ng_mode_fast, m, P.tmin, P.tmax, c->d_inp_rec, P);
     HIP_TRY(c, hipGetLastError());
     const size_t lds = sizeof(double) * ((size_t)c->raw_lx + ((size_t)(kConvTile + c->raw_lx - 1) * 5) / 4 + 2);
-    if (lds > 150 * 1024) return fail(c, MSX_ERR_RANGE, "in-path broadening: kernel too long for the LDS tile");
-    static bool raised = false;  // (once per process; the limit is per function)
-    if (lds > 64 * 1024 && !raised) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)inpath_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        raised = true;
-    }
+    // (the tile fits: checked, and the kernel's dynamic-LDS limit raised, at msx_stage_problem -- a launch neither allocates nor
+    // changes function attributes, so that it can be captured like the others)
     hipLaunchKernelGGL(inpath_conv_kernel, dim3((unsigned)((nwin + kConvTile - 1) / kConvTile), (unsigned)m), dim3(256), lds, A.s,
                        c->d_raw_win, nwin, c->d_inp_rec, c->d_inp_tmp, nwin, nwin, c->raw_lx, c->raw_dx, c->raw_sigma);
     HIP_TRY(c, hipGetLastError());
@@ -1000,6 +996,10 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
             HIP_TRY(c, hipMalloc((void **)&c->d_inp_rec, sizeof(InpathRec) * rows_i));
             HIP_TRY(c, hipMalloc((void **)&c->d_inp_tmp, sizeof(double) * rows_i * c->raw_n));
             HIP_TRY(c, hipMalloc((void **)&c->d_inp_given, sizeof(double) * rows_i * gstride));
+            const size_t lds_conv = sizeof(double) * ((size_t)c->raw_lx + ((size_t)(kConvTile + c->raw_lx - 1) * 5) / 4 + 2);
+            if (lds_conv > 150 * 1024) return fail(c, MSX_ERR_RANGE, "in-path broadening: kernel too long for the LDS tile");
+            if (lds_conv > 48 * 1024)
+                HIP_TRY(c, hipFuncSetAttribute((const void *)inpath_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             c->inp_rows = rows_i; c->inp_gstride = gstride;
         }
     }
