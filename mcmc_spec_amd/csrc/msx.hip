@@ -1172,11 +1172,11 @@ int msx_stage_problem(msx_ctx *c, const msx_problem *p) {
         c->h_pair_stats[0] = 1; c->h_pair_stats[1] = 0;  // (nothing known yet: try)
         c->pair_auto_launches = 0;
         c->pair_rows = rows;
-        // From where the pair form pays (the planner costs 10.6 us whatever the batch; 14.6 before its searches went 4-ary
+        // From where the pair form pays (the planner costs 10.4 us whatever the batch; 14.6 before its searches went 4-ary
         // and side by side, round 4): measured on 256 CUs in one process, fused (FULL variants) against pair, us per batch
-        // -- 4096 px (profiles/r4_crossover_4096px.jsonl): 1,024 walkers 40.0 / 42.3, 1,536: 50.1 / 49.3, 2,048: 61.1 / 56.8,
-        // 2,304: 66.4 / 61.4, 3,072: 86.0 / 73.4, 4,096: 111.0 / 89.4.  1194 px (r4_crossover_1194px.jsonl): 2,304 walkers
-        // 46.6 / 46.3, 3,072: 56.2 / 53.1, 4,096: 72.2 / 63.9, 6,144: 104.3 / 85.2.  In walkers per CU: 8 for the long
+        // -- 4096 px (profiles/r4_crossover_4096px.jsonl): 1,024 walkers 39.6 / 42.2, 1,536: 49.7 / 48.9, 2,048: 61.4 / 57.2,
+        // 2,304: 66.9 / 61.6, 3,072: 85.2 / 73.5, 4,096: 109.5 / 89.6.  1194 px (r4_crossover_1194px.jsonl): 2,304 walkers
+        // 45.8 / 45.7, 3,072: 55.4 / 53.2, 4,096: 72.2 / 64.0, 6,144: 104.5 / 85.7.  In walkers per CU: 8 for the long
         // spectra, 12 for the short ones.
         {
             const int64_t cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
