@@ -920,6 +920,20 @@ def main():
                 'kernel': inf32['kernel'].split(' (')[0], 'requested_bytes_per_eval': inf32['requested_bytes_per_eval'],
                 'note': 'labelled precision: R stored in float32 (2^-24 on the grid values), float64 arithmetic; plain launches back '
                         'to back, HIP events; BASELINE tolerance 1e-6 relative'}
+            # the broadening placed INSIDE the evaluation (include/msx.h, MSX_PATH_INPATH): a form of its own,
+            # never the automatic choice -- timed beside the default form in the same loop, values compared
+            ein = Engine(local)
+            build_workload(ein, args.npix, False, grid=W.get('flux'), broaden='in_path')
+            ein.ctx.set_path(_lib.PATH_INPATH)
+            us_in = device_time_us(ein, t32, lp_, st_, stream, n, 100)
+            g_in, _ = ein.ctx.logprob_batch(th32, _lib.MODE_LOGPOST)
+            extra['in_path_broadening'] = {
+                'walkers': n, 'device_us': us_in, 'evals_per_s': n / us_in * 1e6, 'device_us_default_form_same_loop': us64,
+                'max_rel_dev_from_default_placement': float(np.max(np.abs(g_in[fin] - g64[fin]) / np.abs(g64[fin]))),
+                'kernel': ein.ctx.launch_info(n)['kernel'].split(' (')[0],
+                'note': 'mft6.py:124-152 applied per walker to the unreddened composite inside the data window (the call the reference '
+                        'keeps commented out at :550, placed as SURVEY A3 (ii)); the default -- and the headline -- broadens per grid '
+                        'node at staging, mft6.py:366-378'}
         if extra:
             out['extra'] = extra
         sys.stdout.flush()
