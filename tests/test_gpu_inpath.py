@@ -98,3 +98,28 @@ def test_inpath_is_refused_without_the_raw_window():
         eng.logposterior(th)
     eng.ctx.set_path(_lib.PATH_AUTO)
     assert np.all(np.isfinite(eng.logposterior(th)))
+    # ... for a triple (the form is the binaries'), and for float32-stored tables, even with the raw window kept
+    from common import golden_case
+    from mcmc_spec_amd import bands
+    c = golden_case('C')
+    e3 = Engine(0)
+    e3.stage_specs(c.specs)
+    w = [float(min(c.data[0])) * 1e4 - 2.0, float(max(c.data[0])) * 1e4 + 2.0]
+    e3.broaden_grid_window(w, 1700.0, 'in_path')
+    e3.stage_problem(c.data, c.err, c.fr, c.r, c.ctm, c.ptm, c.tmi, c.tma, c.matrix, nspec=3, bands=bands.make_bands(c.tables, *c.vega))
+    e3.ctx.set_path(_lib.PATH_INPATH)
+    with pytest.raises(_lib.MsxError):
+        e3.loglikelihood(c.theta)
+    b = golden_case('B')
+    e2 = Engine(0)
+    e2.stage_specs(b.specs)
+    e2.broaden_grid_window(w, 1700.0, 'in_path')
+    kw = dict(nspec=2, bands=bands.make_bands(b.tables, *b.vega))
+    e2.stage_problem(b.data, b.err, b.fr, b.r, b.ctm, b.ptm, b.tmi, b.tma, b.matrix, store='f32', **kw)
+    e2.ctx.set_path(_lib.PATH_INPATH)
+    with pytest.raises(_lib.MsxError):
+        e2.loglikelihood(b.theta)
+    e2.stage_problem(b.data, b.err, b.fr, b.r, b.ctm, b.ptm, b.tmi, b.tma, b.matrix, **kw)   # float64 again: the form is there
+    got = e2.loglikelihood(b.theta)
+    e2.ctx.set_path(_lib.PATH_FUSED)
+    assert e2.ctx.last_form() == _lib.FORM_INPATH and rel_err(got, e2.loglikelihood(b.theta)).max() < 1e-11
