@@ -202,7 +202,7 @@ struct ChiElem {
                 cu[j] = nu[SET][j]; cf[j] = nf[SET][j];
                 if (FLDS) {
                     int e = (base >> 1) + j * MAXT + (int)threadIdx.x;
-                    e = e < ne ? e : ne - 1;
+                    e = (FULL || e < ne) ? e : ne - 1;
                     cf[j] = f2[e];  // LDS (f2 is the workgroup's staged copy, indexed by the element's own number)
                 }
             }
@@ -291,7 +291,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 //        pass and the candidates' gather.  Same arithmetic on the same pixels: same bits (the launcher picks it; msx.hip,
 //        choose_variant).  Which bits pay was measured per workgroup size (same box, alternating runs): the 256-thread
 //        variants gain from both (2,048 walkers 63.3 -> 60.4 us), the 512-thread headline variant gains from the chi^2
-//        pass's (14.63 -> 14.36 us per step) and LOSES with the blend's (14.67 -> 14.96: the loads' order changed).
+//        pass's (14.63 -> 14.36 us per step) and LOSES with the blend's (14.67 -> 14.96: the loads' order changed); the
+//        two-per-CU and the linked 512-thread variants likewise (config 4's share 26.2 -> 25.8 us with bit 1, 26.4 with both).
 // GIVEN = the model values are not blended here: the in-path broadening kernels (inpath_kernels.h) have left them in
 //        P.given[walker][pixel]; everything else -- recipe (for the walker's status, its prior and band terms), fit sums,
 //        median, chi^2 pass -- is this kernel's.  One variant: 512 threads, quad trips.
@@ -863,7 +864,7 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         // (the element's "npix" is this segment's end: pixels beyond it are not this workgroup's, and the canonical sum
         // of ONE segment has no fold)
         const int p_lo = myseg * (2 * kSegElems), p_hi = (p_lo + 2 * kSegElems < npix) ? p_lo + 2 * kSegElems : npix;
-        ChiElem<MAXT, false, true, true, true> ce{P.u2, lds_lf2, P.iv2, ne, p_hi, 0.0, 0.0, 0.0, {}, true, &red[0][0][0], {}, {}, {}, 0.0};
+        ChiElem<MAXT, false, true, true, true, (FULL & 2) != 0> ce{P.u2, lds_lf2, P.iv2, ne, p_hi, 0.0, 0.0, 0.0, {}, true, &red[0][0][0], {}, {}, {}, 0.0};
         ce.prime_from(p_lo);
         if (tid == 0) {
             // (test hook: nobody signals, so every wait below runs into its bound)
@@ -928,11 +929,11 @@ logprob_kernel(const double *theta, const unsigned char *__restrict__ rblk, int 
         const bool direct = frange_applicable(fmin_, fmax_) && logbin_locate_h<MAXT>(npix, fmin_, S, &Q);
         if (direct) {
             const unsigned int sel_p = Q.sel_p, nxt_p = Q.nxt_p;
-            pass_trips_range<MAXT>(model, p_lo, p_hi, ce, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
+            pass_trips_range<MAXT, (FULL & 2) != 0>(model, p_lo, p_hi, ce, [&](const int (&p)[4], const double (&xv)[4]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const unsigned int pb = logbin(xv[u]);
-                    if (p[u] < p_hi && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
+                    if (((FULL & 2) != 0 || p[u] < p_hi) && (pb == sel_p || pb == nxt_p)) S.cand[atomicAdd(&S.cand_n, 1u)] = key_of(xv[u]);
                 }
             });
             ce.flush(S);

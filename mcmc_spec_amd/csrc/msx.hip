@@ -406,6 +406,10 @@ const Variant kVariants[] = {
     MSX_VF(256, true, false, kFull256, "two per CU, four pixels per lane and trip; whole trips, no clamps"),
     MSX_VF(256, true, true, kFull256, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps"),
     MSX_VF(512, false, true, 2, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps in the chi^2 pass"),
+    MSX_VF(512, true, false, 2, "<= 128 VGPRs: two workgroups fit a CU; rows one star at a time; whole trips, no clamps in the chi^2 pass"),
+    // the linked form for whole-trip segments: no clamps in the segment's chi^2 pass and candidates' gather
+    {(const void *)logprob_kernel<2, 2, 512, false, false, false, true, false, 2>, 2, 512, false, false, false, true, false, 2,
+     "linked: one workgroup per walker and 8192-pixel segment; whole trips, no clamps in the chi^2 pass"},
     // in-path broadening (inpath_kernels.h): the model values are given, the blend is compiled out
     {(const void *)logprob_kernel<2, 2, 512, false, false, false, false, false, 0, true>, 2, 512, false, false, false, false, false, 0,
      "model values given by the in-path broadening kernels; four pixels per lane and trip", true},
@@ -437,7 +441,10 @@ VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, i
     // PF adds u and the data flux in the tables' pair layout
     const size_t lds_pf = sizeof(double) * (size_t)((P.npix + 1) & ~1ll) + 2 * sizeof(double2) * (size_t)P.npair;
     const int ns = P.nspec == 2 ? 2 : 3;
-    if (LK) return {find_variant(ns, 512, false, false, false, true), lds};
+    if (LK) {
+        const bool full_lk = ns == 2 && c->use_full && P.npix == 2 * P.npair && P.npair % 1024 == 0;
+        return {find_variant(ns, 512, false, false, false, true, false, full_lk ? 2 : 0), lds};
+    }
     // spectra longer than the LDS: the model vector lives in the global scratch (the kernel writes it there itself)
     if (c->model_in_global) return {find_variant(ns, 512, true, false, false, false), 0};
     // pixel statics staged in LDS (PF): 512-thread workgroups that own their CU and whose 3 npix doubles fit
@@ -469,6 +476,8 @@ VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, i
     }
     if (ns == 2 && B == 512 && pf && c->use_full && P.npix == 2 * P.npair && P.npair % 1024 == 0)
         return {find_variant(2, 512, false, false, true, false, false, 2), lds_pf};
+    if (ns == 2 && B == 512 && sh && c->use_full && P.npix == 2 * P.npair && P.npair % 1024 == 0)
+        return {find_variant(2, 512, false, true, false, false, false, 2), lds};
     if (ns == 2) {
         // 256 threads, at most two walkers per CU (config 5's 512 x 1194 px): the variant compiled for two workgroups per
         // CU has the registers for quad trips (16.0 against 16.3 us); beyond, three per CU matter more (MSX_Q256=1 / 0 forces)
