@@ -407,6 +407,8 @@ const Variant kVariants[] = {
     MSX_VF(256, true, true, kFull256, "two per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps"),
     MSX_VF(512, false, true, 2, "one workgroup per CU, u / flux staged in LDS during the recipe, four pixels per lane and trip; whole trips, no clamps in the chi^2 pass"),
     MSX_VF(512, true, false, 2, "<= 128 VGPRs: two workgroups fit a CU; rows one star at a time; whole trips, no clamps in the chi^2 pass"),
+    {(const void *)logprob_kernel<2, 2, 512, false, false, true, false, true, 2>, 2, 512, false, false, true, false, true, 2,
+     "float32-stored grid table R; one workgroup per CU, u / flux staged in LDS; whole trips, no clamps in the chi^2 pass"},
     // the linked form for whole-trip segments: no clamps in the segment's chi^2 pass and candidates' gather
     {(const void *)logprob_kernel<2, 2, 512, false, false, false, true, false, 2>, 2, 512, false, false, false, true, false, 2,
      "linked: one workgroup per walker and 8192-pixel segment; whole trips, no clamps in the chi^2 pass"},
@@ -461,6 +463,8 @@ VariantChoice choose_variant(const msx_ctx *c, const DevProblem &P, int64_t n, i
         if (B == 256 && q256 && c->pf256_ok && c->use_pf) return {find_variant(2, 256, false, true, true, false, true), lds_pf};
         if (B == 256 && q256) return {find_variant(2, 256, false, true, false, false, true), lds};
         if (B == 256) return {find_variant(2, 256, false, false, false, false, true), lds};
+        if (pf && c->use_full && P.npix == 2 * P.npair && P.npair % 1024 == 0)
+            return {find_variant(2, 512, false, false, true, false, true, 2), lds_pf};
         if (pf) return {find_variant(2, 512, false, false, true, false, true), lds_pf};
         if (sh) return {find_variant(2, 512, false, true, false, false, true), lds};
         return {find_variant(2, 512, false, false, false, false, true), lds};
